@@ -1,0 +1,233 @@
+// ref_shim.cpp -- extern "C" doorway onto the REAL reference templates.
+//
+// TEST INFRASTRUCTURE ONLY.  This translation unit is compiled against the
+// reference headers where they lie (-I/root/reference/include, see Makefile)
+// into oracle/_ref/libsmref.so.  It contains no reference code: it only calls
+// the reference's own element_wise_op / array_scalar_op / dot_product /
+// sm::broadcast / SMArray operators so that tests/golden/make_golden.py can
+// record their outputs and tests/test_oracle.py can compare the restatement
+// (sm_oracle.c) with them.  /root/reference does not exist on the GPU box;
+// the prebuilt .so travels, the headers do not.
+//
+// Build flags are the only ones the reference compiles with:
+//   g++ -std=c++20 -O3 -fopenmp -mavx2 -mfma
+#include <sm.h>
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+namespace {
+
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_DIV = 3, OP_POW = 4 };
+enum { DT_F32 = 0, DT_F64 = 1, DT_I32 = 2 };
+
+std::vector<size_t> vec(const size_t *p, int n) { return std::vector<size_t>(p, p + n); }
+
+template <typename T>
+int elementwise_t(int op, const T *a, const std::vector<size_t> &sa, const T *b,
+                  const std::vector<size_t> &sb, size_t n, T *r, const std::vector<size_t> &shape) {
+    switch (op) {
+        case OP_ADD: element_wise_op<T, AddOp<T>>(a, sa, b, sb, n, r, shape); return 0;
+        case OP_SUB: element_wise_op<T, SubtractOp<T>>(a, sa, b, sb, n, r, shape); return 0;
+        case OP_MUL: element_wise_op<T, MultiplyOp<T>>(a, sa, b, sb, n, r, shape); return 0;
+        case OP_DIV: element_wise_op<T, DivideOp<T>>(a, sa, b, sb, n, r, shape); return 0;
+    }
+    return -1;
+}
+
+template <typename T>
+int scalar_t(int op, const T *a, T v, size_t n, T *r) {
+    switch (op) {
+        case OP_ADD: array_scalar_op<T, AddOp<T>>(a, v, n, r); return 0;
+        case OP_SUB: array_scalar_op<T, SubtractOp<T>>(a, v, n, r); return 0;
+        case OP_MUL: array_scalar_op<T, MultiplyOp<T>>(a, v, n, r); return 0;
+        case OP_DIV: array_scalar_op<T, DivideOp<T>>(a, v, n, r); return 0;
+    }
+    return -1;
+}
+
+template <typename T>
+sm::SMArray<T> owning(const T *src, const size_t *shape, int nd) {
+    std::vector<size_t> sh = vec(shape, nd);
+    size_t n = 1;
+    for (auto d : sh) n *= d;
+    T *buf = new T[n];
+    std::memcpy(buf, src, n * sizeof(T));
+    return sm::SMArray<T>(buf, std::move(sh));
+}
+
+template <typename T>
+int smarray_binary_t(int op, const T *a, const size_t *ashape, int and_, int at, const T *b,
+                     const size_t *bshape, int bnd, int bt, T *out, size_t *oshape, int *ond) {
+    auto A = owning(a, ashape, and_);
+    auto B = owning(b, bshape, bnd);
+    auto run = [&](const sm::SMArray<T> &x, const sm::SMArray<T> &y) {
+        auto apply = [&]() {
+            switch (op) {
+                case OP_ADD: return x + y;
+                case OP_SUB: return x - y;
+                case OP_MUL: return x * y;
+                default: return x / y;
+            }
+        };
+        auto r = apply();
+        const auto &rs = r.shape();
+        *ond = (int)rs.size();
+        size_t n = 1;
+        for (size_t i = 0; i < rs.size(); ++i) { oshape[i] = rs[i]; n *= rs[i]; }
+        std::memcpy(out, r.data, n * sizeof(T));
+    };
+    if (at && bt) { auto x = A.transpose(); auto y = B.transpose(); run(x, y); }
+    else if (at) { auto x = A.transpose(); run(x, B); }
+    else if (bt) { auto y = B.transpose(); run(A, y); }
+    else run(A, B);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// sm::broadcast (include/SMUtils.h:34-99). Returns rank, -1 if it threw.
+int ref_broadcast(int nd1, const size_t *shape1, const size_t *strides1, int nd2,
+                  const size_t *shape2, const size_t *strides2, size_t *result_shape,
+                  size_t *new_strides1, size_t *new_strides2, size_t *total_size) {
+    try {
+        auto r = sm::broadcast(vec(shape1, nd1), vec(strides1, nd1), vec(shape2, nd2), vec(strides2, nd2));
+        const int nd = (int)r.resultShape.size();
+        for (int i = 0; i < nd; ++i) {
+            result_shape[i] = r.resultShape[i];
+            new_strides1[i] = r.newStrides1[i];
+            new_strides2[i] = r.newStrides2[i];
+        }
+        *total_size = r.totalSize;
+        return nd;
+    } catch (const std::runtime_error &) {
+        return -1;
+    }
+}
+
+int ref_is_contiguous(int ndim, const size_t *shape, const size_t *stride) {
+    return is_contiguous(vec(shape, ndim), vec(stride, ndim)) ? 1 : 0;
+}
+
+// element_wise_op<T,Op> (include/math/calculate.h:5-99)
+int ref_elementwise(int op, int dtype, const void *a, const size_t *sa, const void *b,
+                    const size_t *sb, size_t n, void *r, const size_t *shape, int ndim) {
+    auto SA = vec(sa, ndim), SB = vec(sb, ndim), SH = vec(shape, ndim);
+    switch (dtype) {
+        case DT_F32: return elementwise_t<float>(op, (const float *)a, SA, (const float *)b, SB, n, (float *)r, SH);
+        case DT_F64: return elementwise_t<double>(op, (const double *)a, SA, (const double *)b, SB, n, (double *)r, SH);
+        case DT_I32: return elementwise_t<int32_t>(op, (const int32_t *)a, SA, (const int32_t *)b, SB, n, (int32_t *)r, SH);
+    }
+    return -1;
+}
+
+// array_scalar_op<T,Op> (calculate.h:137-169); pow only for int32 -- the
+// float/double PowOp::apply_simd symbols do not exist (pow.h:12-13).
+int ref_array_scalar(int op, int dtype, const void *a, const void *value, size_t n, void *r) {
+    if (op == OP_POW) {
+        if (dtype != DT_I32) return -2;
+        array_scalar_op<int, PowOp<int>>((const int *)a, *(const int *)value, n, (int *)r);
+        return 0;
+    }
+    switch (dtype) {
+        case DT_F32: return scalar_t<float>(op, (const float *)a, *(const float *)value, n, (float *)r);
+        case DT_F64: return scalar_t<double>(op, (const double *)a, *(const double *)value, n, (double *)r);
+        case DT_I32: return scalar_t<int32_t>(op, (const int32_t *)a, *(const int32_t *)value, n, (int32_t *)r);
+    }
+    return -1;
+}
+
+// PowOp<T>::apply per element (pow.h:8-10): the only float pow arithmetic the
+// reference defines.
+int ref_pow_apply(int dtype, const void *a, const void *value, size_t n, void *r) {
+    if (dtype == DT_F32) {
+        const float v = *(const float *)value;
+        for (size_t i = 0; i < n; ++i) ((float *)r)[i] = PowOp<float>::apply(((const float *)a)[i], v);
+        return 0;
+    }
+    if (dtype == DT_F64) {
+        const double v = *(const double *)value;
+        for (size_t i = 0; i < n; ++i) ((double *)r)[i] = PowOp<double>::apply(((const double *)a)[i], v);
+        return 0;
+    }
+    return -1;
+}
+
+// dot_product<T> (include/math/product.h)
+int ref_dot(int dtype, const void *a, const void *b, size_t n, void *out) {
+    switch (dtype) {
+        case DT_F32: *(float *)out = dot_product<float>((const float *)a, (const float *)b, n); return 0;
+        case DT_F64: *(double *)out = dot_product<double>((const double *)a, (const double *)b, n); return 0;
+        case DT_I32: *(int *)out = dot_product<int>((const int *)a, (const int *)b, n); return 0;
+    }
+    return -1;
+}
+
+// SMArray<T>::operator+,-,*,/ on dense owning arrays, each optionally viewed
+// through transpose() (include/SMArray.h:121-136, 217-305).  Returns -1 if
+// broadcast threw.
+int ref_smarray_binary(int op, int dtype, const void *a, const size_t *ashape, int and_, int at,
+                       const void *b, const size_t *bshape, int bnd, int bt, void *out,
+                       size_t *oshape, int *ond) {
+    try {
+        switch (dtype) {
+            case DT_F32: return smarray_binary_t<float>(op, (const float *)a, ashape, and_, at, (const float *)b, bshape, bnd, bt, (float *)out, oshape, ond);
+            case DT_F64: return smarray_binary_t<double>(op, (const double *)a, ashape, and_, at, (const double *)b, bshape, bnd, bt, (double *)out, oshape, ond);
+            case DT_I32: return smarray_binary_t<int>(op, (const int *)a, ashape, and_, at, (const int *)b, bshape, bnd, bt, (int *)out, oshape, ond);
+        }
+    } catch (const std::runtime_error &) {
+        return -1;
+    }
+    return -2;
+}
+
+// The 4-D broadcast-through-a-view scenario of the reference's own tests
+// (tests/add.cpp:59-92 and siblings): big(d0,d1,d2,d3)(0, SLICE_ALL) op
+// small(1,d1,1,d3).  out holds d1*d2*d3 floats; oshape receives the rank-4
+// result shape.
+int ref_view_broadcast4(int op, const float *big, const size_t *bigshape, const float *small_,
+                        float *out, size_t *oshape) {
+    auto A = owning(big, bigshape, 4);
+    size_t sshape[4] = {1, bigshape[1], 1, bigshape[3]};
+    auto B = owning(small_, sshape, 4);
+    auto view = A(0, SLICE_ALL);
+    auto fin = [&](const sm::SMArray<float> &r) {
+        size_t n = 1;
+        for (size_t i = 0; i < r.shape().size(); ++i) { oshape[i] = r.shape()[i]; n *= r.shape()[i]; }
+        std::memcpy(out, r.data, n * sizeof(float));
+        return (int)r.shape().size();
+    };
+    switch (op) {
+        case OP_ADD: return fin(view + B);
+        case OP_SUB: return fin(view - B);
+        case OP_MUL: return fin(view * B);
+        case OP_DIV: return fin(view / B);
+    }
+    return -1;
+}
+
+// CPU-baseline helpers: the reference's public operator path exactly as its
+// benchmark drives it (benchmark/add.cpp:21-29): result allocated with new[]
+// inside the call and freed by the destructor.
+double ref_bench_add_f32(const float *a, const float *b, size_t n) {
+    // Wrap the borrowed buffers without copying; the owning ctor is the only
+    // public one, so `data` is nulled before the destructors run.
+    size_t shape[1] = {n};
+    std::vector<size_t> sh1(shape, shape + 1), sh2(shape, shape + 1);
+    sm::SMArray<float> A(const_cast<float *>(a), std::move(sh1));
+    sm::SMArray<float> B(const_cast<float *>(b), std::move(sh2));
+    double probe;
+    {
+        auto r = A + B;
+        probe = r.data[n / 2];
+    }
+    A.data = nullptr;  // do not let the destructors delete[] borrowed memory
+    B.data = nullptr;
+    return probe;
+}
+
+}  // extern "C"
