@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+metric   "Gelem/s" of the contiguous float32 add c = a + b (BASELINE.json `metric`,
+         configs[1]): one step = one pass of smhip_contiguous over N = 2^28 elements,
+         inputs already resident in HBM (generated on device by the counter-based
+         hash), output preallocated.
+N GPUs   one process per GPU; each rank owns one outer-dimension shard of 2^28 elements
+         of the N * 2^28 array (config 5's partitioning) -- elementwise work has no
+         data-path collective, so scaling is "weak" and value = all ranks' elements / time.
+         The reduction path of config 5 (fused add + sum, then ONE RCCL all-reduce of an
+         fp64 scalar over xGMI) is timed after the headline region and reported under "c5".
+roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024>;
+         algorithmic bytes 12 B/elem (2 reads + 1 write) * 2^28 = 3 221 225 472 B per launch;
+         duration = HIP events (smhip_event_*, recorded on the stream the kernel runs on)
+         over the timed region / launches; peak = 8000 GB/s (MI355X HBM3E spec).
+cpu_baseline  rank 0, N = 1 only: the reference's own operator path (oracle/_ref, kind
+         "reference": SMArray<float>::operator+ exactly as benchmark/add.cpp drives it, result
+         new[]-allocated inside the call, one core) if the prebuilt .so travelled, else the
+         oracle's restatement (kind "port"); on a bounded 2^26-element sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BASELINE_METRIC = "Gelem/s + achieved HBM GB/s (% of peak), float32 add N=2^28, 1/2/4/8 GPU"  # BASELINE.json
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (bytes per element, description)
+    "add": (12, "1D float32 add, N=2^28, contiguous (BASELINE config 2)"),
+    "bcast_mul": (None, "2D float32 (4096x4096) * (1x4096) broadcast multiply (BASELINE config 3)"),
+    "pow": (8, "1D float32 pow(a, 2.5), N=2^26 (BASELINE config 4)"),
+    "add_sum": (12, "1D float32 fused add + sum, 2^28 per GPU (BASELINE config 5 shard)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="add", choices=sorted(WORKLOADS))
+    ap.add_argument("--log2n", type=int, default=None, help="elements per GPU = 2^log2n (default: the config's size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=26)
+    return ap.parse_args()
+
+
+def cpu_baseline(log2n):
+    """Reference / oracle timed on this box's host cores.  Checker code: used here only
+    as the thing measured BESIDE the GPU, never on the product path."""
+    import numpy as np
+    from oracle import oracle as orc
+
+    n = 1 << log2n
+    o = orc.Oracle()
+    a = o.uniform_f32(n, 1, -1.0, 1.0)
+    b = o.uniform_f32(n, 2, -1.0, 1.0)
+    out = np.empty_like(a)
+
+    def best(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return min(ts), sorted(ts)[len(ts) // 2]
+
+    res = {"unit": "Gelem/s", "sample": f"1D float32 add, N=2^{log2n} of the 2^28 workload, uniform[-1,1) seeds 1/2",
+           "threads_available": o.num_threads()}
+    o.contiguous(orc.ADD, a, b, out=out)  # warm
+    tmin, tmed = best(lambda: o.contiguous(orc.ADD, a, b, out=out), 5)
+    res["port_1core_prealloc"] = n / tmed / 1e9
+    tmin, tmed = best(lambda: o.contiguous(orc.ADD, a, b, out=out, mt=True), 5)
+    res["port_allcores_prealloc"] = n / tmed / 1e9
+    if orc.Reference.available():
+        r = orc.Reference()
+        r.bench_add_f32(a, b)
+        tmin, tmed = best(lambda: r.bench_add_f32(a, b), 5)
+        res.update(kind="reference", value=n / tmed / 1e9, cores=1,
+                   note="SMArray<float>::operator+ (SMArray.h:217-225 -> calculate.h:101-134): single thread, "
+                        "result new[]-allocated and first-touched inside the timed call, as benchmark/add.cpp times it")
+    else:
+        res.update(kind="port", value=res["port_1core_prealloc"], cores=1,
+                   note="oracle restatement of handle_contiguous_arrays (calculate.h:101-134), single thread as the "
+                        "reference runs it, output preallocated")
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    res["cpu"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    res["nproc"] = os.cpu_count()
+    return res
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run (one rank per GPU)")
+
+    dist = torch = None
+    if world > 1:
+        # torch first: libsmhip must bind to the HIP runtime torch already loaded (one runtime per process)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import simplemath_amd as sma
+
+    lib = sma.load()  # raises if the HIP library is missing: no CPU fallback
+    lib.set_device(local_rank)
+    if torch is not None:
+        lib.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        lib.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    wl = args.workload
+    F32 = np.float32
+    if wl == "add" or wl == "add_sum":
+        log2n = args.log2n or 28
+        n = 1 << log2n
+        first = rank * n  # this rank's shard of the global array
+        a = lib.uniform_f32(n, 1 if wl == "add" else 6, -1.0 if wl == "add" else 0.0, 1.0, first=first)
+        b = lib.uniform_f32(n, 2 if wl == "add" else 7, -1.0 if wl == "add" else 0.0, 1.0, first=first)
+        c = lib.empty((n,), F32)
+        sum_ptr = lib.alloc(8)
+        units, alg_bytes = n, 12 * n
+        if wl == "add":
+            step = lambda: lib.contiguous(sma.OP_ADD, a, b, out=c)
+            kernel = "contiguous_vec_kernel<float, AddOp<float>, 1024>"
+        else:
+            step = lambda: lib.contiguous_sum_async(sma.OP_ADD, a, b, c, sum_ptr)
+            kernel = "reduce_kernel<float, AddOp<float>, kFused>"
+        workload = f"1D float32 {'add' if wl == 'add' else 'fused add+sum'}, N=2^{log2n} per GPU, contiguous, HBM-resident"
+    elif wl == "bcast_mul":
+        rows = cols = 4096
+        A = lib.uniform_f32(rows * cols, 3, -1.0, 1.0)
+        r = lib.uniform_f32(cols, 4, -1.0, 1.0)
+        A2 = sma.DeviceArray(lib, A.base_ptr, F32, (rows, cols), (cols, 1), 0, A._owner)
+        r2 = sma.DeviceArray(lib, r.base_ptr, F32, (1, cols), (cols, 1), 0, r._owner)
+        out = lib.empty((rows, cols), F32)
+        units, alg_bytes = rows * cols, 4 * (2 * rows * cols + cols)
+        step = lambda: lib.binary(sma.OP_MUL, A2, r2, out=out)
+        kernel = "row_kernel<float, MultiplyOp<float>, VEC, 1, 1, false, true, 256, 4>"
+        workload = "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident"
+    else:  # pow
+        log2n = args.log2n or 26
+        n = 1 << log2n
+        a = lib.uniform_f32(n, 5, 0.01, 100.0)
+        out = lib.empty((n,), F32)
+        units, alg_bytes = n, 8 * n
+        step = lambda: lib.array_scalar(sma.OP_POW, a, np.float32(2.5), out=out)
+        kernel = "scalar_vec_kernel<float, PowOp<float>, 1024, false>"
+        workload = f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident"
+
+    for _ in range(args.warmup):
+        step()
+    e0, e1 = lib.event(), lib.event()
+    barrier()
+    t0 = time.perf_counter()
+    lib.record(e0)
+    for _ in range(args.steps):
+        step()
+    lib.record(e1)
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kern_ms = lib.elapsed_ms(e0, e1) / args.steps  # average launch duration, back-to-back on one stream
+
+    if dist is not None:
+        t = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kern_ms = float(t[0]), float(t[1])
+
+    ms_per_step = wall / args.steps * 1e3
+    value = world * units / (wall / args.steps) / 1e9
+
+    # config 5's exchange step: fused add+sum per shard, then ONE all-reduce of the fp64 scalar
+    c5 = None
+    if wl == "add" and world > 1:
+        part = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            lib.contiguous_sum_async(sma.OP_ADD, a, b, c, part.data_ptr())
+            dist.all_reduce(part)
+        barrier()
+        tc = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            lib.contiguous_sum_async(sma.OP_ADD, a, b, c, part.data_ptr())
+            dist.all_reduce(part)
+        barrier()
+        tc = (time.perf_counter() - tc) / reps
+        tt = torch.tensor([tc], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        c5 = {"workload": f"fused add+sum over {world} x 2^{log2n} f32 + one RCCL all-reduce (1 x fp64)",
+              "ms_per_step": float(tt[0]) * 1e3, "value": world * n / float(tt[0]) / 1e9, "unit": "Gelem/s",
+              "global_sum": float(part[0])}
+
+    if rank == 0:
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic = tj.get(wl, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        line = {
+            "metric": BASELINE_METRIC if wl == "add" else f"Gelem/s, {WORKLOADS[wl][1]}",
+            "value": value, "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "elements_per_gpu": units, "sharding": f"outer-dim x{world}, no data-path collective",
+                       "kernel": kernel},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+        }
+        if c5:
+            line["c5"] = c5
+        if world == 1 and not args.no_cpu_baseline and wl == "add":
+            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

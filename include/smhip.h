@@ -1,0 +1,139 @@
+/*
+ * smhip.h -- C ABI of libsmhip.so, the MI355X (gfx950) implementation of
+ * simpleMath's element_wise_op hot path.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++ or
+ * torch types.  Each entry point names the reference interface it stands in
+ * for (file:line in alielmorsy/simpleMath @ 2025-10-10).  The header-only C++
+ * host side (include/sm.h, include/SMArray.h ...) calls these exactly where
+ * the reference calls its loop templates; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - Every function returns SMHIP_OK (0) or a negative smhip_status; nothing
+ *     throws across the boundary.  smhip_last_error() gives the text for the
+ *     calling thread's last failure.
+ *   - `a`, `b`, `out`, `dptr` are DEVICE pointers on the calling thread's
+ *     current device (smhip_set_device) unless a parameter says `_host`.
+ *     The caller owns every buffer; the library keeps no pointer past return.
+ *   - Shapes and strides are in ELEMENTS (like the reference's
+ *     std::vector<size_t>), passed as int64_t; strides must be >= 0.
+ *   - Work is enqueued on the calling thread's stream (smhip_set_stream; the
+ *     library's own per-device stream by default) and is asynchronous unless a
+ *     function returns a value to host memory.
+ *   - Callable from any host thread; device and stream selection are per thread.
+ *   - There is no CPU fallback: without a HIP device every compute entry point
+ *     fails with SMHIP_ERR_NO_DEVICE.
+ */
+#ifndef SMHIP_H
+#define SMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMHIP_MAX_NDIM 6 /* MAX_NDIM, include/math/helpers.h:4 */
+
+typedef enum smhip_status {
+    SMHIP_OK = 0,
+    SMHIP_ERR_INVALID = -1,     /* bad op / dtype / ndim / null pointer / negative stride */
+    SMHIP_ERR_HIP = -2,         /* a HIP runtime call failed; see smhip_last_error() */
+    SMHIP_ERR_NO_DEVICE = -3,   /* no usable gfx950 device */
+    SMHIP_ERR_UNSUPPORTED = -4, /* combination not implemented */
+    SMHIP_ERR_BROADCAST = -5    /* shapes not broadcastable (SMUtils.h:76-78 throws) */
+} smhip_status;
+
+/* Op policy ids: AddOp, SubtractOp, MultiplyOp, DivideOp, PowOp
+ * (include/math/{add,subtract,multiply,division,pow}.h). */
+typedef enum smhip_op {
+    SMHIP_OP_ADD = 0, SMHIP_OP_SUB = 1, SMHIP_OP_MUL = 2, SMHIP_OP_DIV = 3, SMHIP_OP_POW = 4
+} smhip_op;
+
+/* Element types: the SimdTraits<T> specialisations (helpers.h:23-119) plus
+ * int64 (declared TODO at helpers.h:122-127). */
+typedef enum smhip_dtype {
+    SMHIP_F32 = 0, SMHIP_F64 = 1, SMHIP_I32 = 2, SMHIP_I64 = 3
+} smhip_dtype;
+
+/* ------------------------------------------------------------- context */
+const char *smhip_version(void);
+const char *smhip_last_error(void);
+int smhip_device_count(int *count);
+int smhip_set_device(int device);
+int smhip_get_device(int *device);
+/* Use the caller's hipStream_t (e.g. torch's current stream) for this thread;
+ * NULL restores the library's own stream. */
+int smhip_set_stream(void *hip_stream);
+int smhip_get_stream(void **hip_stream);
+int smhip_synchronize(void);
+
+/* -------------------------------------------------------------- memory */
+/* Replaces the per-operator `new T[n]` / `delete[]` (SMArray.h:219, :342-346)
+ * with a pooled device allocator. */
+int smhip_alloc(void **dptr, size_t bytes);
+int smhip_free(void *dptr);
+int smhip_pool_trim(void);
+int smhip_pool_stats(size_t *bytes_in_use, size_t *bytes_cached);
+int smhip_upload(void *dst, const void *src_host, size_t bytes);
+int smhip_download(void *dst_host, const void *src, size_t bytes);
+int smhip_copy(void *dst, const void *src, size_t bytes);
+/* sm::ones / sm::zeros fill (UserFunctions.h:18-40) on device. */
+int smhip_fill(int dtype, void *dst, const void *value_host, size_t n);
+/* Synthetic input: element i = uniform[lo,hi) from a counter-based hash of
+ * (seed, first + i); bit-identical to the CPU checker generator. */
+int smhip_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi);
+
+/* --------------------------------------------------------- shape layer */
+/* sm::broadcast (SMUtils.h:34-99), host only.  Outputs hold max(nd1, nd2)
+ * entries.  Returns the broadcast rank (>= 0) or SMHIP_ERR_BROADCAST. */
+int smhip_broadcast(int nd1, const int64_t *shape1, const int64_t *strides1,
+                    int nd2, const int64_t *shape2, const int64_t *strides2,
+                    int64_t *result_shape, int64_t *new_strides1, int64_t *new_strides2,
+                    int64_t *total_size);
+/* is_contiguous (helpers.h:130-139): 1 / 0. */
+int smhip_is_contiguous(int ndim, const int64_t *shape, const int64_t *strides);
+
+/* ------------------------------------------------------------ hot path */
+/* element_wise_op<T,Op> (calculate.h:5-99): out[linear] = a[sum idx_k*sa_k]
+ * op b[sum idx_k*sb_k], idx from the row-major unravel of `linear` over
+ * `shape`; `out` is dense row-major with prod(shape) elements.  Unlike
+ * calculate.h:10 a 1-D call walks its strides, and
+ * ndim > SMHIP_MAX_NDIM is rejected instead of overflowing (quirk 6). */
+int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
+                      const void *b, const int64_t *stride_b,
+                      const int64_t *shape, int ndim, void *out);
+/* handle_contiguous_arrays<T,Op> (calculate.h:101-134): out[i] = a[i] op b[i]. */
+int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n);
+/* array_scalar_op<T,Op> (calculate.h:137-169): out[i] = a[i] op value; `value_host`
+ * points at one T in host memory.  Also sm::pow (UserFunctions.h:42-48). */
+int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out);
+/* dot_product<T> (product.h:8-224 via SMArray.h:213-215): one T to *out_host.
+ * f32/f64 accumulate in fp64 (the reference's f32 lane accumulators saturate,
+ * SURVEY section 0); i32/i64 wrap exactly like the reference. Synchronous. */
+int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host);
+/* Whole-array sum in fp64 (no reference counterpart; BASELINE config 5). Synchronous. */
+int smhip_sum(int dtype, const void *a, size_t n, double *out_host);
+/* Asynchronous forms leaving the fp64 result in device memory so a multi-GPU
+ * caller can all-reduce it (RCCL) without a host round trip. */
+int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev);
+int smhip_dot_async(int dtype, const void *a, const void *b, size_t n, double *out_dev);
+/* Fused out = a op b and *sum_dev = sum(out) in one pass (config 5: 12 B/elem). */
+int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, void *out, size_t n,
+                               double *sum_dev);
+
+/* -------------------------------------------------------------- timing */
+/* HIP events on the calling thread's stream (what bench.py brackets the
+ * timed region with). */
+int smhip_event_create(void **event);
+int smhip_event_record(void *event);
+int smhip_event_synchronize(void *event);
+int smhip_event_elapsed_ms(void *start, void *stop, float *ms);
+int smhip_event_destroy(void *event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMHIP_H */

@@ -1,0 +1,303 @@
+"""simplemath_amd -- MI355X (gfx950) implementation of simpleMath's element_wise_op hot path.
+
+The product is `libsmhip.so` (HIP kernels behind the C ABI of include/smhip.h) plus the
+header-only C++20 host side in include/ (sm.h, SMArray.h, ...).  This Python package is
+only the thin ctypes binding the tests and bench.py drive the C ABI through -- the same
+entry points the C++ headers call.  There is no CPU fallback anywhere in it: if the
+library or a GPU is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_PATH = os.path.join(PKG, "lib", "libsmhip.so")
+HEADER = os.path.join(ROOT, "include", "smhip.h")
+
+OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_POW = range(5)
+OPS = {"add": OP_ADD, "sub": OP_SUB, "mul": OP_MUL, "div": OP_DIV, "pow": OP_POW}
+F32, F64, I32, I64 = range(4)
+DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int32): I32, np.dtype(np.int64): I64}
+MAX_NDIM = 6
+
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_BROADCAST = -1, -2, -3, -4, -5
+
+
+class SmhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"smhip error {code}: {msg}")
+        self.code = code
+
+
+def declared_symbols():
+    """Every function name include/smhip.h declares."""
+    with open(HEADER) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(smhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def _i64(seq):
+    return (C.c_int64 * max(len(seq), 1))(*[int(x) for x in seq])
+
+
+class DeviceArray:
+    """A (possibly strided) view on device memory: what sm::SMArray<T> holds host-side."""
+
+    def __init__(self, lib, base_ptr, dtype, shape, strides, offset=0, owner=None):
+        self.lib, self.base_ptr, self.dtype = lib, base_ptr, np.dtype(dtype)
+        self.shape, self.strides, self.offset = tuple(int(s) for s in shape), tuple(int(s) for s in strides), int(offset)
+        self._owner = owner if owner is not None else _Owner(lib, base_ptr)
+
+    @property
+    def ptr(self):
+        return self.base_ptr + self.offset * self.dtype.itemsize
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def is_dense(self):
+        exp = 1
+        for d, s in zip(self.shape[::-1], self.strides[::-1]):
+            if s != exp:
+                return False
+            exp *= d
+        return True
+
+    def view_like(self, np_view, np_base):
+        """The same view numpy made on the host base, on the device base."""
+        off = (np_view.__array_interface__["data"][0] - np_base.__array_interface__["data"][0]) // self.dtype.itemsize
+        return DeviceArray(self.lib, self.base_ptr, self.dtype, np_view.shape,
+                           [s // self.dtype.itemsize for s in np_view.strides], off, self._owner)
+
+    def numpy(self):
+        assert self.is_dense(), "download a dense array (views alias their parent)"
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.lib.download(out, self.ptr)
+        return out
+
+
+class _Owner:
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.free(self.ptr)
+        except Exception:
+            pass
+
+
+class Smhip:
+    """ctypes face of include/smhip.h."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: build it with `python -m simplemath_amd.build` "
+                                    "(there is no CPU fallback)")
+        self.path = path
+        self.c = C.CDLL(path)
+        c = self.c
+        c.smhip_version.restype = C.c_char_p
+        c.smhip_last_error.restype = C.c_char_p
+        for name in declared_symbols():
+            fn = getattr(c, name)  # AttributeError here = header/library mismatch
+            if name not in ("smhip_version", "smhip_last_error"):
+                fn.restype = C.c_int
+        c.smhip_fill_uniform_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_float, C.c_float]
+
+    # -- plumbing ---------------------------------------------------------
+    def _ck(self, rc):
+        if rc < 0:
+            raise SmhipError(rc, self.c.smhip_last_error().decode())
+        return rc
+
+    def version(self):
+        return self.c.smhip_version().decode()
+
+    def device_count(self):
+        n = C.c_int(0)
+        self._ck(self.c.smhip_device_count(C.byref(n)))
+        return n.value
+
+    def set_device(self, d):
+        self._ck(self.c.smhip_set_device(C.c_int(d)))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.c.smhip_set_stream(C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.c.smhip_synchronize())
+
+    def alloc(self, nbytes):
+        p = C.c_void_p(0)
+        self._ck(self.c.smhip_alloc(C.byref(p), C.c_size_t(nbytes)))
+        return p.value
+
+    def free(self, ptr):
+        self._ck(self.c.smhip_free(C.c_void_p(ptr)))
+
+    def pool_trim(self):
+        self._ck(self.c.smhip_pool_trim())
+
+    def pool_stats(self):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.c.smhip_pool_stats(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def upload(self, ptr, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        self._ck(self.c.smhip_upload(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes)))
+
+    def download(self, host: np.ndarray, ptr):
+        assert host.flags.c_contiguous
+        self._ck(self.c.smhip_download(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(host.nbytes)))
+
+    # -- arrays -----------------------------------------------------------
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        shape = tuple(int(s) for s in np.atleast_1d(shape))
+        n = int(np.prod(shape, dtype=np.int64))
+        ptr = self.alloc(max(n, 1) * dtype.itemsize)
+        strides, acc = [], 1
+        for d in shape[::-1]:
+            strides.append(acc)
+            acc *= d
+        return DeviceArray(self, ptr, dtype, shape, strides[::-1])
+
+    def to_device(self, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        d = self.empty(host.shape if host.ndim else (1,), host.dtype)
+        self.upload(d.ptr, host)
+        return d
+
+    def full(self, shape, value, dtype):
+        d = self.empty(shape, dtype)
+        v = np.array([value], dtype=dtype)
+        self._ck(self.c.smhip_fill(C.c_int(DTYPES[d.dtype]), C.c_void_p(d.ptr), v.ctypes.data_as(C.c_void_p), C.c_size_t(d.size)))
+        return d
+
+    def uniform_f32(self, n, seed, lo, hi, first=0):
+        d = self.empty((n,), np.float32)
+        self._ck(self.c.smhip_fill_uniform_f32(C.c_void_p(d.ptr), n, seed, first, lo, hi))
+        return d
+
+    # -- shape layer --------------------------------------------------------
+    def broadcast(self, shape1, strides1, shape2, strides2):
+        nd = max(len(shape1), len(shape2))
+        rs, s1, s2 = _i64([0] * nd), _i64([0] * nd), _i64([0] * nd)
+        tot = C.c_int64(0)
+        rc = self.c.smhip_broadcast(C.c_int(len(shape1)), _i64(shape1), _i64(strides1), C.c_int(len(shape2)),
+                                    _i64(shape2), _i64(strides2), rs, s1, s2, C.byref(tot))
+        if rc == ERR_BROADCAST:
+            return None
+        self._ck(rc)
+        return list(rs[:nd]), list(s1[:nd]), list(s2[:nd]), tot.value
+
+    def is_contiguous(self, shape, strides):
+        return bool(self.c.smhip_is_contiguous(C.c_int(len(shape)), _i64(shape), _i64(strides)))
+
+    # -- hot path -------------------------------------------------------------
+    def elementwise_raw(self, op, dtype, a_ptr, sa, b_ptr, sb, shape, out_ptr):
+        self._ck(self.c.smhip_elementwise(C.c_int(op), C.c_int(DTYPES[np.dtype(dtype)]), C.c_void_p(a_ptr), _i64(sa),
+                                          C.c_void_p(b_ptr), _i64(sb), _i64(shape), C.c_int(len(shape)), C.c_void_p(out_ptr)))
+
+    def binary(self, op, a: DeviceArray, b: DeviceArray, out: DeviceArray | None = None):
+        """a op b with broadcasting: what SMArray::operator+ does (SMArray.h:217-225)."""
+        assert a.dtype == b.dtype
+        res = self.broadcast(a.shape, a.strides, b.shape, b.strides)
+        if res is None:
+            raise RuntimeError("Cannot broadcast shapes: incompatible dimensions")
+        shape, sa, sb, _ = res
+        if out is None:
+            out = self.empty(shape, a.dtype)
+        self.elementwise_raw(op, a.dtype, a.ptr, sa, b.ptr, sb, shape, out.ptr)
+        return out
+
+    def contiguous(self, op, a: DeviceArray, b: DeviceArray, out: DeviceArray | None = None):
+        assert a.dtype == b.dtype and a.size == b.size
+        if out is None:
+            out = self.empty(a.shape, a.dtype)
+        self._ck(self.c.smhip_contiguous(C.c_int(op), C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+                                         C.c_void_p(out.ptr), C.c_size_t(a.size)))
+        return out
+
+    def array_scalar(self, op, a: DeviceArray, value, out: DeviceArray | None = None):
+        if out is None:
+            out = self.empty(a.shape, a.dtype)
+        v = np.array([value], dtype=a.dtype)
+        self._ck(self.c.smhip_array_scalar(C.c_int(op), C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr),
+                                           v.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_void_p(out.ptr)))
+        return out
+
+    def dot(self, a: DeviceArray, b: DeviceArray):
+        out = np.zeros(1, dtype=a.dtype)
+        self._ck(self.c.smhip_dot(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),
+                                  out.ctypes.data_as(C.c_void_p)))
+        return out[0]
+
+    def sum(self, a: DeviceArray):
+        out = C.c_double(0)
+        self._ck(self.c.smhip_sum(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_size_t(a.size), C.byref(out)))
+        return out.value
+
+    def sum_async(self, a: DeviceArray, out_ptr):
+        self._ck(self.c.smhip_sum_async(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_size_t(a.size), C.c_void_p(out_ptr)))
+
+    def dot_async(self, a: DeviceArray, b: DeviceArray, out_ptr):
+        self._ck(self.c.smhip_dot_async(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),
+                                        C.c_void_p(out_ptr)))
+
+    def contiguous_sum_async(self, op, a: DeviceArray, b: DeviceArray, out: DeviceArray, sum_ptr):
+        self._ck(self.c.smhip_contiguous_sum_async(C.c_int(op), C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+                                                   C.c_void_p(out.ptr), C.c_size_t(a.size), C.c_void_p(sum_ptr)))
+
+    def read_f64(self, ptr):
+        out = np.zeros(1, dtype=np.float64)
+        self.download(out, ptr)
+        return float(out[0])
+
+    def read_i64(self, ptr):
+        out = np.zeros(1, dtype=np.int64)
+        self.download(out, ptr)
+        return int(out[0])
+
+    # -- timing -----------------------------------------------------------------
+    def event(self):
+        e = C.c_void_p(0)
+        self._ck(self.c.smhip_event_create(C.byref(e)))
+        return e.value
+
+    def record(self, ev):
+        self._ck(self.c.smhip_event_record(C.c_void_p(ev)))
+
+    def event_sync(self, ev):
+        self._ck(self.c.smhip_event_synchronize(C.c_void_p(ev)))
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float(0)
+        self._ck(self.c.smhip_event_elapsed_ms(C.c_void_p(e0), C.c_void_p(e1), C.byref(ms)))
+        return ms.value
+
+    def event_destroy(self, ev):
+        self._ck(self.c.smhip_event_destroy(C.c_void_p(ev)))
+
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> Smhip:
+    """The loaded library (cached).  Raises if libsmhip.so has not been built."""
+    global _lib
+    if _lib is None or _lib.path != path:
+        _lib = Smhip(path)
+    return _lib

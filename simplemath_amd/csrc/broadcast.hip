@@ -1,0 +1,329 @@
+// broadcast.hip -- the strided / broadcast kernels.
+//
+// Replaces the general N-D loop of element_wise_op<T,Op> (reference
+// include/math/calculate.h:16-96): per element, ndim x (div + mod) to unravel
+// the linear index, scalar Op::apply, OpenMP over 1024-element chunks;
+// `canVectorize` is identically false there (:43-46).
+//
+// Here the host first normalises the problem (drop size-1 dims, merge dims
+// that are jointly dense in both operands) and then picks
+//   row kernel     inner strides in {0,1}: the contiguous axis is streamed with
+//                  16-byte vectors; the unravel runs once per ROW (mul-hi/shift
+//                  "fast division", no / or %), an operand with inner stride 0
+//                  is one scalar per row, and an operand with all-zero outer
+//                  strides (the (1 x 4096) row of BASELINE config 3) is loaded
+//                  once per workgroup and kept in registers across its rows;
+//   gather kernel  anything else (transposed views, tiny inner extents): W
+//                  consecutive outputs per lane so the store is still a
+//                  coalesced 16-byte vector; operand loads are per-element
+//                  gathers through fast-division unravel.
+// Roofline: HBM-bound; algorithmic bytes = sizeof(T) * (|a| + |b| + |out|)
+// with each broadcast operand counted once (config 3: 134 234 112 B).
+#include <type_traits>
+
+#include "internal.h"
+#include "ops.hip.h"
+
+namespace smhip {
+namespace {
+
+using namespace dev;
+
+constexpr int kMaxOuter = SMHIP_MAX_NDIM - 1;
+
+struct RowParams {
+    int64_t sa[kMaxOuter], sb[kMaxOuter];  // outer strides, elements, innermost-outer first
+    FastDiv shape[kMaxOuter];              // outer extents, innermost-outer first
+    int n_outer;
+    uint32_t rows;    // product of outer extents
+    uint32_t inner;   // inner extent in elements
+    uint32_t vpr;     // vector slots per row = ceil(inner / W)
+};
+
+// INNER_x: 1 = dense along the inner axis, 0 = broadcast along it.
+// CONST_x: operand has all outer strides zero -> identical for every row.
+// VEC: 16-byte accesses legal (extent, alignment and outer strides all multiples of W).
+template <typename T, typename Op, bool VEC, int INNER_A, int INNER_B, bool CONST_A, bool CONST_B, int TX, int ROWS>
+__global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                  RowParams p) {
+    constexpr int W = VEC ? VecTraits<T>::width : 1;
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int TY = 256 / TX;
+    const uint32_t tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const uint32_t col = blockIdx.x * TX + tx;  // vector slot within the row
+    if (col >= p.vpr) return;
+    const size_t col_elem = (size_t)col * W;
+
+    T va[ROWS][W], vb[ROWS][W];
+    auto load = [&](const T *base, int64_t off, int inner_mode, T (&dst)[W]) {
+        if (inner_mode == 0) {
+            const T s = base[off];
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = s;
+        } else if constexpr (VEC) {
+            const V v = *reinterpret_cast<const V *>(base + off + col_elem);
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = v[k];
+        } else {
+            dst[0] = base[off + col_elem];
+        }
+    };
+
+    T ca[W], cb[W];
+    if constexpr (CONST_A) load(a, 0, INNER_A, ca);
+    if constexpr (CONST_B) load(b, 0, INNER_B, cb);
+
+    const uint32_t row0 = (blockIdx.y * ROWS) * TY + ty;
+    uint32_t rows_here = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t row = row0 + r * TY;
+        if (row >= p.rows) break;
+        ++rows_here;
+        int64_t offA = 0, offB = 0;
+        if constexpr (!CONST_A || !CONST_B) {
+            uint32_t rem = row;
+            for (int k = 0; k < p.n_outer; ++k) {
+                uint32_t q, idx;
+                p.shape[k].divmod(rem, q, idx);
+                rem = q;
+                if constexpr (!CONST_A) offA += (int64_t)idx * p.sa[k];
+                if constexpr (!CONST_B) offB += (int64_t)idx * p.sb[k];
+            }
+        }
+        if constexpr (!CONST_A) load(a, offA, INNER_A, va[r]);
+        if constexpr (!CONST_B) load(b, offB, INNER_B, vb[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (r >= (int)rows_here) break;
+        const uint32_t row = row0 + r * TY;
+        T res[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) res[k] = Op::apply(CONST_A ? ca[k] : va[r][k], CONST_B ? cb[k] : vb[r][k]);
+        T *dst = out + (size_t)row * p.inner + col_elem;
+        if constexpr (VEC) {
+            V v;
+#pragma unroll
+            for (int k = 0; k < W; ++k) v[k] = res[k];
+            store_stream(reinterpret_cast<V *>(dst), v);
+        } else {
+            __builtin_nontemporal_store(res[0], dst);
+        }
+    }
+}
+
+struct GatherParams {
+    int64_t sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];  // innermost first
+    FastDiv shape[SMHIP_MAX_NDIM];                    // innermost first
+    int ndim;
+    uint32_t n;
+};
+
+// OUTVEC: `out` is 16-byte aligned -> each lane stores one vector; otherwise
+// one element per lane.
+template <typename T, typename Op, bool OUTVEC>
+__global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                     GatherParams p) {
+    constexpr int W = OUTVEC ? VecTraits<T>::width : 1;
+    typedef typename VecTraits<T>::vec_t V;
+    const uint32_t first = (blockIdx.x * 256u + threadIdx.x) * W;
+    if (first >= p.n) return;
+    T res[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const uint32_t linear = first + k;
+        if (linear < p.n) {
+            uint32_t rem = linear;
+            int64_t offA = 0, offB = 0;
+            for (int d = 0; d < p.ndim; ++d) {
+                uint32_t q, idx;
+                p.shape[d].divmod(rem, q, idx);
+                rem = q;
+                offA += (int64_t)idx * p.sa[d];
+                offB += (int64_t)idx * p.sb[d];
+            }
+            res[k] = Op::apply(a[offA], b[offB]);
+        }
+    }
+    if constexpr (OUTVEC) {
+        if (first + W <= p.n) {
+            V v;
+#pragma unroll
+            for (int k = 0; k < W; ++k) v[k] = res[k];
+            store_stream(reinterpret_cast<V *>(out + first), v);
+        } else {
+            for (int k = 0; k < W && first + k < p.n; ++k) out[first + k] = res[k];
+        }
+    } else {
+        out[first] = res[0];
+    }
+}
+
+struct Plan {
+    int ndim;
+    int64_t shape[SMHIP_MAX_NDIM], sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];
+    size_t n;
+};
+
+// Drop size-1 dims; merge neighbours (i, i+1) when both operands satisfy
+// stride[i] == shape[i+1] * stride[i+1] (jointly dense, or jointly broadcast).
+Plan normalise(const int64_t *shape, const int64_t *sa, const int64_t *sb, int ndim) {
+    Plan p{};
+    p.n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        p.n *= (size_t)shape[i];
+        if (shape[i] == 1) continue;
+        const int k = p.ndim;
+        if (k > 0 && p.sa[k - 1] == shape[i] * sa[i] && p.sb[k - 1] == shape[i] * sb[i]) {
+            p.shape[k - 1] *= shape[i];
+            p.sa[k - 1] = sa[i];
+            p.sb[k - 1] = sb[i];
+        } else {
+            p.shape[k] = shape[i];
+            p.sa[k] = sa[i];
+            p.sb[k] = sb[i];
+            ++p.ndim;
+        }
+    }
+    if (p.ndim == 0) {  // every dim was 1: a single element
+        p.ndim = 1;
+        p.shape[0] = 1;
+        p.sa[0] = p.sb[0] = 1;
+    }
+    return p;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T, typename Op, bool VEC, int IA, int IB, bool CA, bool CB>
+int launch_row_tx(const T *a, const T *b, T *out, const RowParams &p, hipStream_t s) {
+    constexpr int ROWS = 4;
+    auto go = [&](auto tx_tag) {
+        constexpr int TX = decltype(tx_tag)::value;
+        constexpr int TY = 256 / TX;
+        const unsigned gx = (p.vpr + TX - 1) / TX;
+        const unsigned gy = (p.rows + TY * ROWS - 1) / (TY * ROWS);
+        hipLaunchKernelGGL((row_kernel<T, Op, VEC, IA, IB, CA, CB, TX, ROWS>), dim3(gx, gy), dim3(256), 0, s, a, b, out, p);
+    };
+    if (p.vpr > 128) go(std::integral_constant<int, 256>{});
+    else if (p.vpr > 64) go(std::integral_constant<int, 128>{});
+    else if (p.vpr > 32) go(std::integral_constant<int, 64>{});
+    else if (p.vpr > 16) go(std::integral_constant<int, 32>{});
+    else go(std::integral_constant<int, 16>{});
+    SMHIP_LAUNCH_CHECK("row_kernel");
+    return SMHIP_OK;
+}
+
+template <typename T, typename Op, bool VEC>
+int launch_row(const T *a, const T *b, T *out, const RowParams &p, int ia, int ib, bool ca, bool cb, hipStream_t s) {
+    // inner (1,1): neither, one or the other operand constant over rows; (1,0)/(0,1): the
+    // broadcast side may additionally be row-constant only together with being a scalar,
+    // which normalise() has already folded away -- so CONST applies to dense sides only.
+#define ROW(IA, IB, CA, CB) return launch_row_tx<T, Op, VEC, IA, IB, CA, CB>(a, b, out, p, s)
+    if (ia == 1 && ib == 1) {
+        if (cb && !ca) ROW(1, 1, false, true);
+        if (ca && !cb) ROW(1, 1, true, false);
+        ROW(1, 1, false, false);
+    }
+    if (ia == 1 && ib == 0) {
+        if (ca) ROW(1, 0, true, false);
+        ROW(1, 0, false, false);
+    }
+    if (cb) ROW(0, 1, false, true);
+    ROW(0, 1, false, false);
+#undef ROW
+}
+
+template <typename T, typename Op>
+int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const T *a = static_cast<const T *>(a_), *b = static_cast<const T *>(b_);
+    T *out = static_cast<T *>(out_);
+    const int nd = pl.ndim;
+    const int64_t ia = pl.sa[nd - 1], ib = pl.sb[nd - 1];
+    const int64_t inner = pl.shape[nd - 1];
+    const size_t rows = pl.n / (size_t)inner;
+
+    const bool row_ok = (ia == 0 || ia == 1) && (ib == 0 || ib == 1) && (ia | ib) != 0 && inner >= 16 &&
+                        rows < 0x7fffffffull && inner < 0x7fffffffll;
+    if (row_ok) {
+        RowParams p{};
+        p.n_outer = nd - 1;
+        p.rows = (uint32_t)rows;
+        p.inner = (uint32_t)inner;
+        // a side that is broadcast along the inner axis is read as scalars: no alignment demand
+        bool ca = true, cb = true;
+        bool vec = (inner % W == 0) && aligned16(out) && (ia == 0 || aligned16(a)) && (ib == 0 || aligned16(b));
+        for (int k = 0; k < nd - 1; ++k) {  // innermost-outer first
+            const int src = nd - 2 - k;
+            p.shape[k] = FastDiv((uint32_t)pl.shape[src]);
+            p.sa[k] = pl.sa[src];
+            p.sb[k] = pl.sb[src];
+            ca &= pl.sa[src] == 0;
+            cb &= pl.sb[src] == 0;
+            if (ia == 1 && pl.sa[src] % W) vec = false;
+            if (ib == 1 && pl.sb[src] % W) vec = false;
+        }
+        if (vec) {
+            p.vpr = (uint32_t)(inner / W);
+            return launch_row<T, Op, true>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
+        }
+        p.vpr = (uint32_t)inner;
+        return launch_row<T, Op, false>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
+    }
+
+    if (pl.n >= 0x7fffffffull)
+        return fail(SMHIP_ERR_UNSUPPORTED, "gather path limited to < 2^31 elements (got %zu)", pl.n);
+    GatherParams g{};
+    g.ndim = nd;
+    g.n = (uint32_t)pl.n;
+    for (int d = 0; d < nd; ++d) {
+        const int src = nd - 1 - d;
+        g.shape[d] = FastDiv((uint32_t)pl.shape[src]);
+        g.sa[d] = pl.sa[src];
+        g.sb[d] = pl.sb[src];
+    }
+    if (aligned16(out)) {
+        const unsigned grid = (unsigned)(((pl.n + W - 1) / W + 255) / 256);
+        hipLaunchKernelGGL((gather_kernel<T, Op, true>), dim3(grid), dim3(256), 0, s, a, b, out, g);
+    } else {
+        const unsigned grid = (unsigned)((pl.n + 255) / 256);
+        hipLaunchKernelGGL((gather_kernel<T, Op, false>), dim3(grid), dim3(256), 0, s, a, b, out, g);
+    }
+    SMHIP_LAUNCH_CHECK("gather_kernel");
+    return SMHIP_OK;
+}
+
+}  // namespace
+
+int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
+                     const int64_t *shape, int ndim, void *out, hipStream_t s) {
+    const Plan pl = normalise(shape, sa, sb, ndim);
+    if (pl.n == 0) return SMHIP_OK;
+    if (pl.ndim == 1) {
+        // calculate.h:10-11's fast path, decided on the normalised problem
+        if (pl.sa[0] == 1 && pl.sb[0] == 1) return launch_contiguous(op, dtype, a, b, out, pl.n, s);
+        if (pl.sa[0] == 1 && pl.sb[0] == 0) return launch_array_devscalar(op, dtype, a, b, pl.n, out, false, s);
+        if (pl.sa[0] == 0 && pl.sb[0] == 1) return launch_array_devscalar(op, dtype, b, a, pl.n, out, true, s);
+    }
+#define SMHIP_DISPATCH_OP(T)                                                                   \
+    switch (op) {                                                                              \
+        case SMHIP_OP_ADD: return run_broadcast<T, AddOp<T>>(a, b, out, pl, s);                \
+        case SMHIP_OP_SUB: return run_broadcast<T, SubtractOp<T>>(a, b, out, pl, s);           \
+        case SMHIP_OP_MUL: return run_broadcast<T, MultiplyOp<T>>(a, b, out, pl, s);           \
+        case SMHIP_OP_DIV: return run_broadcast<T, DivideOp<T>>(a, b, out, pl, s);             \
+        case SMHIP_OP_POW: return run_broadcast<T, PowOp<T>>(a, b, out, pl, s);                \
+    }                                                                                          \
+    break;
+    switch (dtype) {
+        case SMHIP_F32: SMHIP_DISPATCH_OP(float)
+        case SMHIP_F64: SMHIP_DISPATCH_OP(double)
+        case SMHIP_I32: SMHIP_DISPATCH_OP(int32_t)
+        case SMHIP_I64: SMHIP_DISPATCH_OP(int64_t)
+    }
+#undef SMHIP_DISPATCH_OP
+    return fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype);
+}
+
+}  // namespace smhip

@@ -1,0 +1,247 @@
+// contiguous.hip -- the dense streaming kernels.
+//
+// Replaces handle_contiguous_arrays<T,Op> (reference include/math/calculate.h:
+// 101-134, an 8-wide AVX2 loop on ONE host thread) and array_scalar_op<T,Op>
+// (calculate.h:137-169) with HBM-streaming gfx950 kernels.
+//
+// Roofline: HBM-bound.  Algorithmic traffic 3 * sizeof(T) B/elem for a op b
+// (2 reads + 1 write; 12 B/elem for f32), 2 * sizeof(T) for a op scalar.
+// Shape of the launch (profiles/sweep_r1_stream.txt, N = 2^28 f32 add):
+//   - one 16-byte vector per lane (float4 / double2 / int4 / long2): a wave
+//     moves 1 KiB per memory instruction, fully coalesced;
+//   - NO grid-stride loop: one vector per thread, >= 65k workgroups, so the
+//     hardware dispatcher (not a software loop) keeps all 256 CUs / 8 XCDs
+//     fed and every wave retires after 2 loads + 1 store.  Persistent
+//     grid-stride variants with 2-8 vectors in flight per lane measured
+//     5-12 % slower on this 2R+1W stream;
+//   - non-temporal loads and stores (each byte is touched once): +8 %.
+// Blocks are dealt round-robin over the 8 XCDs, consecutive blocks touch
+// consecutive 16 KiB spans, so every XCD streams from all HBM stacks at once;
+// there is no reuse for an XCD-affine mapping to exploit.
+#include "internal.h"
+#include "ops.hip.h"
+
+namespace smhip {
+namespace {
+
+using namespace dev;
+
+constexpr int kBlockBig = 1024;   // n_vec >= kBigThreshold
+constexpr int kBlockSmall = 256;
+constexpr size_t kBigThreshold = (size_t)1 << 20;
+
+// out[i] = a[i] op b[i], vector body + <= width-1 scalar tail elements done
+// by the first thread past the body.
+template <typename T, typename Op, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restrict__ a, const T *__restrict__ b,
+                                                               T *__restrict__ out, size_t n_vec, int tail) {
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_vec) {
+        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
+        const V vb = load_stream(reinterpret_cast<const V *>(b) + i);
+        store_stream(reinterpret_cast<V *>(out) + i, apply_vec<Op, T>(va, vb));
+    } else if (i == n_vec) {
+        for (int k = 0; k < tail; ++k) out[n_vec * W + k] = Op::apply(a[n_vec * W + k], b[n_vec * W + k]);
+    }
+}
+
+// Fallback for operands that are not 16-byte aligned (e.g. a view that starts
+// mid-row): one element per lane, still fully coalesced (256 B per wave).
+template <typename T, typename Op, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void contiguous_elem_kernel(const T *__restrict__ a, const T *__restrict__ b,
+                                                                T *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(Op::apply(__builtin_nontemporal_load(a + i), __builtin_nontemporal_load(b + i)), out + i);
+}
+
+// out[i] = a[i] op s  (SWAPPED: s op a[i]); s is a kernel argument, i.e. it
+// lives in SGPRs -- the `set1` of calculate.h:141-146 costs nothing here.
+template <typename T, typename Op, int BLOCK, bool SWAPPED>
+__global__ __launch_bounds__(BLOCK) void scalar_vec_kernel(const T *__restrict__ a, T s, T *__restrict__ out,
+                                                           size_t n_vec, int tail) {
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_vec) {
+        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
+        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(va, s));
+    } else if (i == n_vec) {
+        for (int k = 0; k < tail; ++k) {
+            const T x = a[n_vec * W + k];
+            out[n_vec * W + k] = SWAPPED ? Op::apply(s, x) : Op::apply(x, s);
+        }
+    }
+}
+
+template <typename T, typename Op, int BLOCK, bool SWAPPED>
+__global__ __launch_bounds__(BLOCK) void scalar_elem_kernel(const T *__restrict__ a, T s, T *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const T x = __builtin_nontemporal_load(a + i);
+        __builtin_nontemporal_store(SWAPPED ? Op::apply(s, x) : Op::apply(x, s), out + i);
+    }
+}
+
+// Same, with the scalar fetched from device memory (a fully broadcast array
+// operand, e.g. `A + one_element_array`): a wave-uniform load.
+template <typename T, typename Op, int BLOCK, bool SWAPPED>
+__global__ __launch_bounds__(BLOCK) void devscalar_elem_kernel(const T *__restrict__ a, const T *__restrict__ sp,
+                                                               T *__restrict__ out, size_t n) {
+    const T s = *sp;
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const T x = __builtin_nontemporal_load(a + i);
+        __builtin_nontemporal_store(SWAPPED ? Op::apply(s, x) : Op::apply(x, s), out + i);
+    }
+}
+template <typename T, typename Op, int BLOCK, bool SWAPPED>
+__global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restrict__ a, const T *__restrict__ sp,
+                                                              T *__restrict__ out, size_t n_vec, int tail) {
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    const T s = *sp;
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_vec) {
+        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
+        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(va, s));
+    } else if (i == n_vec) {
+        for (int k = 0; k < tail; ++k) {
+            const T x = a[n_vec * W + k];
+            out[n_vec * W + k] = SWAPPED ? Op::apply(s, x) : Op::apply(x, s);
+        }
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int grid_for(size_t threads, int block, unsigned *grid) {
+    const size_t g = (threads + block - 1) / block;
+    if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch (%zu workgroups)", g);
+    *grid = (unsigned)g;
+    return SMHIP_OK;
+}
+
+template <typename T, typename Op>
+int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const T *pa = static_cast<const T *>(a), *pb = static_cast<const T *>(b);
+    T *po = static_cast<T *>(out);
+    unsigned grid;
+    if (aligned16(a) && aligned16(b) && aligned16(out)) {
+        const size_t n_vec = n / W;
+        const int tail = (int)(n % W);
+        const size_t threads = n_vec + (tail ? 1 : 0);
+        if (n_vec >= kBigThreshold) {
+            if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
+            hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail);
+        } else {
+            if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
+            hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail);
+        }
+    } else {
+        if (int rc = grid_for(n, kBlockSmall, &grid)) return rc;
+        hipLaunchKernelGGL((contiguous_elem_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n);
+    }
+    SMHIP_LAUNCH_CHECK("contiguous");
+    return SMHIP_OK;
+}
+
+template <typename T, typename Op, bool SWAPPED>
+int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const T *pa = static_cast<const T *>(a);
+    T *po = static_cast<T *>(out);
+    unsigned grid;
+    if (aligned16(a) && aligned16(out)) {
+        const size_t n_vec = n / W;
+        const int tail = (int)(n % W);
+        const size_t threads = n_vec + (tail ? 1 : 0);
+        if (n_vec >= kBigThreshold) {
+            if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
+            hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockBig, SWAPPED>), dim3(grid), dim3(kBlockBig), 0, s, pa, value, po, n_vec, tail);
+        } else {
+            if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
+            hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail);
+        }
+    } else {
+        if (int rc = grid_for(n, kBlockSmall, &grid)) return rc;
+        hipLaunchKernelGGL((scalar_elem_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n);
+    }
+    SMHIP_LAUNCH_CHECK("array_scalar");
+    return SMHIP_OK;
+}
+
+template <typename T, typename Op, bool SWAPPED>
+int run_devscalar(const void *a, const void *sp, size_t n, void *out, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const T *pa = static_cast<const T *>(a);
+    const T *ps = static_cast<const T *>(sp);
+    T *po = static_cast<T *>(out);
+    unsigned grid;
+    if (aligned16(a) && aligned16(out)) {
+        const size_t n_vec = n / W;
+        const int tail = (int)(n % W);
+        if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
+        hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail);
+    } else {
+        if (int rc = grid_for(n, kBlockSmall, &grid)) return rc;
+        hipLaunchKernelGGL((devscalar_elem_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n);
+    }
+    SMHIP_LAUNCH_CHECK("array_devscalar");
+    return SMHIP_OK;
+}
+
+// op x dtype dispatch: F(T, Op) expands to a call.
+#define SMHIP_DISPATCH_OP(T, F)                                  \
+    switch (op) {                                                \
+        case SMHIP_OP_ADD: return F(T, AddOp<T>);                \
+        case SMHIP_OP_SUB: return F(T, SubtractOp<T>);           \
+        case SMHIP_OP_MUL: return F(T, MultiplyOp<T>);           \
+        case SMHIP_OP_DIV: return F(T, DivideOp<T>);             \
+        case SMHIP_OP_POW: return F(T, PowOp<T>);                \
+    }                                                            \
+    break;
+#define SMHIP_DISPATCH(F)                                        \
+    switch (dtype) {                                             \
+        case SMHIP_F32: SMHIP_DISPATCH_OP(float, F)              \
+        case SMHIP_F64: SMHIP_DISPATCH_OP(double, F)             \
+        case SMHIP_I32: SMHIP_DISPATCH_OP(int32_t, F)            \
+        case SMHIP_I64: SMHIP_DISPATCH_OP(int64_t, F)            \
+    }
+
+}  // namespace
+
+int launch_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s) {
+    if (n == 0) return SMHIP_OK;
+#define F(T, OP) run_contiguous<T, OP>(a, b, out, n, s)
+    SMHIP_DISPATCH(F)
+#undef F
+    return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
+}
+
+int launch_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s) {
+    if (n == 0) return SMHIP_OK;
+#define F(T, OP) run_scalar<T, OP, false>(a, *static_cast<const T *>(value_host), n, out, s)
+    SMHIP_DISPATCH(F)
+#undef F
+    return fail(SMHIP_ERR_INVALID, "array_scalar: bad op %d / dtype %d", op, dtype);
+}
+
+int launch_array_devscalar(int op, int dtype, const void *a, const void *value_dev, size_t n, void *out, bool swapped,
+                           hipStream_t s) {
+    if (n == 0) return SMHIP_OK;
+    if (swapped) {
+#define F(T, OP) run_devscalar<T, OP, true>(a, value_dev, n, out, s)
+        SMHIP_DISPATCH(F)
+#undef F
+    } else {
+#define F(T, OP) run_devscalar<T, OP, false>(a, value_dev, n, out, s)
+        SMHIP_DISPATCH(F)
+#undef F
+    }
+    return fail(SMHIP_ERR_INVALID, "array_devscalar: bad op %d / dtype %d", op, dtype);
+}
+
+}  // namespace smhip

@@ -1,0 +1,57 @@
+// internal.h -- shared plumbing of libsmhip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "smhip.h"
+
+namespace smhip {
+
+// Records the message for smhip_last_error() on this thread; returns `code`.
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Makes sure this thread has a usable gfx950 device selected and returns the
+// stream its work goes to.  SMHIP_OK or SMHIP_ERR_NO_DEVICE / SMHIP_ERR_HIP.
+int acquire(hipStream_t *stream);
+
+// Per-device scratch for reductions: `count` doubles, stable until the next
+// call with a larger count on the same device.
+int reduce_scratch(size_t count, double **ptr);
+
+#define SMHIP_TRY(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t smhip_e_ = (expr);                                                          \
+        if (smhip_e_ != hipSuccess)                                                            \
+            return ::smhip::fail(SMHIP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(smhip_e_)); \
+    } while (0)
+
+#define SMHIP_LAUNCH_CHECK(what)                                                              \
+    do {                                                                                       \
+        hipError_t smhip_e_ = hipGetLastError();                                               \
+        if (smhip_e_ != hipSuccess)                                                            \
+            return ::smhip::fail(SMHIP_ERR_HIP, "launch %s: %s", what, hipGetErrorString(smhip_e_)); \
+    } while (0)
+
+inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }
+inline bool valid_dtype(int dtype) { return dtype >= SMHIP_F32 && dtype <= SMHIP_I64; }
+inline bool valid_op(int op) { return op >= SMHIP_OP_ADD && op <= SMHIP_OP_POW; }
+
+// Kernel launchers (one translation unit each).
+int launch_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);
+int launch_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s);
+// b is a device pointer to ONE element (a fully broadcast operand); `swapped`
+// computes value op a[i] instead of a[i] op value.
+int launch_array_devscalar(int op, int dtype, const void *a, const void *value_dev, size_t n, void *out,
+                           bool swapped, hipStream_t s);
+int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
+                     const int64_t *shape, int ndim, void *out, hipStream_t s);
+int launch_fill(int dtype, void *dst, const void *value_host, size_t n, hipStream_t s);
+int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi, hipStream_t s);
+int launch_sum(int dtype, const void *a, size_t n, double *out_dev, hipStream_t s);
+int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out_dev, void *out_native_dev, hipStream_t s);
+int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev,
+                          hipStream_t s);
+
+}  // namespace smhip

@@ -1,0 +1,173 @@
+// ops.hip.h -- device-side Op policies and vector traits for gfx950.
+//
+// Device mirror of the reference's plugin contract: where the reference has
+//   template<class T> struct XOp { static T apply(const T&, const T&);
+//                                  template<class R> static R apply_simd(const R&, const R&); };
+// (include/math/add.h:5-14 and siblings), the device side has
+//   template<class T> struct XOp { static __device__ T apply(T, T); };
+// and `apply_vec` below plays apply_simd's role on a 16-byte register group
+// (float4 / double2 / int4 / long2 instead of __m256 -- SimdTraits<T>,
+// include/math/helpers.h:12-119).  One wave = 64 lanes x 16 B = 1 KiB per
+// memory instruction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "sm_pow.h"
+
+namespace smhip {
+namespace dev {
+
+// ----------------------------------------------------------------- vectors
+template <typename T> struct VecTraits;
+template <> struct VecTraits<float>   { typedef float   vec_t __attribute__((ext_vector_type(4))); static constexpr int width = 4; };
+template <> struct VecTraits<int32_t> { typedef int32_t vec_t __attribute__((ext_vector_type(4))); static constexpr int width = 4; };
+template <> struct VecTraits<double>  { typedef double  vec_t __attribute__((ext_vector_type(2))); static constexpr int width = 2; };
+template <> struct VecTraits<int64_t> { typedef int64_t vec_t __attribute__((ext_vector_type(2))); static constexpr int width = 2; };
+
+// Streaming accesses carry the `nt` (non-temporal) policy: every byte of the
+// contiguous path is touched once, and keeping it out of L2's replacement
+// order is worth ~8 % on the 2R+1W stream (profiles/sweep_r1_stream.txt).
+template <typename V> __device__ __forceinline__ V load_stream(const V *p) { return __builtin_nontemporal_load(p); }
+template <typename V> __device__ __forceinline__ void store_stream(V *p, V v) { __builtin_nontemporal_store(v, p); }
+
+// -------------------------------------------------------------- Op policies
+// f32/f64: one correctly rounded IEEE operation each (add.h:18-59 etc.);
+// kernels are built with -ffp-contract=off, denormals on, and hipcc's default
+// correctly-rounded f32 division, so results are bit-identical to the AVX2 path.
+// i32/i64 + - * wrap like _mm256_{add,sub,mullo}_epi32 (add.h:64-82,
+// subtract.h:65-83, multiply.h:68-86).
+template <typename T> struct UInt;
+template <> struct UInt<int32_t> { typedef uint32_t type; };
+template <> struct UInt<int64_t> { typedef uint64_t type; };
+
+template <typename T> struct AddOp { static __device__ __forceinline__ T apply(T a, T b) { return a + b; } };
+template <typename T> struct SubtractOp { static __device__ __forceinline__ T apply(T a, T b) { return a - b; } };
+template <typename T> struct MultiplyOp { static __device__ __forceinline__ T apply(T a, T b) { return a * b; } };
+template <typename T> struct DivideOp { static __device__ __forceinline__ T apply(T a, T b) { return a / b; } };
+template <typename T> struct PowOp;
+
+#define SMHIP_INT_OPS(T)                                                                             \
+    template <> struct AddOp<T> { static __device__ __forceinline__ T apply(T a, T b) {             \
+        typedef UInt<T>::type U; return (T)((U)a + (U)b); } };                                       \
+    template <> struct SubtractOp<T> { static __device__ __forceinline__ T apply(T a, T b) {        \
+        typedef UInt<T>::type U; return (T)((U)a - (U)b); } };                                       \
+    template <> struct MultiplyOp<T> { static __device__ __forceinline__ T apply(T a, T b) {        \
+        typedef UInt<T>::type U; return (T)((U)a * (U)b); } };
+SMHIP_INT_OPS(int32_t)
+SMHIP_INT_OPS(int64_t)
+#undef SMHIP_INT_OPS
+
+// division.h:67-70 (C `/`: truncation toward zero).  The reference traps on
+// x/0 and INT_MIN/-1; a kernel cannot, so both are defined: x/0 = 0,
+// INT_MIN/-1 = INT_MIN (DESIGN.md "defined where the reference traps").
+template <> struct DivideOp<int32_t> {
+    static __device__ __forceinline__ int32_t apply(int32_t a, int32_t b) {
+        if (b == 0) return 0;
+        if (b == -1) return (int32_t)(0u - (uint32_t)a);
+        return a / b;
+    }
+};
+template <> struct DivideOp<int64_t> {
+    static __device__ __forceinline__ int64_t apply(int64_t a, int64_t b) {
+        if (b == 0) return 0;
+        if (b == -1) return (int64_t)(0ull - (uint64_t)a);
+        return a / b;
+    }
+};
+
+// __sm256_powi_ps, include/math/simd/crafted_pow.h:54-103, one lane: square
+// and multiply on |e| with wrapping products, then the sign-of-exponent fix-ups.
+// With a wave-uniform exponent (sm::pow(arr, scalar)) the loop trip count is
+// uniform, so there is no divergence.
+template <typename T> __device__ __forceinline__ T powi(T base, T exponent) {
+    typedef typename UInt<T>::type U;
+    U e = exponent < 0 ? (U)0 - (U)exponent : (U)exponent;  // :60 abs (INT_MIN stays 2^31)
+    U cur = (U)base, pos = 1;
+    while (e != 0) {                                          // :65
+        if (e & 1) pos *= cur;                                // :67-72
+        cur *= cur;                                           // :76
+        e >>= 1;                                              // :79
+    }
+    if (base == 0 && exponent > 0) pos = 0;                   // :81-84
+    T neg = 0;                                                // :85
+    if (base == 1) neg = 1;                                   // :88-89
+    if (base == -1) neg = (exponent & 1) ? -1 : 1;            // :92-95
+    return exponent < 0 ? neg : (T)pos;                       // :99-102
+}
+template <> struct PowOp<int32_t> { static __device__ __forceinline__ int32_t apply(int32_t a, int32_t b) { return powi<int32_t>(a, b); } };
+template <> struct PowOp<int64_t> { static __device__ __forceinline__ int64_t apply(int64_t a, int64_t b) { return powi<int64_t>(a, b); } };
+// PowOp<float>::apply = std::pow (pow.h:8-10) -> in-register fp64 exp2/log2 chain.
+template <> struct PowOp<float> { static __device__ __forceinline__ float apply(float a, float b) { return smpow::powf(a, b); } };
+// f64 pow is a "next" row: ROCm's device libm keeps the API whole meanwhile.
+template <> struct PowOp<double> { static __device__ __forceinline__ double apply(double a, double b) { return ::pow(a, b); } };
+
+// apply_simd's role: the Op across W independent elements held in registers.
+// PowOp<float> evaluates them side by side (one constant load per polynomial
+// step, no branches); every other Op is one instruction per element.
+template <typename Op, typename T, int W>
+__device__ __forceinline__ void apply_n(const T (&a)[W], const T (&b)[W], T (&r)[W]) {
+    if constexpr (std::is_same<Op, PowOp<float>>::value) {
+        smpow::pow_n<W>(a, b, r);
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);
+    }
+}
+
+// ... and across one 16-byte register group.
+template <typename Op, typename T>
+__device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec(typename VecTraits<T>::vec_t a, typename VecTraits<T>::vec_t b) {
+    constexpr int W = VecTraits<T>::width;
+    T xa[W], xb[W], xr[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) { xa[i] = a[i]; xb[i] = b[i]; }
+    apply_n<Op, T, W>(xa, xb, xr);
+    typename VecTraits<T>::vec_t r;
+#pragma unroll
+    for (int i = 0; i < W; ++i) r[i] = xr[i];
+    return r;
+}
+// SWAPPED = false: a[i] op s;  true: s op a[i]
+template <typename Op, typename T, bool SWAPPED>
+__device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec_scalar(typename VecTraits<T>::vec_t a, T s) {
+    typename VecTraits<T>::vec_t sv;
+#pragma unroll
+    for (int i = 0; i < VecTraits<T>::width; ++i) sv[i] = s;
+    return SWAPPED ? apply_vec<Op, T>(sv, a) : apply_vec<Op, T>(a, sv);
+}
+
+// ------------------------------------------------------------- fast divmod
+// Division of a 31-bit index by a launch-constant divisor as mul-hi + shift
+// (replaces the per-element `/` and `%` chain of calculate.h:58-63).
+// Valid for 0 <= n < 2^31, 1 <= d < 2^31.
+struct FastDiv {
+    uint32_t d, mul, shr;
+    __host__ __device__ FastDiv() : d(1), mul(0), shr(0) {}
+    __host__ explicit FastDiv(uint32_t div) : d(div), mul(0), shr(0) {
+        if (div > 1) {
+            uint32_t l = 0;
+            while ((1ull << l) < div) ++l;  // ceil(log2 d)
+            const uint32_t p = 31 + l;
+            mul = (uint32_t)(((1ull << p) + div - 1) / div);
+            shr = p - 32;
+        }
+    }
+    __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return d == 1 ? n : (__umulhi(n, mul) >> shr);
+#else
+        return d == 1 ? n : (uint32_t)(((uint64_t)n * mul) >> 32) >> shr;
+#endif
+    }
+    __host__ __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const {
+        q = div(n);
+        r = n - q * d;
+    }
+};
+
+}  // namespace dev
+}  // namespace smhip

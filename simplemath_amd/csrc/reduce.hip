@@ -1,0 +1,247 @@
+// reduce.hip -- whole-array reductions.
+//
+// Replaces dot_product<T> (reference include/math/product.h:8-224, reached
+// through SMArray::operator% at include/SMArray.h:213-215): one host thread,
+// 8 f32 lane accumulators that stop absorbing addends past 2^24 (SURVEY 0:
+// the dot of 2^28 ones returns 2^27).  Adds sum() and the fused a op b + sum
+// of BASELINE config 5, which the reference lacks.
+//
+// Structure: each lane streams 16-byte vectors and accumulates privately
+// (fp64 for f32/f64, wrapping 64-bit integers for i32/i64 -- so integer results
+// are bit-identical to the reference in any order), then a 64-lane wavefront
+// shuffle tree (__shfl_down), then LDS across the workgroup's waves, one partial
+// per workgroup, and a second single-workgroup pass over the partials in a
+// fixed order: results are deterministic run to run.
+// Roofline: HBM-bound; sizeof(T) B/elem (sum), 2*sizeof(T) (dot),
+// 3*sizeof(T) (fused op+sum: the sum adds no traffic).
+#include <type_traits>
+
+#include "internal.h"
+#include "ops.hip.h"
+
+namespace smhip {
+namespace {
+
+using namespace dev;
+
+constexpr int kBlock = 256;
+constexpr int kVecPerThread = 4;  // 4 x 16 B in flight per lane and operand; 64 KiB+ tiles keep partials few
+constexpr int kFinalBlock = 1024;
+
+template <typename T> struct AccOf { typedef double type; };
+template <> struct AccOf<int32_t> { typedef uint64_t type; };
+template <> struct AccOf<int64_t> { typedef uint64_t type; };
+
+template <typename A> __device__ __forceinline__ A wave_reduce(A v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int off) {
+    const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <> __device__ __forceinline__ uint64_t wave_reduce<uint64_t>(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += shfl_down_u64(v, off);
+    return v;
+}
+
+// Workgroup total in thread 0.
+template <typename A, int BLOCK> __device__ __forceinline__ A block_reduce(A v) {
+    __shared__ A lds[BLOCK / 64];
+    v = wave_reduce(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        v = lane < BLOCK / 64 ? lds[lane] : A(0);
+        v = wave_reduce(v);
+    }
+    return v;
+}
+
+template <typename T, typename A> __device__ __forceinline__ A widen(T x) { return (A)x; }
+template <> __device__ __forceinline__ uint64_t widen<int32_t, uint64_t>(int32_t x) { return (uint64_t)(int64_t)x; }
+template <> __device__ __forceinline__ uint64_t widen<int64_t, uint64_t>(int64_t x) { return (uint64_t)x; }
+
+// acc += x*y.  f32: the product of two 24-bit significands is exact in fp64, so the
+// whole dot is an fp64 fma chain (the reference's -mfma build fuses too, but into f32
+// lanes).  f64: fused, one rounding per term.  i32/i64: product wraps in T like
+// _mm256_mullo_epi32, then accumulates mod 2^64.
+template <typename T, typename A> __device__ __forceinline__ void add_prod(A &acc, T x, T y) { acc += widen<T, A>(MultiplyOp<T>::apply(x, y)); }
+template <> __device__ __forceinline__ void add_prod<float, double>(double &acc, float x, float y) { acc = __builtin_fma((double)x, (double)y, acc); }
+template <> __device__ __forceinline__ void add_prod<double, double>(double &acc, double x, double y) { acc = __builtin_fma(x, y, acc); }
+
+enum Mode { kSum = 0, kDot = 1, kFused = 2 };
+
+// MODE kSum: partial = sum a;  kDot: partial = sum a*b;  kFused: out = a op b, partial = sum out.
+template <typename T, typename Op, int MODE>
+__global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                        size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials) {
+    typedef typename AccOf<T>::type A;
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    const size_t tile0 = (size_t)blockIdx.x * (kBlock * kVecPerThread) + threadIdx.x;
+    A acc = A(0);
+    V va[kVecPerThread], vb[kVecPerThread];
+#pragma unroll
+    for (int u = 0; u < kVecPerThread; ++u) {
+        const size_t i = tile0 + (size_t)u * kBlock;
+        if (i < n_vec) {
+            va[u] = load_stream(reinterpret_cast<const V *>(a) + i);
+            if constexpr (MODE != kSum) vb[u] = load_stream(reinterpret_cast<const V *>(b) + i);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kVecPerThread; ++u) {
+        const size_t i = tile0 + (size_t)u * kBlock;
+        if (i < n_vec) {
+            if constexpr (MODE == kFused) {
+                const V r = apply_vec<Op, T>(va[u], vb[u]);
+                store_stream(reinterpret_cast<V *>(out) + i, r);
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc += widen<T, A>(r[k]);
+            } else if constexpr (MODE == kDot) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) add_prod<T, A>(acc, va[u][k], vb[u][k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc += widen<T, A>(va[u][k]);
+            }
+        }
+    }
+    // scalar tail (n % W elements) by the very last lane of the grid's range
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        for (size_t k = n_vec * W; k < n; ++k) {
+            if constexpr (MODE == kFused) {
+                const T r = Op::apply(a[k], b[k]);
+                out[k] = r;
+                acc += widen<T, A>(r);
+            } else if constexpr (MODE == kDot) add_prod<T, A>(acc, a[k], b[k]);
+            else acc += widen<T, A>(a[k]);
+        }
+    }
+    acc = block_reduce<A, kBlock>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// Unaligned fallback: one element per lane per step, grid-stride.
+template <typename T, typename Op, int MODE>
+__global__ __launch_bounds__(kBlock) void reduce_elem_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                             size_t n, typename AccOf<T>::type *__restrict__ partials) {
+    typedef typename AccOf<T>::type A;
+    A acc = A(0);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if constexpr (MODE == kFused) {
+            const T r = Op::apply(a[i], b[i]);
+            out[i] = r;
+            acc += widen<T, A>(r);
+        } else if constexpr (MODE == kDot) add_prod<T, A>(acc, a[i], b[i]);
+        else acc += widen<T, A>(a[i]);
+    }
+    acc = block_reduce<A, kBlock>(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// Second pass: fixed-order sum of the partials.  *out8 receives 8 bytes:
+//   floats            the fp64 total;
+//   ints, AS_DOUBLE   (double) of the exact 64-bit total         (sum, fused op+sum);
+//   ints, !AS_DOUBLE  the total wrapped to T, sign-extended to int64 (dot: per-rank
+//                     partials add up mod 2^32 / 2^64 exactly like the reference's
+//                     _mm256_add_epi32 accumulators, in any order).
+// *out_native (optional) receives the value narrowed to T (dot's return type).
+template <typename T, bool AS_DOUBLE>
+__global__ __launch_bounds__(kFinalBlock) void finalize_kernel(const typename AccOf<T>::type *__restrict__ partials, size_t count,
+                                                               void *__restrict__ out8, T *__restrict__ out_native) {
+    typedef typename AccOf<T>::type A;
+    A acc = A(0);
+    for (size_t i = threadIdx.x; i < count; i += kFinalBlock) acc += partials[i];
+    acc = block_reduce<A, kFinalBlock>(acc);
+    if (threadIdx.x == 0) {
+        if constexpr (std::is_floating_point<T>::value) {
+            if (out8) *static_cast<double *>(out8) = acc;
+            if (out_native) *out_native = (T)acc;
+        } else {
+            const T wrapped = (T)acc;
+            if (out8) {
+                if constexpr (AS_DOUBLE) *static_cast<double *>(out8) = (double)(int64_t)acc;
+                else *static_cast<int64_t *>(out8) = (int64_t)wrapped;
+            }
+            if (out_native) *out_native = wrapped;
+        }
+    }
+}
+
+inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T, typename Op, int MODE>
+int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8, void *out_native, hipStream_t s) {
+    typedef typename AccOf<T>::type A;
+    constexpr int W = VecTraits<T>::width;
+    const T *a = static_cast<const T *>(a_), *b = static_cast<const T *>(b_);
+    T *out = static_cast<T *>(out_);
+    const size_t n_vec = n / W;
+    const size_t tile = (size_t)kBlock * kVecPerThread;
+    size_t blocks;
+    const bool vec = aligned16(a) && aligned16(b) && aligned16(out);
+    if (vec) blocks = n_vec ? (n_vec + tile - 1) / tile : 1;
+    else blocks = n < (size_t)kBlock * 2048 ? (n + kBlock - 1) / kBlock : 2048;
+    if (blocks == 0) blocks = 1;
+    if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);
+    double *scratch;
+    if (int rc = reduce_scratch(blocks, &scratch)) return rc;
+    A *partials = reinterpret_cast<A *>(scratch);
+    if (vec)
+        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials);
+    else
+        hipLaunchKernelGGL((reduce_elem_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n, partials);
+    SMHIP_LAUNCH_CHECK("reduce");
+    hipLaunchKernelGGL((finalize_kernel<T, MODE != kDot>), dim3(1), dim3(kFinalBlock), 0, s, partials, blocks, out8, static_cast<T *>(out_native));
+    SMHIP_LAUNCH_CHECK("reduce finalize");
+    return SMHIP_OK;
+}
+
+}  // namespace
+
+int launch_sum(int dtype, const void *a, size_t n, double *out_dev, hipStream_t s) {
+    switch (dtype) {
+        case SMHIP_F32: return run_reduce<float, AddOp<float>, kSum>(a, nullptr, nullptr, n, out_dev, nullptr, s);
+        case SMHIP_F64: return run_reduce<double, AddOp<double>, kSum>(a, nullptr, nullptr, n, out_dev, nullptr, s);
+        case SMHIP_I32: return run_reduce<int32_t, AddOp<int32_t>, kSum>(a, nullptr, nullptr, n, out_dev, nullptr, s);
+        case SMHIP_I64: return run_reduce<int64_t, AddOp<int64_t>, kSum>(a, nullptr, nullptr, n, out_dev, nullptr, s);
+    }
+    return fail(SMHIP_ERR_INVALID, "sum: bad dtype %d", dtype);
+}
+
+int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out8_dev, void *out_native_dev, hipStream_t s) {
+    switch (dtype) {
+        case SMHIP_F32: return run_reduce<float, AddOp<float>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_F64: return run_reduce<double, AddOp<double>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_I32: return run_reduce<int32_t, AddOp<int32_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_I64: return run_reduce<int64_t, AddOp<int64_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+    }
+    return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
+}
+
+int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev, hipStream_t s) {
+#define SMHIP_DISPATCH_OP(T)                                                                                          \
+    switch (op) {                                                                                                     \
+        case SMHIP_OP_ADD: return run_reduce<T, AddOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);                 \
+        case SMHIP_OP_SUB: return run_reduce<T, SubtractOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);            \
+        case SMHIP_OP_MUL: return run_reduce<T, MultiplyOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);            \
+        case SMHIP_OP_DIV: return run_reduce<T, DivideOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);              \
+        case SMHIP_OP_POW: return run_reduce<T, PowOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);                 \
+    }                                                                                                                 \
+    break;
+    switch (dtype) {
+        case SMHIP_F32: SMHIP_DISPATCH_OP(float)
+        case SMHIP_F64: SMHIP_DISPATCH_OP(double)
+        case SMHIP_I32: SMHIP_DISPATCH_OP(int32_t)
+        case SMHIP_I64: SMHIP_DISPATCH_OP(int64_t)
+    }
+#undef SMHIP_DISPATCH_OP
+    return fail(SMHIP_ERR_INVALID, "contiguous_sum: bad op %d / dtype %d", op, dtype);
+}
+
+}  // namespace smhip

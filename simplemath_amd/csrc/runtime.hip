@@ -1,0 +1,458 @@
+// runtime.hip -- libsmhip.so's C ABI (include/smhip.h): per-thread device and
+// stream selection, the pooled device allocator, the host-side shape layer and
+// the entry points that validate arguments and hand off to the kernel launchers.
+//
+// The reference has no runtime at all (header-only loops, `new T[n]` per
+// operator, SMArray.h:219); this file is what the process/device boundary costs.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "internal.h"
+
+namespace smhip {
+namespace {
+
+constexpr int kMaxDevices = 64;
+
+struct ThreadState {
+    int device = -1;              // -1: not chosen yet (device 0 on first use)
+    bool checked[kMaxDevices] = {};
+    hipStream_t user_stream = nullptr;
+    bool use_user_stream = false;
+    std::string error;
+    double *scratch[kMaxDevices] = {};
+    size_t scratch_count[kMaxDevices] = {};
+};
+thread_local ThreadState tls;
+
+// One library-owned stream per device, shared by all threads that did not
+// bring their own.
+std::mutex g_mutex;
+hipStream_t g_streams[kMaxDevices] = {};
+int g_device_count = -1;
+
+// ---------------------------------------------------------------- the pool
+// Size-class free lists per device.  Classes: powers of two from 256 B up to
+// 2 MiB, then multiples of 2 MiB -- so a freed 1 GiB operand buffer is reused
+// as-is by the next same-sized result, which is what turns the reference's
+// per-operator `new T[n]` + first-touch page faults into a pointer pop.
+struct Block { size_t cls; int device; hipStream_t last_stream; };
+std::unordered_map<void *, Block> g_live;                       // allocated, handed out
+std::map<std::pair<int, size_t>, std::vector<std::pair<void *, hipStream_t>>> g_free;  // cached
+size_t g_bytes_live = 0, g_bytes_cached = 0;
+
+size_t size_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    constexpr size_t big = (size_t)2 << 20;
+    if (bytes >= big) return (bytes + big - 1) / big * big;
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+
+}  // namespace
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tls.error = buf;
+    return code;
+}
+
+int acquire(hipStream_t *stream) {
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_device_count < 0) {
+            int n = 0;
+            hipError_t e = hipGetDeviceCount(&n);
+            if (e != hipSuccess || n <= 0) {
+                (void)hipGetLastError();
+                return fail(SMHIP_ERR_NO_DEVICE,
+                            "no HIP device available (%s); libsmhip has no CPU fallback",
+                            e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+            }
+            g_device_count = n < kMaxDevices ? n : kMaxDevices;
+        }
+    }
+    if (tls.device < 0) tls.device = 0;
+    if (tls.device >= g_device_count) return fail(SMHIP_ERR_INVALID, "device %d out of range (%d devices)", tls.device, g_device_count);
+    SMHIP_TRY(hipSetDevice(tls.device));
+    if (!tls.checked[tls.device]) {
+        hipDeviceProp_t prop;
+        SMHIP_TRY(hipGetDeviceProperties(&prop, tls.device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SMHIP_ERR_NO_DEVICE, "device %d is %s; libsmhip carries gfx950 (MI355X) code only", tls.device, prop.gcnArchName);
+        tls.checked[tls.device] = true;
+    }
+    if (tls.use_user_stream) {
+        *stream = tls.user_stream;
+        return SMHIP_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_streams[tls.device]) SMHIP_TRY(hipStreamCreateWithFlags(&g_streams[tls.device], hipStreamNonBlocking));
+    *stream = g_streams[tls.device];
+    return SMHIP_OK;
+}
+
+int reduce_scratch(size_t count, double **ptr) {
+    const int d = tls.device;
+    if (tls.scratch_count[d] < count) {
+        size_t want = count < 4096 ? 4096 : count * 2;
+        void *p = nullptr;
+        if (int rc = smhip_alloc(&p, want * sizeof(double))) return rc;
+        if (tls.scratch[d]) smhip_free(tls.scratch[d]);
+        tls.scratch[d] = static_cast<double *>(p);
+        tls.scratch_count[d] = want;
+    }
+    *ptr = tls.scratch[d];
+    return SMHIP_OK;
+}
+
+}  // namespace smhip
+
+using namespace smhip;
+
+#define SMHIP_ACQUIRE(stream_var)  \
+    hipStream_t stream_var;        \
+    if (int rc_ = acquire(&stream_var)) return rc_
+
+extern "C" {
+
+const char *smhip_version(void) { return "smhip 0.1 (gfx950)"; }
+const char *smhip_last_error(void) { return tls.error.c_str(); }
+
+int smhip_device_count(int *count) {
+    if (!count) return fail(SMHIP_ERR_INVALID, "device_count: null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return SMHIP_OK;
+}
+
+int smhip_set_device(int device) {
+    if (device < 0 || device >= kMaxDevices) return fail(SMHIP_ERR_INVALID, "set_device: %d", device);
+    const int prev = tls.device;
+    tls.device = device;
+    hipStream_t s;
+    if (int rc = acquire(&s)) {
+        tls.device = prev;
+        return rc;
+    }
+    return SMHIP_OK;
+}
+
+int smhip_get_device(int *device) {
+    if (!device) return fail(SMHIP_ERR_INVALID, "get_device: null");
+    *device = tls.device < 0 ? 0 : tls.device;
+    return SMHIP_OK;
+}
+
+int smhip_set_stream(void *hip_stream) {
+    tls.user_stream = static_cast<hipStream_t>(hip_stream);
+    tls.use_user_stream = hip_stream != nullptr;
+    return SMHIP_OK;
+}
+
+int smhip_get_stream(void **hip_stream) {
+    if (!hip_stream) return fail(SMHIP_ERR_INVALID, "get_stream: null");
+    SMHIP_ACQUIRE(s);
+    *hip_stream = s;
+    return SMHIP_OK;
+}
+
+int smhip_synchronize(void) {
+    SMHIP_ACQUIRE(s);
+    SMHIP_TRY(hipStreamSynchronize(s));
+    return SMHIP_OK;
+}
+
+/* ---------------------------------------------------------------- memory */
+
+int smhip_alloc(void **dptr, size_t bytes) {
+    if (!dptr) return fail(SMHIP_ERR_INVALID, "alloc: null");
+    SMHIP_ACQUIRE(s);
+    const size_t cls = size_class(bytes);
+    const int dev = tls.device;
+    void *p = nullptr;
+    hipStream_t last = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto it = g_free.find({dev, cls});
+        if (it != g_free.end() && !it->second.empty()) {
+            p = it->second.back().first;
+            last = it->second.back().second;
+            it->second.pop_back();
+            g_bytes_cached -= cls;
+        }
+    }
+    if (p) {
+        // stream-ordered reuse: work queued by the previous owner on another
+        // stream must drain before the new owner writes
+        if (last != s) SMHIP_TRY(hipStreamSynchronize(last));
+    } else {
+        hipError_t e = hipMalloc(&p, cls);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            smhip_pool_trim();
+            e = hipMalloc(&p, cls);
+        }
+        if (e != hipSuccess) return fail(SMHIP_ERR_HIP, "hipMalloc(%zu): %s", cls, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_live[p] = Block{cls, dev, s};
+    g_bytes_live += cls;
+    *dptr = p;
+    return SMHIP_OK;
+}
+
+int smhip_free(void *dptr) {
+    if (!dptr) return SMHIP_OK;
+    hipStream_t s = nullptr;
+    if (tls.use_user_stream) s = tls.user_stream;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_live.find(dptr);
+    if (it == g_live.end()) return fail(SMHIP_ERR_INVALID, "free: %p was not allocated by smhip_alloc", dptr);
+    const Block b = it->second;
+    g_live.erase(it);
+    g_bytes_live -= b.cls;
+    if (!tls.use_user_stream) s = g_streams[b.device];
+    g_free[{b.device, b.cls}].push_back({dptr, s});
+    g_bytes_cached += b.cls;
+    return SMHIP_OK;
+}
+
+int smhip_pool_trim(void) {
+    std::vector<std::pair<int, void *>> victims;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (auto &kv : g_free) {
+            for (auto &e : kv.second) victims.push_back({kv.first.first, e.first});
+            kv.second.clear();
+        }
+        g_bytes_cached = 0;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &v : victims) {
+        (void)hipSetDevice(v.first);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(v.second);
+    }
+    (void)hipSetDevice(cur);
+    return SMHIP_OK;
+}
+
+int smhip_pool_stats(size_t *bytes_in_use, size_t *bytes_cached) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (bytes_in_use) *bytes_in_use = g_bytes_live;
+    if (bytes_cached) *bytes_cached = g_bytes_cached;
+    return SMHIP_OK;
+}
+
+int smhip_upload(void *dst, const void *src_host, size_t bytes) {
+    if (bytes == 0) return SMHIP_OK;
+    if (!dst || !src_host) return fail(SMHIP_ERR_INVALID, "upload: null");
+    SMHIP_ACQUIRE(s);
+    SMHIP_TRY(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, s));
+    SMHIP_TRY(hipStreamSynchronize(s));  // pageable source: the caller may reuse it at once
+    return SMHIP_OK;
+}
+
+int smhip_download(void *dst_host, const void *src, size_t bytes) {
+    if (bytes == 0) return SMHIP_OK;
+    if (!dst_host || !src) return fail(SMHIP_ERR_INVALID, "download: null");
+    SMHIP_ACQUIRE(s);
+    SMHIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, s));
+    SMHIP_TRY(hipStreamSynchronize(s));
+    return SMHIP_OK;
+}
+
+int smhip_copy(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return SMHIP_OK;
+    if (!dst || !src) return fail(SMHIP_ERR_INVALID, "copy: null");
+    SMHIP_ACQUIRE(s);
+    SMHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    return SMHIP_OK;
+}
+
+int smhip_fill(int dtype, void *dst, const void *value_host, size_t n) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fill: bad dtype %d", dtype);
+    if (n == 0) return SMHIP_OK;
+    if (!dst || !value_host) return fail(SMHIP_ERR_INVALID, "fill: null");
+    SMHIP_ACQUIRE(s);
+    return launch_fill(dtype, dst, value_host, n, s);
+}
+
+int smhip_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi) {
+    if (n == 0) return SMHIP_OK;
+    if (!dst) return fail(SMHIP_ERR_INVALID, "fill_uniform_f32: null");
+    SMHIP_ACQUIRE(s);
+    return launch_fill_uniform_f32(dst, n, seed, first, lo, hi, s);
+}
+
+/* ----------------------------------------------------------- shape layer */
+
+int smhip_broadcast(int nd1, const int64_t *shape1, const int64_t *strides1, int nd2, const int64_t *shape2,
+                    const int64_t *strides2, int64_t *result_shape, int64_t *new_strides1, int64_t *new_strides2,
+                    int64_t *total_size) {
+    if (nd1 < 0 || nd2 < 0 || (nd1 && (!shape1 || !strides1)) || (nd2 && (!shape2 || !strides2)))
+        return fail(SMHIP_ERR_INVALID, "broadcast: bad arguments");
+    const int nd = nd1 > nd2 ? nd1 : nd2;
+    if (nd && (!result_shape || !new_strides1 || !new_strides2)) return fail(SMHIP_ERR_INVALID, "broadcast: null output");
+    const int off1 = nd - nd1, off2 = nd - nd2;
+    int64_t total = 1;
+    for (int i = 0; i < nd; ++i) {
+        // right-align; absent leading dims count as extent 1 / stride 0 (SMUtils.h:51-72)
+        const int64_t d1 = i < off1 ? 1 : shape1[i - off1], d2 = i < off2 ? 1 : shape2[i - off2];
+        int64_t s1 = i < off1 ? 0 : strides1[i - off1], s2 = i < off2 ? 0 : strides2[i - off2];
+        if (d1 != d2 && d1 != 1 && d2 != 1)
+            return fail(SMHIP_ERR_BROADCAST, "Cannot broadcast shapes: incompatible dimensions");  // SMUtils.h:76-78
+        const int64_t d = d1 > d2 ? d1 : d2;
+        if (d1 == 1 && d2 > 1) s1 = 0;  // SMUtils.h:83-88
+        if (d2 == 1 && d1 > 1) s2 = 0;
+        result_shape[i] = d;
+        new_strides1[i] = s1;
+        new_strides2[i] = s2;
+        total *= d;
+    }
+    if (total_size) *total_size = total;
+    return nd;
+}
+
+int smhip_is_contiguous(int ndim, const int64_t *shape, const int64_t *strides) {
+    int64_t expected = 1;
+    for (int i = ndim - 1; i >= 0; --i) {
+        if (strides[i] != expected) return 0;
+        expected *= shape[i];
+    }
+    return 1;
+}
+
+/* -------------------------------------------------------------- hot path */
+
+int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a, const void *b, const int64_t *stride_b,
+                      const int64_t *shape, int ndim, void *out) {
+    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype);
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM)
+        return fail(SMHIP_ERR_INVALID, "elementwise: ndim %d outside 1..%d (the reference's MAX_NDIM, helpers.h:4)", ndim, SMHIP_MAX_NDIM);
+    if (!stride_a || !stride_b || !shape) return fail(SMHIP_ERR_INVALID, "elementwise: null shape/stride");
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0 || stride_a[i] < 0 || stride_b[i] < 0) return fail(SMHIP_ERR_INVALID, "elementwise: negative extent or stride at dim %d", i);
+        n *= shape[i];
+    }
+    if (n == 0) return SMHIP_OK;
+    if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
+}
+
+int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n) {
+    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
+    if (n == 0) return SMHIP_OK;
+    if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "contiguous: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_contiguous(op, dtype, a, b, out, n, s);
+}
+
+int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out) {
+    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "array_scalar: bad op %d / dtype %d", op, dtype);
+    if (n == 0) return SMHIP_OK;
+    if (!a || !value_host || !out) return fail(SMHIP_ERR_INVALID, "array_scalar: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_array_scalar(op, dtype, a, value_host, n, out, s);
+}
+
+int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "sum: bad dtype %d", dtype);
+    if (!out_dev || (n && !a)) return fail(SMHIP_ERR_INVALID, "sum: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_sum(dtype, a, n, out_dev, s);
+}
+
+int smhip_dot_async(int dtype, const void *a, const void *b, size_t n, double *out_dev) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
+    if (!out_dev || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_dot(dtype, a, b, n, out_dev, nullptr, s);
+}
+
+int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev) {
+    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "contiguous_sum: bad op %d / dtype %d", op, dtype);
+    if (!sum_dev || (n && (!a || !b || !out))) return fail(SMHIP_ERR_INVALID, "contiguous_sum: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_contiguous_sum(op, dtype, a, b, out, n, sum_dev, s);
+}
+
+int smhip_sum(int dtype, const void *a, size_t n, double *out_host) {
+    if (!out_host) return fail(SMHIP_ERR_INVALID, "sum: null result");
+    void *d = nullptr;
+    if (int rc = smhip_alloc(&d, sizeof(double))) return rc;
+    int rc = smhip_sum_async(dtype, a, n, static_cast<double *>(d));
+    if (!rc) rc = smhip_download(out_host, d, sizeof(double));
+    smhip_free(d);
+    return rc;
+}
+
+int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
+    if (!out_host || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot: null buffer");
+    void *d = nullptr;
+    if (int rc = smhip_alloc(&d, 16)) return rc;
+    hipStream_t s;
+    int rc = acquire(&s);
+    if (!rc) rc = launch_dot(dtype, a, b, n, nullptr, d, s);
+    if (!rc) rc = smhip_download(out_host, d, dtype_size(dtype));
+    smhip_free(d);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- timing */
+
+int smhip_event_create(void **event) {
+    if (!event) return fail(SMHIP_ERR_INVALID, "event_create: null");
+    SMHIP_ACQUIRE(s);
+    (void)s;
+    hipEvent_t e;
+    SMHIP_TRY(hipEventCreate(&e));
+    *event = e;
+    return SMHIP_OK;
+}
+
+int smhip_event_record(void *event) {
+    SMHIP_ACQUIRE(s);
+    SMHIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), s));
+    return SMHIP_OK;
+}
+
+int smhip_event_synchronize(void *event) {
+    SMHIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return SMHIP_OK;
+}
+
+int smhip_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!ms) return fail(SMHIP_ERR_INVALID, "event_elapsed_ms: null");
+    SMHIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return SMHIP_OK;
+}
+
+int smhip_event_destroy(void *event) {
+    if (event) SMHIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return SMHIP_OK;
+}
+
+}  // extern "C"
