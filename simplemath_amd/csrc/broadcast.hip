@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
     constexpr int W = VEC ? VecTraits<T>::width : 1;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int TY = 256 / TX;
+    OpCtx<Op> ctx;
+    ctx.init();
     const uint32_t tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const uint32_t col = blockIdx.x * TX + tx;  // vector slot within the row
     if (col >= p.vpr) return;
@@ -99,8 +101,7 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
         if (r >= (int)rows_here) break;
         const uint32_t row = row0 + r * TY;
         T res[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) res[k] = Op::apply(CONST_A ? ca[k] : va[r][k], CONST_B ? cb[k] : vb[r][k]);
+        apply_n<Op, T, W>(ctx, CONST_A ? ca : va[r], CONST_B ? cb : vb[r], res);
         T *dst = out + (size_t)row * p.inner + col_elem;
         if constexpr (VEC) {
             V v;

@@ -37,11 +37,13 @@ __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restri
                                                                T *__restrict__ out, size_t n_vec, int tail) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
+    OpCtx<Op> ctx;
+    ctx.init();
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
         const V va = load_stream(reinterpret_cast<const V *>(a) + i);
         const V vb = load_stream(reinterpret_cast<const V *>(b) + i);
-        store_stream(reinterpret_cast<V *>(out) + i, apply_vec<Op, T>(va, vb));
+        store_stream(reinterpret_cast<V *>(out) + i, apply_vec<Op, T>(ctx, va, vb));
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) out[n_vec * W + k] = Op::apply(a[n_vec * W + k], b[n_vec * W + k]);
     }
@@ -63,10 +65,12 @@ __global__ __launch_bounds__(BLOCK) void scalar_vec_kernel(const T *__restrict__
                                                            size_t n_vec, int tail) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
+    OpCtx<Op> ctx;
+    ctx.init();
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
         const V va = load_stream(reinterpret_cast<const V *>(a) + i);
-        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(va, s));
+        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s));
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
             const T x = a[n_vec * W + k];
@@ -101,11 +105,13 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
                                                               T *__restrict__ out, size_t n_vec, int tail) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
+    OpCtx<Op> ctx;
+    ctx.init();
     const T s = *sp;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
         const V va = load_stream(reinterpret_cast<const V *>(a) + i);
-        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(va, s));
+        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s));
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
             const T x = a[n_vec * W + k];

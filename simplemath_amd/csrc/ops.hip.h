@@ -105,13 +105,31 @@ template <> struct PowOp<float> { static __device__ __forceinline__ float apply(
 // f64 pow is a "next" row: ROCm's device libm keeps the API whole meanwhile.
 template <> struct PowOp<double> { static __device__ __forceinline__ double apply(double a, double b) { return ::pow(a, b); } };
 
+// Per-workgroup state an Op may need.  Kernels create one and call init() at
+// their top, before any early exit (init may contain a barrier).  Only
+// PowOp<float> has any: its 752-byte log2 breakpoint table, staged from
+// constant memory into LDS once per workgroup so the per-lane lookups are
+// ds_read_b128s instead of divergent global loads.
+template <typename Op> struct OpCtx {
+    __device__ __forceinline__ void init() {}
+};
+template <> struct OpCtx<PowOp<float>> {
+    const double *tab;
+    __device__ __forceinline__ void init() {
+        __shared__ __attribute__((aligned(16))) double lds_tab[2 * smpow::kTabN];
+        for (int i = threadIdx.x; i < 2 * smpow::kTabN; i += blockDim.x) lds_tab[i] = smpow::kLogTab[i];
+        __syncthreads();
+        tab = lds_tab;
+    }
+};
+
 // apply_simd's role: the Op across W independent elements held in registers.
-// PowOp<float> evaluates them side by side (one constant load per polynomial
-// step, no branches); every other Op is one instruction per element.
+// PowOp<float> evaluates them side by side (one constant per polynomial step,
+// no branches); every other Op is one instruction per element.
 template <typename Op, typename T, int W>
-__device__ __forceinline__ void apply_n(const T (&a)[W], const T (&b)[W], T (&r)[W]) {
+__device__ __forceinline__ void apply_n(const OpCtx<Op> &ctx, const T (&a)[W], const T (&b)[W], T (&r)[W]) {
     if constexpr (std::is_same<Op, PowOp<float>>::value) {
-        smpow::pow_n<W>(a, b, r);
+        smpow::pow_n<W>(a, b, r, ctx.tab);
     } else {
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);
@@ -120,12 +138,13 @@ __device__ __forceinline__ void apply_n(const T (&a)[W], const T (&b)[W], T (&r)
 
 // ... and across one 16-byte register group.
 template <typename Op, typename T>
-__device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec(typename VecTraits<T>::vec_t a, typename VecTraits<T>::vec_t b) {
+__device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec(const OpCtx<Op> &ctx, typename VecTraits<T>::vec_t a,
+                                                                  typename VecTraits<T>::vec_t b) {
     constexpr int W = VecTraits<T>::width;
     T xa[W], xb[W], xr[W];
 #pragma unroll
     for (int i = 0; i < W; ++i) { xa[i] = a[i]; xb[i] = b[i]; }
-    apply_n<Op, T, W>(xa, xb, xr);
+    apply_n<Op, T, W>(ctx, xa, xb, xr);
     typename VecTraits<T>::vec_t r;
 #pragma unroll
     for (int i = 0; i < W; ++i) r[i] = xr[i];
@@ -133,11 +152,11 @@ __device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec(typename VecTr
 }
 // SWAPPED = false: a[i] op s;  true: s op a[i]
 template <typename Op, typename T, bool SWAPPED>
-__device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec_scalar(typename VecTraits<T>::vec_t a, T s) {
+__device__ __forceinline__ typename VecTraits<T>::vec_t apply_vec_scalar(const OpCtx<Op> &ctx, typename VecTraits<T>::vec_t a, T s) {
     typename VecTraits<T>::vec_t sv;
 #pragma unroll
     for (int i = 0; i < VecTraits<T>::width; ++i) sv[i] = s;
-    return SWAPPED ? apply_vec<Op, T>(sv, a) : apply_vec<Op, T>(a, sv);
+    return SWAPPED ? apply_vec<Op, T>(ctx, sv, a) : apply_vec<Op, T>(ctx, a, sv);
 }
 
 // ------------------------------------------------------------- fast divmod

@@ -9,20 +9,23 @@
 // 1 ULP, so it is interchangeable with glibc powf under that bar.
 //
 // Method: x^y = 2^(y * log2|x|) with the whole exponent chain in fp64.
-//   log2|x| = e + t * P(t^2),  t = (m-1)/(m+1),  m in [~sqrt(1/2), ~sqrt(2))
-//             P = (2/ln2) * sum_{k<=6} w^k/(2k+1): the factor t is exact, so the
-//             error is RELATIVE to log2(m) (< 2^-39) -- it stays harmless when
-//             x is near 1 and y is huge;
-//             1/(m+1) = v_rcp_f64 seed (~2^-23) + one Newton step (~2^-46)
+//   |x| = 2^e * m, m in [~sqrt(1/2), ~sqrt(2));  c = k/64 the breakpoint nearest m
+//   log2|x| = e + logc[k] + r * Q(r),   r = m * invc[k] - 1,  |r| <= 2^-6.5
+//             {invc, logc} from a 47-entry table (752 B, staged in LDS by the kernels);
+//             the k = 64 entry is exactly {1, 0}, so around x = 1 the result
+//             r * Q(r) keeps its RELATIVE accuracy (< 2^-41) -- harmless even
+//             when x is near 1 and y is huge.  No division, no reciprocal.
 //   2^E     = 2^n * exp(f*ln2),  n = rint(E), |f| <= 1/2, degree-9 Taylor (< 2^-36)
 //   one rounding to f32 at the end (v_cvt_f32_f64), which also yields
 //   subnormal results, 0 and +inf correctly.
-// No tables, no MFMA (nothing to contract): ~31 fp64-rate VALU ops + 1 rcp per
-// element.  Everything is straight-line: W elements are evaluated side by side
-// (pow_n<W>) so each polynomial constant is materialised once per step and the
-// special cases are selects, not branches.  The special-case lattice is C99
-// F.9.4.4 / IEEE 754-2008 9.2.1 as glibc implements it (x^0 = 1 and 1^y = 1
-// even for quiet NaN, not for signalling NaN).
+// No MFMA (nothing to contract): ~27 fp64-rate VALU ops per element, measured
+// 4 cycles each per wave (tools/ubench_valu.hip).  Everything is straight-line:
+// W elements are evaluated side by side (pow_n<W>), polynomial constants come
+// from constant memory into SGPRs (so a Horner step is one v_fma_f64 with an
+// SGPR addend instead of two v_mov + v_fmac), and the special-case lattice is
+// skipped wave-uniformly when no lane needs it.  The lattice is C99 F.9.4.4 /
+// IEEE 754-2008 9.2.1 as glibc implements it (x^0 = 1 and 1^y = 1 even for
+// quiet NaN, not for signalling NaN).
 #pragma once
 
 #include <stdint.h>
@@ -36,34 +39,90 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SM_POW_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define SM_POW_RINT(x) __builtin_rint(x)
-// v_rcp_f64: ~2^-23 relative; one Newton step brings it to ~2^-46
-#define SM_POW_RCP_SEED(x) __builtin_amdgcn_rcp(x)
+#define SM_POW_FMIN(a, b) __builtin_fmin((a), (b))
+#define SM_POW_FMAX(a, b) __builtin_fmax((a), (b))
 #else
 #include <math.h>
 #define SM_POW_FMA(a, b, c) fma((a), (b), (c))
 #define SM_POW_RINT(x) rint(x)
-// host stand-in with the hardware seed's accuracy (24 bits), so the CPU check
-// exercises the same Newton refinement
-#define SM_POW_RCP_SEED(x) ((double)(float)(1.0 / (x)))
+#define SM_POW_FMIN(a, b) fmin((a), (b))
+#define SM_POW_FMAX(a, b) fmax((a), (b))
 #endif
 
 namespace smpow {
 
-// Polynomial constants.  On the device they sit in constant memory: a uniform
-// s_load puts them in SGPRs, and v_fma_f64 takes an SGPR pair as its addend,
-// so a Horner step is ONE VALU instruction (as VGPR immediates each step would
-// cost two extra v_mov_b32 -- as much issue time as the fma itself).
-//   [0..6]  (2/ln2) / (2k+1), k = 6 .. 0      log2 series in w = t^2
-//   [7]     ln2
-//   [8..15] 1/9!, 1/8!, ... 1/2!               exp series in g = f*ln2
-// (not `const` on the device, or the compiler folds the values back into immediates)
+constexpr int kTabFirst = 45, kTabLast = 91, kTabN = kTabLast - kTabFirst + 1;  // c = k/64
+
+// Device: constant memory (not `const`, or the compiler folds the values back
+// into 64-bit immediates that cost two v_mov_b32 per use).  Host: plain tables.
 #if defined(__HIPCC__)
-inline __constant__ double kC[16] = {
+#define SM_POW_TABLE inline __constant__ double
 #else
-static const double kC[16] = {
+#define SM_POW_TABLE static const double
 #endif
-    0.22195308321368667, 0.2623081892525388, 0.3205988979753252, 0.4121985831111324,
-    0.5770780163555853,  0.9617966939259756, 2.8853900817779268, 0.6931471805599453,
+
+// {invc, logc} pairs: invc = fl(64/k), logc = fl(log2(1/invc)); tools/gen_pow_table.py
+SM_POW_TABLE kLogTab[2 * kTabN] = {
+    0x1.6c16c16c16c17p+0, -0x1.042bd4b9a7c99p-1,  // k=45
+    0x1.642c8590b2164p+0, -0x1.e7df5fe538ab3p-2,  // k=46
+    0x1.5c9882b931057p+0, -0x1.c819dc2d45fe4p-2,  // k=47
+    0x1.5555555555555p+0, -0x1.a8ff971810a5dp-2,  // k=48
+    0x1.4e5e0a72f0539p+0, -0x1.8a8980abfbd30p-2,  // k=49
+    0x1.47ae147ae147bp+0, -0x1.6cb0f6865c8ebp-2,  // k=50
+    0x1.4141414141414p+0, -0x1.4f6fbb2cec598p-2,  // k=51
+    0x1.3b13b13b13b14p+0, -0x1.32bfee370ee6ap-2,  // k=52
+    0x1.3521cfb2b78c1p+0, -0x1.169c05363f157p-2,  // k=53
+    0x1.2f684bda12f68p+0, -0x1.f5fd8a9063e32p-3,  // k=54
+    0x1.29e4129e4129ep+0, -0x1.bfc67a7fff4cap-3,  // k=55
+    0x1.2492492492492p+0, -0x1.8a8980abfbd30p-3,  // k=56
+    0x1.1f7047dc11f70p+0, -0x1.563dc29ffacafp-3,  // k=57
+    0x1.1a7b9611a7b96p+0, -0x1.22dadc2ab3496p-3,  // k=58
+    0x1.15b1e5f75270dp+0, -0x1.e0b1ae8f2fd56p-4,  // k=59
+    0x1.1111111111111p+0, -0x1.7d60496cfbb4bp-4,  // k=60
+    0x1.0c9714fbcda3bp+0, -0x1.1bb32a60054a2p-4,  // k=61
+    0x1.0842108421084p+0, -0x1.77394c9d958d0p-5,  // k=62
+    0x1.0410410410410p+0, -0x1.743ee861f353fp-6,  // k=63
+    0x1.0000000000000p+0, 0x0.0p+0,  // k=64
+    0x1.f81f81f81f820p-1, 0x1.6e79685c2d212p-6,  // k=65
+    0x1.f07c1f07c1f08p-1, 0x1.6bad3758efd81p-5,  // k=66
+    0x1.e9131abf0b767p-1, 0x1.0eb389fa29f9dp-4,  // k=67
+    0x1.e1e1e1e1e1e1ep-1, 0x1.663f6fac91318p-4,  // k=68
+    0x1.dae6076b981dbp-1, 0x1.bc84240adabb9p-4,  // k=69
+    0x1.d41d41d41d41dp-1, 0x1.08c588cda79e5p-3,  // k=70
+    0x1.cd85689039b0bp-1, 0x1.32ae9e278ae19p-3,  // k=71
+    0x1.c71c71c71c71cp-1, 0x1.5c01a39fbd68bp-3,  // k=72
+    0x1.c0e070381c0e0p-1, 0x1.84c2bd02f03b6p-3,  // k=73
+    0x1.bacf914c1bad0p-1, 0x1.acf5e2db4ec91p-3,  // k=74
+    0x1.b4e81b4e81b4fp-1, 0x1.d49ee4c32596cp-3,  // k=75
+    0x1.af286bca1af28p-1, 0x1.fbc16b902680dp-3,  // k=76
+    0x1.a98ef606a63bep-1, 0x1.11307dad30b74p-2,  // k=77
+    0x1.a41a41a41a41ap-1, 0x1.24407ab0e073ap-2,  // k=78
+    0x1.9ec8e951033d9p-1, 0x1.37124cea4cdedp-2,  // k=79
+    0x1.999999999999ap-1, 0x1.49a784bcd1b8ap-2,  // k=80
+    0x1.948b0fcd6e9e0p-1, 0x1.5c01a39fbd689p-2,  // k=81
+    0x1.8f9c18f9c18fap-1, 0x1.6e221cd9d0cddp-2,  // k=82
+    0x1.8acb90f6bf3aap-1, 0x1.800a563161c53p-2,  // k=83
+    0x1.8618618618618p-1, 0x1.91bba891f170ap-2,  // k=84
+    0x1.8181818181818p-1, 0x1.a33760a7f6051p-2,  // k=85
+    0x1.7d05f417d05f4p-1, 0x1.b47ebf73882a1p-2,  // k=86
+    0x1.78a4c8178a4c8p-1, 0x1.c592fad295b57p-2,  // k=87
+    0x1.745d1745d1746p-1, 0x1.d6753e032ea0ep-2,  // k=88
+    0x1.702e05c0b8170p-1, 0x1.e726aa1e754d3p-2,  // k=89
+    0x1.6c16c16c16c17p-1, 0x1.f7a8568cb06cep-2,  // k=90
+    0x1.6816816816817p-1, 0x1.03fda8b97997ep-1,  // k=91
+};
+
+//   [0..5]  (-1)^i / ((i+1) ln2)              Q(r) = log2(1+r)/r
+//   [6]     ln2
+//   [7..14] 1/9!, 1/8!, ... 1/2!              exp series in g = f*ln2
+SM_POW_TABLE kC[15] = {
+    0x1.71547652b82fep+0,  // 1.4426950408889634
+    -0x1.71547652b82fep-1,  // -0.7213475204444817
+    0x1.ec709dc3a03fdp-2,  // 0.4808983469629878
+    -0x1.71547652b82fep-2,  // -0.36067376022224085
+    0x1.2776c50ef9bfep-2,  // 0.28853900817779266
+    -0x1.ec709dc3a03fdp-3,  // -0.2404491734814939
+    0.6931471805599453,
     2.7557319223985893e-06, 2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889,
     0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
 
@@ -85,54 +144,52 @@ SM_POW_FN int int_class(uint32_t iy) {
 }
 
 // 2^(y * log2(ax)) for W finite positive ax (subnormals included) and finite y,
-// rounded to f32.  Straight-line; the loops are over the W independent elements.
+// rounded to f32.  `tab` = kLogTab's layout (LDS copy on the device).
+// Straight-line; the loops are over the W independent elements.
 template <int W>
-SM_POW_FN void pow_core_n(const float (&ax)[W], const float (&y)[W], float (&out)[W]) {
-    double m[W], t[W], w[W], p[W], E[W], g[W], q[W];
-    int e[W];
+SM_POW_FN void pow_core_n(const float (&ax)[W], const float (&y)[W], float (&out)[W], const double *tab) {
+    double m[W], r[W], p[W], le[W], E[W], g[W], q[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         // exact widening; f32 subnormals become normal doubles
         const uint64_t db = f64_bits((double)ax[k]);
         const uint32_t hi = (uint32_t)(db >> 32), lo = (uint32_t)db;
         const uint32_t mant = hi & 0x000fffffu;
-        const uint32_t big = mant > 0x0006a09eu ? 1u : 0u;       // m > ~sqrt(2): use m/2, e+1
-        e[k] = (int)(hi >> 20) - 1023 + (int)big;
+        const bool big = mant > 0x0006a09eu;                     // m > ~sqrt(2): use m/2, e+1
+        const int e = (int)(hi >> 20) - 1023 + (big ? 1 : 0);
         m[k] = make_f64(mant | (big ? 0x3fe00000u : 0x3ff00000u), lo);
-    }
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-        const double den = m[k] + 1.0;
-        double r = SM_POW_RCP_SEED(den);
-        r = SM_POW_FMA(r, SM_POW_FMA(-den, r, 1.0), r);
-        t[k] = (m[k] - 1.0) * r;
-        w[k] = t[k] * t[k];
+        // k = round(64 m): m = 1+f -> 64 + round(64 f);  m = (1+f)/2 -> 32 + round(32 f)
+        const uint32_t idx = big ? (32u - kTabFirst) + ((mant + 0x4000u) >> 15) : (64u - kTabFirst) + ((mant + 0x2000u) >> 14);
+        const double invc = tab[2 * idx], logc = tab[2 * idx + 1];
+        r[k] = SM_POW_FMA(m[k], invc, -1.0);                     // exact when invc == 1
+        le[k] = logc + (double)e;
     }
 #define SM_POW_STEP(acc, x, c) for (int k = 0; k < W; ++k) acc[k] = SM_POW_FMA(acc[k], x[k], c)
 #pragma unroll
-    for (int k = 0; k < W; ++k) p[k] = kC[0];
+    for (int k = 0; k < W; ++k) p[k] = kC[5];
 #pragma unroll
-    SM_POW_STEP(p, w, kC[1]);
+    SM_POW_STEP(p, r, kC[4]);
 #pragma unroll
-    SM_POW_STEP(p, w, kC[2]);
+    SM_POW_STEP(p, r, kC[3]);
 #pragma unroll
-    SM_POW_STEP(p, w, kC[3]);
+    SM_POW_STEP(p, r, kC[2]);
 #pragma unroll
-    SM_POW_STEP(p, w, kC[4]);
+    SM_POW_STEP(p, r, kC[1]);
 #pragma unroll
-    SM_POW_STEP(p, w, kC[5]);
-#pragma unroll
-    SM_POW_STEP(p, w, kC[6]);
+    SM_POW_STEP(p, r, kC[0]);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        const double lg = SM_POW_FMA(t[k], p[k], (double)e[k]);  // log2(ax)
-        E[k] = (double)y[k] * lg;
+        const double lg = SM_POW_FMA(r[k], p[k], le[k]);         // log2(ax)
+        // |E| beyond +-300 is 0 / inf in f32 anyway; the clamp keeps 2^n * q a normal double
+        E[k] = SM_POW_FMIN(SM_POW_FMAX((double)y[k] * lg, -300.0), 300.0);
         const double n = SM_POW_RINT(E[k]);
-        g[k] = (E[k] - n) * kC[7];                               // f * ln2, |g| <= 0.3466
+        g[k] = (E[k] - n) * kC[6];                               // f * ln2, |g| <= 0.3466
         E[k] = n;
     }
 #pragma unroll
-    for (int k = 0; k < W; ++k) q[k] = kC[8];
+    for (int k = 0; k < W; ++k) q[k] = kC[7];
+#pragma unroll
+    SM_POW_STEP(q, g, kC[8]);
 #pragma unroll
     SM_POW_STEP(q, g, kC[9]);
 #pragma unroll
@@ -146,27 +203,44 @@ SM_POW_FN void pow_core_n(const float (&ax)[W], const float (&y)[W], float (&out
 #pragma unroll
     SM_POW_STEP(q, g, kC[14]);
 #pragma unroll
-    SM_POW_STEP(q, g, kC[15]);
-#pragma unroll
     SM_POW_STEP(q, g, 1.0);
 #pragma unroll
     SM_POW_STEP(q, g, 1.0);
 #undef SM_POW_STEP
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        // |E| beyond +-300 is 0 / inf in f32 anyway; the clamp keeps 2^n * q a normal double
-        const double nc = E[k] > 300.0 ? 300.0 : (E[k] < -300.0 ? -300.0 : E[k]);
-        const int n = (int)nc;
+        const int n = (int)E[k];
         const uint64_t qb = f64_bits(q[k]);                      // q in [0.70, 1.42]
         const double scaled = make_f64((uint32_t)(qb >> 32) + ((uint32_t)n << 20), (uint32_t)qb);
         out[k] = (float)scaled;
     }
 }
 
+// True when any lane of the wavefront (device) / the value itself (host) is set.
+SM_POW_FN bool any_lane(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(v) != 0;
+#else
+    return v;
+#endif
+}
+
 // x^y for W independent (x, y) pairs.
 template <int W>
-SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W]) {
+SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W], const double *tab) {
     const uint32_t ONE = 0x3f800000u, INF = 0x7f800000u, QNAN = 0x7fc00000u;
+    // Ordinary operands -- x positive, finite, non-zero; y finite, non-zero -- need none of
+    // the special-case lattice.  The test is wave-uniform (one ballot), so the usual case
+    // (e.g. BASELINE config 4: a in (0.01, 100), y = 2.5) runs the bare exp2/log2 chain and
+    // only wavefronts that actually hold a special lane pay for the selects below.
+    bool special = false;
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+        special |= (f32_bits(x[k]) - 1u >= INF - 1u) || ((f32_bits(y[k]) & 0x7fffffffu) - 1u >= INF - 1u);
+    if (!any_lane(special)) {
+        pow_core_n<W>(x, y, out, tab);
+        return;
+    }
     float axc[W], yc_f[W], core[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -175,7 +249,7 @@ SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W]) 
         axc[k] = bits_f32((ax == 0 || ax >= INF) ? ONE : ax);
         yc_f[k] = ay >= INF ? 1.0f : y[k];
     }
-    pow_core_n<W>(axc, yc_f, core);
+    pow_core_n<W>(axc, yc_f, core, tab);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         const uint32_t ix = f32_bits(x[k]), iy = f32_bits(y[k]);
@@ -198,10 +272,12 @@ SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W]) 
     }
 }
 
+// One element, table read from where it lives (constant memory on the device):
+// the per-element kernels and vector tails.
 SM_POW_FN float powf(float x, float y) {
     const float xs[1] = {x}, ys[1] = {y};
     float r[1];
-    pow_n<1>(xs, ys, r);
+    pow_n<1>(xs, ys, r, kLogTab);
     return r[0];
 }
 

@@ -129,8 +129,9 @@ def test_golden_dot(smhip, oracle):
             eps = np.finfo(a.dtype).eps
             # fp64 fma chain: one final rounding to the result type + n roundings at 2^-53 of the running sum
             assert abs(float(got) - exact) <= eps * abs(exact) + c["n"] * 2.0 ** -53 * scale, c["id"]
-            # and at least as close to the truth as the reference's lane accumulators are
-            assert abs(float(got) - exact) <= abs(float(ref) - exact) + eps * abs(exact), c["id"]
+            if a.dtype == np.float32:
+                # and at least as close to the truth as the reference's f32 lane accumulators are
+                assert abs(float(got) - exact) <= abs(float(ref) - exact) + eps * abs(exact), c["id"]
 
 
 def test_golden_powf(smhip):
