@@ -1,0 +1,484 @@
+// SMArray.h -- sm::SMArray<T>, the drop-in array class, MI355X-resident.
+//
+// Public surface of the reference's class (include/SMArray.h:30-438): public
+// `data` and `totalSize`; construction from (nested) initializer lists or from
+// an owned `new T[]` buffer plus a shape; move-only; operator()(ints...) for
+// element access and operator()(ints | Slice ...) for views; transpose(),
+// repeat(); % (dot), + - * / with an array (NumPy broadcasting) or a scalar;
+// toString(), shape(), strides().
+//
+// What is different underneath: an array's elements live in HBM.
+//   * Every array (and all views of it) shares one Storage: a pooled device
+//     buffer and, only when host code asks for it, a host mirror.  Two validity
+//     bits track which side is current.  `data`, operator()(i...) and toString()
+//     bring the host mirror up to date; arithmetic brings the device side up to
+//     date.  Writable host access (`data`, the T& form of operator()) marks the
+//     device side stale, so the reference's idiom `arr.data[i] = v; r = arr * 2;`
+//     keeps working.  A chain of operators never leaves the GPU.
+//   * + - * / % and sm::pow run libsmhip's gfx950 kernels through the C ABI
+//     (smhip.h) at the points where the reference calls element_wise_op /
+//     array_scalar_op / dot_product (SMArray.h:213-305).  Results are born on the
+//     device from a pooled allocator instead of `new T[n]` (SMArray.h:219).
+//   * There is no CPU arithmetic path: without libsmhip + a GPU the operators
+//     throw std::runtime_error.
+//
+// Deliberate deviations from reference quirks:
+//   1-D operands walk their strides (the reference reads them as dense);
+//   views know their real ndim/totalSize, so scalar ops, % and toString work on
+//   views; repeat() has NumPy semantics; rank > MAX_NDIM throws.
+#pragma once
+
+#include <cassert>
+#include <complex>
+#include <cstring>
+#include <functional>
+#include <initializer_list>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "SMUtils.h"
+#include "Slice.h"
+#include "math/calculate.h"
+#include "math/ops.h"
+#include "math/product.h"
+
+namespace sm {
+
+template <typename T>
+concept ArithmeticOrComplex =
+    std::is_arithmetic_v<T> ||
+    (requires { typename T::value_type; } && std::is_arithmetic_v<typename T::value_type> &&
+     std::same_as<T, std::complex<typename T::value_type>>);
+
+namespace detail {
+
+// One allocation, shared by an owning array and every view of it.
+template <typename T>
+struct Storage {
+    T *host = nullptr;
+    void *dev = nullptr;
+    std::size_t count = 0;
+    bool host_valid = false;  // host mirror holds the current values
+    bool dev_valid = false;   // device buffer holds the current values
+
+    explicit Storage(std::size_t n) : count(n) {}
+    Storage(T *adopted, std::size_t n) : host(adopted), count(n), host_valid(true) {}  // takes ownership of new T[]
+    Storage(const Storage &) = delete;
+    Storage &operator=(const Storage &) = delete;
+    ~Storage() {
+        if (dev) smhip_free(dev);
+        delete[] host;
+    }
+
+    // host side current, device side left valid (read-only intent)
+    const T *host_ro() {
+        if (!host) host = new T[count ? count : 1];
+        if (!host_valid) {
+            if (dev_valid) hip::check(smhip_download(host, dev, count * sizeof(T)));
+            host_valid = true;  // nothing valid anywhere: uninitialised, like sm::empty
+        }
+        return host;
+    }
+    // host side current and possibly about to be written: device side goes stale
+    T *host_rw() {
+        host_ro();
+        dev_valid = false;
+        return host;
+    }
+    // device side current, host mirror stays valid
+    T *dev_ro() {
+        if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
+        if (!dev_valid) {
+            if (host_valid) hip::check(smhip_upload(dev, host, count * sizeof(T)));
+            dev_valid = true;
+        }
+        return static_cast<T *>(dev);
+    }
+    // device side about to be overwritten entirely
+    T *dev_wo() {
+        if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
+        dev_valid = true;
+        host_valid = false;
+        return static_cast<T *>(dev);
+    }
+};
+
+// What `arr.data` is.  Converts to T* / indexes like T*; touching it through a
+// non-const route syncs the host mirror and marks the device copy stale.
+template <typename T>
+class HostPtr {
+public:
+    HostPtr() = default;
+    HostPtr(std::shared_ptr<Storage<T>> st, std::size_t offset) : st_(std::move(st)), offset_(offset) {}
+
+    operator T *() const { return st_ ? st_->host_rw() + offset_ : nullptr; }
+    T &operator[](std::size_t i) const { return (st_->host_rw() + offset_)[i]; }
+    T &operator*() const { return *(st_->host_rw() + offset_); }
+    T *operator+(std::ptrdiff_t d) const { return static_cast<T *>(*this) + d; }
+    explicit operator bool() const { return static_cast<bool>(st_); }
+    bool operator==(std::nullptr_t) const { return !st_; }
+    bool operator!=(std::nullptr_t) const { return static_cast<bool>(st_); }
+    HostPtr &operator=(std::nullptr_t) {  // `arr.data = nullptr;` gives the buffer up
+        st_.reset();
+        offset_ = 0;
+        return *this;
+    }
+
+    const T *read() const { return st_->host_ro() + offset_; }  // no invalidation
+    const std::shared_ptr<Storage<T>> &storage() const { return st_; }
+    std::size_t offset() const { return offset_; }
+
+private:
+    std::shared_ptr<Storage<T>> st_;
+    std::size_t offset_ = 0;
+};
+
+inline std::vector<std::size_t> dense_strides(const std::vector<std::size_t> &shape) {
+    std::vector<std::size_t> st(shape.size());
+    std::size_t acc = 1;
+    for (std::size_t i = shape.size(); i-- > 0;) {
+        st[i] = acc;
+        acc *= shape[i];
+    }
+    return st;
+}
+
+}  // namespace detail
+
+template <ArithmeticOrComplex T>
+class SMArray {
+public:
+    detail::HostPtr<T> data;
+    std::size_t totalSize = 0;
+
+    SMArray(const std::initializer_list<T> &list) {
+        _shape = {list.size()};
+        finish_owning(new T[list.size() ? list.size() : 1]);
+        std::copy(list.begin(), list.end(), static_cast<T *>(data));
+    }
+
+    SMArray(const std::initializer_list<SMArray> &list) {
+        const SMArray &first = *list.begin();
+        _shape.reserve(first._shape.size() + 1);
+        _shape.push_back(list.size());
+        _shape.insert(_shape.end(), first._shape.begin(), first._shape.end());
+        finish_owning(new T[calculateTotalSize(_shape)]);
+        T *dst = static_cast<T *>(data);
+        for (const SMArray &child : list) {
+            assert(child._shape == first._shape && "ragged nested initializer list");
+            child.copy_dense_to(dst);
+            dst += child.totalSize;
+        }
+    }
+
+    // Takes ownership of `buffer` (allocated with new T[]), exactly like the reference.
+    SMArray(T *buffer, std::vector<std::size_t> &&shape) {
+        _shape = std::move(shape);
+        finish_owning(buffer);
+    }
+
+    SMArray(SMArray &&other) noexcept = default;
+    SMArray(const SMArray &) = delete;
+    SMArray &operator=(const SMArray &) = delete;
+
+    // Element-wise copy into an existing array of the same shape (reference SMArray.h:89-97).
+    SMArray &operator=(const SMArray &&other) {
+        if (_shape != other._shape) throw std::runtime_error("Shape mismatch in assignment");
+        std::vector<T> tmp(other.totalSize ? other.totalSize : 1);
+        other.copy_dense_to(tmp.data());
+        T *base = static_cast<T *>(data);
+        for_each_offset([&](std::size_t linear, std::size_t off) { base[off] = tmp[linear]; });
+        return *this;
+    }
+
+    // arr(i, j, k) -> value;  arr(i, SLICE_ALL) -> view
+    template <typename... Args>
+        requires((std::is_integral_v<std::remove_cvref_t<Args>> || std::is_same_v<std::remove_cvref_t<Args>, Slice>) && ...)
+    auto operator()(Args &&...args) const {
+        if constexpr ((std::is_integral_v<std::remove_cvref_t<Args>> && ...)) {
+            return data.read()[offset_of({static_cast<std::size_t>(args)...}, false)];
+        } else {
+            return make_view({processIndex(std::forward<Args>(args))...});
+        }
+    }
+
+    template <typename... Args>
+        requires((std::is_integral_v<std::remove_cvref_t<Args>> && ...))
+    T &operator()(Args &&...args) {
+        return data[offset_of({static_cast<std::size_t>(args)...}, true)];
+    }
+
+    SMArray transpose() const {
+        SMArray v;
+        v.data = data;
+        v._shape.assign(_shape.rbegin(), _shape.rend());
+        v._strides.assign(_strides.rbegin(), _strides.rend());
+        v.ndim = ndim;
+        v.totalSize = totalSize;
+        v.isView = true;
+        return v;
+    }
+
+    // NumPy semantics: every element repeated `numberOfRepeats` times, flattened.
+    SMArray repeat(int numberOfRepeats) const {
+        assert(numberOfRepeats >= 1);
+        std::vector<T> flat(totalSize ? totalSize : 1);
+        copy_dense_to(flat.data());
+        T *out = new T[totalSize * numberOfRepeats ? totalSize * numberOfRepeats : 1];
+        for (std::size_t i = 0, o = 0; i < totalSize; ++i)
+            for (int r = 0; r < numberOfRepeats; ++r) out[o++] = flat[i];
+        return SMArray(out, {totalSize * static_cast<std::size_t>(numberOfRepeats)});
+    }
+
+    SMArray repeat(int numberOfRepeats, int axis) const {
+        assert(axis >= 0 && axis < static_cast<int>(ndim) && numberOfRepeats >= 1);
+        if (ndim == 1) return repeat(numberOfRepeats);
+        std::vector<T> flat(totalSize ? totalSize : 1);
+        copy_dense_to(flat.data());
+        std::vector<std::size_t> newShape = _shape;
+        newShape[axis] *= numberOfRepeats;
+        std::size_t inner = 1, outer = 1;
+        for (std::size_t i = axis + 1; i < ndim; ++i) inner *= _shape[i];
+        for (int i = 0; i < axis; ++i) outer *= _shape[i];
+        T *out = new T[calculateTotalSize(newShape) ? calculateTotalSize(newShape) : 1];
+        T *dst = out;
+        for (std::size_t o = 0; o < outer; ++o)
+            for (std::size_t j = 0; j < _shape[axis]; ++j)
+                for (int r = 0; r < numberOfRepeats; ++r) {
+                    std::memcpy(dst, flat.data() + (o * _shape[axis] + j) * inner, inner * sizeof(T));
+                    dst += inner;
+                }
+        return SMArray(out, std::move(newShape));
+    }
+
+    // Dot product over all elements (reference SMArray.h:213-215 -> dot_product<T>).
+    T operator%(const SMArray &arr) const {
+        if (totalSize != arr.totalSize) throw std::runtime_error("dot product: element counts differ");
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            std::unique_ptr<SMArray> lhs_holder, rhs_holder;
+            const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
+            return hip::dot_device<T>(pa, pb, totalSize);
+        } else {
+            throw std::runtime_error("operator%: this element type has no gfx950 kernels yet (no CPU fallback)");
+        }
+    }
+
+    SMArray operator+(const SMArray &arr) const { return apply<AddOp<T>>(arr); }
+    SMArray operator-(const SMArray &arr) const { return apply<SubtractOp<T>>(arr); }
+    SMArray operator*(const SMArray &arr) const { return apply<MultiplyOp<T>>(arr); }
+    SMArray operator/(const SMArray &arr) const { return apply<DivideOp<T>>(arr); }
+    SMArray operator+(const T val) const { return apply_scalar<AddOp<T>>(val); }
+    SMArray operator-(const T val) const { return apply_scalar<SubtractOp<T>>(val); }
+    SMArray operator*(const T val) const { return apply_scalar<MultiplyOp<T>>(val); }
+    SMArray operator/(const T val) const { return apply_scalar<DivideOp<T>>(val); }
+
+    // Broadcasted `*this Op rhs` for any Op policy: what a user-added operator calls
+    // (the README's "add the operator in SMArray.h" step, without editing the class).
+    template <typename Op>
+    SMArray apply(const SMArray &rhs) const {
+        auto br = sm::broadcast(_shape, _strides, rhs._shape, rhs._strides);
+        if (br.resultShape.size() > MAX_NDIM) throw std::runtime_error("rank exceeds MAX_NDIM");
+        if constexpr (hip::on_device_v<T, Op>) {
+            SMArray out = device_empty(std::move(br.resultShape));
+            hip::element_wise_op_device<T, Op>(device_data(), br.newStrides1, rhs.device_data(), br.newStrides2,
+                                               out.device_data_mut(), out._shape);
+            return out;
+        } else {
+            T *result = new T[br.totalSize ? br.totalSize : 1];
+            try {
+                element_wise_op<T, Op>(data.read(), br.newStrides1, rhs.data.read(), br.newStrides2, br.totalSize, result,
+                                       br.resultShape);
+            } catch (...) {
+                delete[] result;
+                throw;
+            }
+            return SMArray(result, std::move(br.resultShape));
+        }
+    }
+
+    // `*this Op scalar` element-wise; shape preserved (reference SMArray.h:226-237 and siblings).
+    template <typename Op>
+    SMArray apply_scalar(T value) const {
+        if constexpr (hip::on_device_v<T, Op>) {
+            SMArray out = device_empty(std::vector<std::size_t>(_shape));
+            if (is_dense()) {
+                hip::array_scalar_op_device<T, Op>(device_data(), value, totalSize, out.device_data_mut());
+            } else {  // a view: honour its strides (the reference reads views as flat here)
+                hip::DeviceBuffer s(sizeof(T));
+                hip::check(smhip_upload(s.get(), &value, sizeof(T)));
+                hip::element_wise_op_device<T, Op>(device_data(), _strides, s.template as<T>(),
+                                                   std::vector<std::size_t>(_shape.size(), 0), out.device_data_mut(), _shape);
+            }
+            return out;
+        } else {
+            std::vector<T> flat(totalSize ? totalSize : 1);
+            copy_dense_to(flat.data());
+            T *result = new T[totalSize ? totalSize : 1];
+            try {
+                array_scalar_op<T, Op>(flat.data(), value, totalSize, result);
+            } catch (...) {
+                delete[] result;
+                throw;
+            }
+            return SMArray(result, std::vector<std::size_t>(_shape));
+        }
+    }
+
+    [[nodiscard]] std::string toString() const {
+        std::ostringstream oss;
+        const T *base = data.read();
+        std::function<void(std::size_t, std::size_t)> emit = [&](std::size_t offset, std::size_t dim) {
+            oss << "[";
+            for (std::size_t i = 0; i < _shape[dim]; ++i) {
+                if (dim + 1 == _shape.size()) {
+                    if (i) oss << ", ";
+                    oss << base[offset + i * _strides[dim]];
+                } else {
+                    if (i) oss << ",\n";
+                    emit(offset + i * _strides[dim], dim + 1);
+                }
+            }
+            oss << "]";
+        };
+        if (_shape.empty()) return "[]";
+        emit(0, 0);
+        return oss.str();
+    }
+
+    [[nodiscard]] const std::vector<std::size_t> &shape() const { return _shape; }
+    [[nodiscard]] const std::vector<std::size_t> &strides() const { return _strides; }
+
+    ~SMArray() = default;  // Storage is reference-counted: the last owner/view releases it
+
+    // ---- MI355X extensions (not in the reference) -------------------------------
+    // Device pointer to this array's first element, values current.  Valid until the
+    // array (and its views) die.  Work is stream-ordered on libsmhip's stream.
+    const T *device_data() const { return data.storage()->dev_ro() + data.offset(); }
+    T *device_data_mut() { return data.storage()->dev_wo() + data.offset(); }
+    bool is_dense() const { return is_contiguous(_shape, _strides); }
+    bool is_view() const { return isView; }
+
+    // A new dense array whose elements exist only in HBM so far.
+    static SMArray device_empty(std::vector<std::size_t> &&shape) {
+        SMArray a;
+        a._shape = std::move(shape);
+        a._strides = detail::dense_strides(a._shape);
+        a.ndim = a._shape.size();
+        a.totalSize = calculateTotalSize(a._shape);
+        a.data = detail::HostPtr<T>(std::make_shared<detail::Storage<T>>(a.totalSize), 0);
+        return a;
+    }
+    static SMArray device_full(std::vector<std::size_t> &&shape, T value) {
+        SMArray a = device_empty(std::move(shape));
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            hip::check(smhip_fill(hip::dtype_of<T>::id, a.device_data_mut(), &value, a.totalSize));
+        } else {
+            T *h = static_cast<T *>(a.data);
+            for (std::size_t i = 0; i < a.totalSize; ++i) h[i] = value;
+        }
+        return a;
+    }
+    // Dense copy of a (possibly strided) array, made on the device.
+    SMArray contiguous() const {
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            return apply_scalar<MultiplyOp<T>>(T{1});
+        } else {
+            T *out = new T[totalSize ? totalSize : 1];
+            copy_dense_to(out);
+            return SMArray(out, std::vector<std::size_t>(_shape));
+        }
+    }
+    // Sum of all elements, accumulated in fp64 on the device.
+    double sum() const {
+        static_assert(hip::dtype_of<T>::id >= 0, "sum(): element type has no kernels");
+        std::unique_ptr<SMArray> holder;
+        const T *p = dense_device(holder);
+        double s = 0;
+        hip::check(smhip_sum(hip::dtype_of<T>::id, p, totalSize, &s));
+        return s;
+    }
+
+private:
+    std::vector<std::size_t> _shape;
+    std::vector<std::size_t> _strides;
+    std::size_t ndim = 0;
+    bool isView = false;
+
+    SMArray() = default;  // internal: views and device-born results
+
+    void finish_owning(T *buffer) {
+        ndim = _shape.size();
+        totalSize = calculateTotalSize(_shape);
+        _strides = detail::dense_strides(_shape);
+        data = detail::HostPtr<T>(std::make_shared<detail::Storage<T>>(buffer, totalSize), 0);
+    }
+
+    std::size_t offset_of(std::initializer_list<std::size_t> indices, [[maybe_unused]] bool exact) const {
+        assert((exact ? indices.size() == _shape.size() : indices.size() <= _shape.size()) && "wrong number of indices");
+        std::size_t off = 0, k = 0;
+        for (std::size_t idx : indices) {
+            assert(idx < _shape[k] && "Index out of bounds");
+            off += idx * _strides[k++];
+        }
+        return off;
+    }
+
+    // f(linear, element offset) over all elements in row-major order
+    template <typename F>
+    void for_each_offset(F &&f) const {
+        std::vector<std::size_t> idx(_shape.size(), 0);
+        for (std::size_t linear = 0; linear < totalSize; ++linear) {
+            std::size_t off = 0;
+            for (std::size_t k = 0; k < idx.size(); ++k) off += idx[k] * _strides[k];
+            f(linear, off);
+            for (std::size_t k = idx.size(); k-- > 0;) {
+                if (++idx[k] < _shape[k]) break;
+                idx[k] = 0;
+            }
+        }
+    }
+
+    void copy_dense_to(T *dst) const {
+        const T *base = data.read();
+        if (is_dense()) std::copy(base, base + totalSize, dst);
+        else for_each_offset([&](std::size_t linear, std::size_t off) { dst[linear] = base[off]; });
+    }
+
+    // Device pointer to a dense version of this array (itself when already dense).
+    const T *dense_device(std::unique_ptr<SMArray> &holder) const {
+        if (is_dense()) return device_data();
+        holder.reset(new SMArray(contiguous()));
+        return holder->device_data();
+    }
+
+    // arr(i, SLICE(a, b), ...): INDEX entries drop their axis, Slice entries keep a sub-range;
+    // missing trailing entries mean SLICE_ALL.  Shares storage (reference SMArray.h:397-437).
+    SMArray make_view(std::initializer_list<Slice> slices) const {
+        SMArray v;
+        std::size_t off = data.offset();
+        std::size_t axis = 0;
+        auto it = slices.begin();
+        for (; axis < _shape.size(); ++axis) {
+            const Slice s = it != slices.end() ? *it++ : Slice(0);
+            assert(s.start <= _shape[axis] && "slice start out of bounds");
+            off += s.start * _strides[axis];
+            if (s.sliceType == Slice::INDEX) continue;
+            const std::size_t stop = s.open_ended() ? _shape[axis] : s.end;
+            assert(stop <= _shape[axis] && stop >= s.start && "slice end out of bounds");
+            v._shape.push_back(stop - s.start);
+            v._strides.push_back(_strides[axis]);
+        }
+        v.data = detail::HostPtr<T>(data.storage(), off);
+        v.ndim = v._shape.size();
+        v.totalSize = calculateTotalSize(v._shape);
+        v.isView = true;
+        return v;
+    }
+};
+
+}  // namespace sm

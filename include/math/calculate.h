@@ -1,0 +1,180 @@
+// calculate.h -- the loop entry points of the drop-in host side.
+//
+// Same three global templates, same signatures, same meaning as the reference
+// (include/math/calculate.h:5-8, 101-102, 137-138):
+//
+//   element_wise_op<T,Op>(a, stride_a, b, stride_b, n, result, shape)
+//   handle_contiguous_arrays<T,Op>(a, b, result, n)
+//   array_scalar_op<T,Op>(a, value, n, result)
+//
+// They take HOST pointers, block until `result` is filled, return void -- and
+// run the loop on the MI355X: operands are staged into pooled device buffers,
+// the Op's gfx950 functor runs (libsmhip: smhip_elementwise / smhip_contiguous /
+// smhip_array_scalar), the result is copied back.  That keeps code that calls
+// these directly (the README's "add the operator in SMArray.h" recipe) working,
+// at PCIe speed.  sm::SMArray's own operators do NOT come through here: they
+// keep their data resident in HBM and call the device-pointer forms in
+// sm::hip below, which is the hot path.
+//
+// Errors: the reference has no error channel here (void, UB on bad input);
+// a failing device call throws std::runtime_error, the library's single
+// exception type (SMUtils.h:76-78).
+//
+// User-defined Ops: an Op with no device functor (sm::hip::device_op<Op>::id < 0)
+// is refused with a std::runtime_error naming it.  Defining
+// SM_ENABLE_HOST_PLUGIN_OPS before including this header instead runs such an
+// Op's own `apply` in a plain host loop -- the plugin's code executing where it
+// was written for; the five built-in Ops can never take that route.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+#include <vector>
+
+#include "helpers.h"
+#include "ops.h"
+#include "smhip.h"
+
+namespace sm::hip {
+
+inline void check(int rc) {
+    if (rc < 0) throw std::runtime_error(std::string("smhip: ") + smhip_last_error());
+}
+
+// RAII pooled device buffer (smhip_alloc / smhip_free).
+class DeviceBuffer {
+public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(std::size_t bytes) { check(smhip_alloc(&ptr_, bytes ? bytes : 1)); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    DeviceBuffer(DeviceBuffer &&o) noexcept : ptr_(o.ptr_) { o.ptr_ = nullptr; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept {
+        if (this != &o) { reset(); ptr_ = o.ptr_; o.ptr_ = nullptr; }
+        return *this;
+    }
+    ~DeviceBuffer() { reset(); }
+    void reset() { if (ptr_) { smhip_free(ptr_); ptr_ = nullptr; } }
+    void *get() const { return ptr_; }
+    template <typename T> T *as() const { return static_cast<T *>(ptr_); }
+private:
+    void *ptr_ = nullptr;
+};
+
+inline std::vector<std::int64_t> to_i64(const std::vector<std::size_t> &v) { return {v.begin(), v.end()}; }
+
+// Elements an operand spans: 1 + sum (extent-1) * stride.
+inline std::size_t span_of(const std::vector<std::size_t> &shape, const std::vector<std::size_t> &stride) {
+    std::size_t last = 0;
+    for (std::size_t i = 0; i < shape.size(); ++i) {
+        if (shape[i] == 0) return 0;
+        last += (shape[i] - 1) * stride[i];
+    }
+    return last + 1;
+}
+
+// ---- device-pointer forms: what SMArray's operators call (the hot path) ----
+template <typename T, typename Op>
+void element_wise_op_device(const T *a, const std::vector<std::size_t> &stride_a, const T *b,
+                            const std::vector<std::size_t> &stride_b, T *result, const std::vector<std::size_t> &shape) {
+    static_assert(on_device_v<T, Op>, "no gfx950 functor for this Op / element type");
+    const auto sa = to_i64(stride_a), sb = to_i64(stride_b), sh = to_i64(shape);
+    check(smhip_elementwise(device_op<Op>::id, dtype_of<T>::id, a, sa.data(), b, sb.data(), sh.data(),
+                            static_cast<int>(sh.size()), result));
+}
+
+template <typename T, typename Op>
+void array_scalar_op_device(const T *a, T value, std::size_t n, T *result) {
+    static_assert(on_device_v<T, Op>, "no gfx950 functor for this Op / element type");
+    check(smhip_array_scalar(device_op<Op>::id, dtype_of<T>::id, a, &value, n, result));
+}
+
+template <typename T, typename Op>
+[[noreturn]] void refuse_host_op() {
+    throw std::runtime_error(std::string("simpleMath/MI355X: Op '") + typeid(Op).name() +
+                             "' has no device functor (sm::hip::device_op<Op>::id < 0) or its element type has no "
+                             "kernels; there is no silent CPU fallback. Define SM_ENABLE_HOST_PLUGIN_OPS to run a "
+                             "user-defined Op's own apply() on the host.");
+}
+
+}  // namespace sm::hip
+
+template <typename T, typename Operation>
+void handle_contiguous_arrays(const T *a, const T *b, T *result, std::size_t n);
+
+template <typename T, typename Operation>
+void element_wise_op(const T *a, const std::vector<std::size_t> &stride_a, const T *b,
+                     const std::vector<std::size_t> &stride_b, std::size_t n, T *result,
+                     const std::vector<std::size_t> &shape) {
+    using namespace sm::hip;
+    if constexpr (on_device_v<T, Operation>) {
+        if (shape.size() > MAX_NDIM) throw std::runtime_error("element_wise_op: rank exceeds MAX_NDIM");
+        if (n == 0) return;
+        const std::size_t na = span_of(shape, stride_a), nb = span_of(shape, stride_b);
+        DeviceBuffer da(na * sizeof(T)), db(nb * sizeof(T)), dr(n * sizeof(T));
+        check(smhip_upload(da.get(), a, na * sizeof(T)));
+        check(smhip_upload(db.get(), b, nb * sizeof(T)));
+        element_wise_op_device<T, Operation>(da.template as<T>(), stride_a, db.template as<T>(), stride_b,
+                                             dr.template as<T>(), shape);
+        check(smhip_download(result, dr.get(), n * sizeof(T)));
+    } else {
+#if defined(SM_ENABLE_HOST_PLUGIN_OPS)
+        // a user plugin without a device functor: its own apply(), where it was written for
+        std::vector<std::size_t> idx(shape.size(), 0);
+        for (std::size_t linear = 0; linear < n; ++linear) {
+            std::size_t oa = 0, ob = 0;
+            for (std::size_t k = 0; k < shape.size(); ++k) { oa += idx[k] * stride_a[k]; ob += idx[k] * stride_b[k]; }
+            result[linear] = Operation::apply(a[oa], b[ob]);
+            for (std::size_t k = shape.size(); k-- > 0;) {
+                if (++idx[k] < shape[k]) break;
+                idx[k] = 0;
+            }
+        }
+#else
+        (void)a; (void)stride_a; (void)b; (void)stride_b; (void)n; (void)result; (void)shape;
+        refuse_host_op<T, Operation>();
+#endif
+    }
+}
+
+template <typename T, typename Operation>
+void handle_contiguous_arrays(const T *a, const T *b, T *result, std::size_t n) {
+    using namespace sm::hip;
+    if constexpr (on_device_v<T, Operation>) {
+        if (n == 0) return;
+        DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T)), dr(n * sizeof(T));
+        check(smhip_upload(da.get(), a, n * sizeof(T)));
+        check(smhip_upload(db.get(), b, n * sizeof(T)));
+        check(smhip_contiguous(device_op<Operation>::id, dtype_of<T>::id, da.get(), db.get(), dr.get(), n));
+        check(smhip_download(result, dr.get(), n * sizeof(T)));
+    } else {
+#if defined(SM_ENABLE_HOST_PLUGIN_OPS)
+        for (std::size_t i = 0; i < n; ++i) result[i] = Operation::apply(a[i], b[i]);
+#else
+        (void)a; (void)b; (void)result; (void)n;
+        refuse_host_op<T, Operation>();
+#endif
+    }
+}
+
+template <typename T, typename Operation>
+void array_scalar_op(const T *a, T value, const std::size_t n, T *result) {
+    using namespace sm::hip;
+    if constexpr (on_device_v<T, Operation>) {
+        if (n == 0) return;
+        DeviceBuffer da(n * sizeof(T)), dr(n * sizeof(T));
+        check(smhip_upload(da.get(), a, n * sizeof(T)));
+        array_scalar_op_device<T, Operation>(da.template as<T>(), value, n, dr.template as<T>());
+        check(smhip_download(result, dr.get(), n * sizeof(T)));
+    } else {
+#if defined(SM_ENABLE_HOST_PLUGIN_OPS)
+        for (std::size_t i = 0; i < n; ++i) result[i] = Operation::apply(a[i], value);
+#else
+        (void)a; (void)value; (void)n; (void)result;
+        refuse_host_op<T, Operation>();
+#endif
+    }
+}

@@ -1,0 +1,76 @@
+// ops.h -- the Op policy structs (the plugin contract) and their device mapping.
+//
+// Contract kept from the reference (include/math/add.h:5-14 and siblings,
+// README "Extending with Custom Operations"): a stateless struct template in
+// the global namespace with
+//     static T apply(const T& a, const T& b);                  // scalar meaning
+//     template<class R> static R apply_simd(const R&, const R&);  // register form, declared only
+// `apply` stays the definition of what the Op means.  What changes is where the
+// loop runs: sm::hip::device_op<Op>::id names the functor libsmhip's gfx950
+// kernels instantiate for it (simplemath_amd/csrc/ops.hip.h).  The five
+// built-in Ops always run on the device; a user Op without a device functor is
+// refused loudly unless the build opts into running it on the host (see
+// math/calculate.h, SM_ENABLE_HOST_PLUGIN_OPS).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <type_traits>
+
+#include "helpers.h"
+#include "smhip.h"
+
+template <typename T>
+struct AddOp {
+    static T apply(const T &a, const T &b) { return a + b; }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
+};
+
+template <typename T>
+struct SubtractOp {
+    static T apply(const T &a, const T &b) { return a - b; }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
+};
+
+template <typename T>
+struct MultiplyOp {
+    static T apply(const T &a, const T &b) { return a * b; }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
+};
+
+template <typename T>
+struct DivideOp {
+    static T apply(const T &a, const T &b) { return a / b; }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
+};
+
+template <typename T>
+struct PowOp {
+    static T apply(const T &base, const T &exponent) { return static_cast<T>(std::pow(base, exponent)); }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &base, const SIMD_T &exponent);
+};
+
+namespace sm::hip {
+
+// Element types the kernels are built for (any signed 32/64-bit integer type maps by size).
+template <typename T> struct dtype_of {
+    static constexpr int id = std::is_same_v<T, float>    ? static_cast<int>(SMHIP_F32)
+                              : std::is_same_v<T, double> ? static_cast<int>(SMHIP_F64)
+                              : (std::is_integral_v<T> && std::is_signed_v<T> && sizeof(T) == 4) ? static_cast<int>(SMHIP_I32)
+                              : (std::is_integral_v<T> && std::is_signed_v<T> && sizeof(T) == 8) ? static_cast<int>(SMHIP_I64)
+                                                                                                 : -1;
+};
+
+// Op -> device functor.  Specialise for your own Op once libsmhip carries a
+// functor for it; id < 0 means "no device implementation".
+template <typename Op> struct device_op { static constexpr int id = -1; };
+template <typename T> struct device_op<AddOp<T>> { static constexpr int id = SMHIP_OP_ADD; };
+template <typename T> struct device_op<SubtractOp<T>> { static constexpr int id = SMHIP_OP_SUB; };
+template <typename T> struct device_op<MultiplyOp<T>> { static constexpr int id = SMHIP_OP_MUL; };
+template <typename T> struct device_op<DivideOp<T>> { static constexpr int id = SMHIP_OP_DIV; };
+template <typename T> struct device_op<PowOp<T>> { static constexpr int id = SMHIP_OP_POW; };
+
+template <typename T, typename Op>
+inline constexpr bool on_device_v = (dtype_of<T>::id >= 0) && (device_op<Op>::id >= 0);
+
+}  // namespace sm::hip

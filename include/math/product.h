@@ -1,0 +1,40 @@
+// product.h -- dot_product<T>, the library's reduction (drop-in for the
+// reference's include/math/product.h:8-224; reached through SMArray::operator%).
+//
+// Host pointers in, one T out, synchronous -- computed by libsmhip's reduction
+// kernels (smhip_dot): wavefront shuffle tree + LDS across waves, accumulating in
+// fp64 for float/double (the reference's 8 f32 lane accumulators stop absorbing
+// addends at 2^24 each) and in wrapping integers for int32/int64 (bit-identical
+// to the reference in any order).  std::complex<double> is a "next" row
+//  and is refused for now.
+#pragma once
+
+#include <complex>
+#include <cstddef>
+#include <stdexcept>
+
+#include "calculate.h"
+
+namespace sm::hip {
+template <typename T>
+T dot_device(const T *a, const T *b, std::size_t n) {
+    static_assert(dtype_of<T>::id >= 0, "dot_product: element type has no kernels");
+    T out{};
+    check(smhip_dot(dtype_of<T>::id, a, b, n, &out));
+    return out;
+}
+}  // namespace sm::hip
+
+template <typename T>
+T dot_product(const T *a, const T *b, std::size_t n) {
+    using namespace sm::hip;
+    if constexpr (dtype_of<T>::id >= 0) {
+        if (n == 0) return T{};
+        DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T));
+        check(smhip_upload(da.get(), a, n * sizeof(T)));
+        check(smhip_upload(db.get(), b, n * sizeof(T)));
+        return dot_device<T>(da.template as<T>(), db.template as<T>(), n);
+    } else {
+        throw std::runtime_error("dot_product: this element type has no gfx950 kernels yet (no CPU fallback)");
+    }
+}

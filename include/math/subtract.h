@@ -1,0 +1,4 @@
+// subtract.h -- kept so that `#include "math/subtract.h"` from code written against
+// simpleMath keeps working; the Op policies live together in math/ops.h.
+#pragma once
+#include "ops.h"

@@ -1,0 +1,49 @@
+// benchmark/add.cpp on MI355X: simple_check and million_check, the bodies of the
+// reference's benchmark/add.cpp:4-29, through the drop-in header.  As in the
+// reference the timed body is the operator call plus the result's destruction;
+// here the result is born in (and returned to) libsmhip's device pool, and the
+// clock stops after the stream has drained.  `large_check` adds BASELINE config
+// 2's size (N = 2^28) with the achieved HBM rate.
+#include <sm.h>
+
+#include "minibench.h"
+
+int main() {
+    using namespace minibench;
+    auto sync = [] { sm::synchronize(); };
+    header();
+
+    print(run("simple_check", [] {  // benchmark/add.cpp:4-19: build a 5x5 array and add it to itself
+        sm::SMArray<float> ac = {{1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}};
+        auto result = ac + ac;
+        DoNotOptimize(result);
+        ClobberMemory();
+    }, sync));
+
+    {
+        const sm::SMArray<float> one = sm::ones<float>(1'000'000);  // benchmark/add.cpp:21-29
+        const sm::SMArray<float> two = sm::ones<float>(1'000'000);
+        auto r = run("million_check", [&] {
+            auto result = one + two;
+            DoNotOptimize(result);
+            ClobberMemory();
+        }, sync);
+        char extra[96];
+        std::snprintf(extra, sizeof extra, "%.1f Gelem/s", 1e6 / r.ns_per_iter);
+        print(r, extra);
+    }
+    {
+        const std::size_t n = std::size_t(1) << 28;
+        const sm::SMArray<float> one = sm::ones<float>(n);
+        const sm::SMArray<float> two = sm::ones<float>(n);
+        auto r = run("large_check/2^28", [&] {
+            auto result = one + two;
+            DoNotOptimize(result);
+            ClobberMemory();
+        }, sync, 50);
+        char extra[96];
+        std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s (12 B/elem)", n / r.ns_per_iter, 12.0 * n / r.ns_per_iter);
+        print(r, extra);
+    }
+    return 0;
+}

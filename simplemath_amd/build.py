@@ -70,5 +70,43 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST_PROGRAMS = {
+    # output (under simplemath_amd/bin/)  ->  source
+    "test_reference_suite": os.path.join(ROOT, "tests", "cpp", "test_reference_suite.cpp"),
+    "pow_host_check": os.path.join(ROOT, "tests", "cpp", "pow_host_check.cpp"),
+    "benchmark_add": os.path.join(PKG, "benchmark", "add.cpp"),
+    "benchmark_pow": os.path.join(PKG, "benchmark", "pow.cpp"),
+}
+BINDIR = os.path.join(PKG, "bin")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host_programs(force: bool = False) -> dict:
+    """g++-compile the header-only C++ host side's programs against libsmhip.so."""
+    os.makedirs(BINDIR, exist_ok=True)
+    inc = os.path.join(ROOT, "include")
+    hdrs = []
+    for dp, _, fs in os.walk(inc):
+        hdrs += [os.path.join(dp, f) for f in fs]
+    hdrs += [os.path.join(CSRC, "sm_pow.h"), os.path.join(PKG, "benchmark", "minibench.h")]
+    out = {}
+    for name, src in HOST_PROGRAMS.items():
+        exe = os.path.join(BINDIR, name)
+        out[name] = exe
+        if not (force or _newer(exe, [src] + hdrs)):
+            continue
+        if name == "pow_host_check":  # pure host check of the pow algorithm: no GPU library involved
+            cmd = [CXX, "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", f"-I{CSRC}", src, "-o", exe]
+        else:
+            cmd = [CXX, "-std=c++20", "-O2", "-Wall", "-Wextra", f"-I{inc}", f"-I{os.path.join(PKG, 'benchmark')}", src, "-o", exe,
+                   f"-L{LIBDIR}", "-lsmhip", "-Wl,-rpath,$ORIGIN/../lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    for k, v in build_host_programs(force="--force" in sys.argv).items():
+        print(v)

@@ -1,0 +1,17 @@
+"""The float pow algorithm itself (simplemath_amd/csrc/sm_pow.h, the source the gfx950
+kernels inline), compiled for the host and swept against the correctly rounded x**y:
+8.8 M (x, y) pairs incl. subnormals, values near 1 with huge exponents, the whole
+special-case lattice against libm."""
+import os
+import re
+import subprocess
+
+
+def test_pow_algorithm_on_host():
+    from simplemath_amd import build
+    exe = build.build_host_programs()["pow_host_check"]
+    out = subprocess.run([exe], capture_output=True, text=True, check=True, timeout=300).stdout
+    m = re.search(r"max_ulp (\d+) over (\d+)", out)
+    assert m and int(m.group(2)) > 8_000_000
+    assert int(m.group(1)) <= 1, out          # parity bar is 4 ULP; the fp64 chain achieves 1
+    assert "lattice_mismatches 0" in out, out
