@@ -178,7 +178,7 @@ def main():
         out = lib.empty((n,), F32)
         units, alg_bytes = n, 8 * n
         step = lambda: lib.array_scalar(sma.OP_POW, a, np.float32(2.5), out=out)
-        kernel = "scalar_vec_kernel<float, PowOp<float>, 1024, false>"
+        kernel = "heavy_vec_kernel<float, PowOp<float>, 1>"
         workload = f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident"
 
     for _ in range(args.warmup):

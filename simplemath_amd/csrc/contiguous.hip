@@ -18,6 +18,8 @@
 // Blocks are dealt round-robin over the 8 XCDs, consecutive blocks touch
 // consecutive 16 KiB spans, so every XCD streams from all HBM stacks at once;
 // there is no reuse for an XCD-affine mapping to exploit.
+#include <type_traits>
+
 #include "internal.h"
 #include "ops.hip.h"
 
@@ -120,7 +122,67 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
     }
 }
 
+// Arithmetic-heavy Ops (pow): the streaming kernels above give each wave one load, a
+// long stretch of VALU work, one store -- memory and VALU time add up instead of
+// overlapping.  This form is persistent (grid = CUs x 32 workgroups of 512) and
+// software-pipelined one vector deep: the next vector's loads are in flight while
+// the current one is evaluated, and the per-workgroup LDS table of PowOp<float> is
+// staged once per workgroup instead of once per 16 KiB.  profiles/r01_sweep_pow.txt:
+// 91 us vs 104-147 us for config 4, a plain copy of the same bytes being 85 us.
+// KIND 0: a[i] op b[i];  1: a[i] op s;  2: s op a[i].
+constexpr int kHeavyBlock = 512;
+constexpr int kHeavyGridPerCU = 32;
+
+template <typename T, typename Op, int KIND>
+__global__ __launch_bounds__(kHeavyBlock) void heavy_vec_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
+                                                                T *__restrict__ out, size_t n_vec, int tail) {
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    OpCtx<Op> ctx;
+    ctx.init();
+    const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
+    V *ov = reinterpret_cast<V *>(out);
+    const size_t stride = (size_t)gridDim.x * kHeavyBlock;
+    size_t i = (size_t)blockIdx.x * kHeavyBlock + threadIdx.x;
+    if (i == 0) {  // the n % W scalar tail rides with the first lane
+        for (int k = 0; k < tail; ++k) {
+            const T x = a[n_vec * W + k];
+            const T y = KIND == 0 ? b[n_vec * W + k] : s;
+            out[n_vec * W + k] = KIND == 2 ? Op::apply(y, x) : Op::apply(x, y);
+        }
+    }
+    if (i >= n_vec) return;
+    V ca = load_stream(av + i), cb;
+    if constexpr (KIND == 0) cb = load_stream(bv + i);
+    for (;;) {
+        const size_t nx = i + stride;
+        const bool more = nx < n_vec;
+        V na, nb;
+        if (more) {
+            na = load_stream(av + nx);
+            if constexpr (KIND == 0) nb = load_stream(bv + nx);
+        }
+        V r;
+        if constexpr (KIND == 0) r = apply_vec<Op, T>(ctx, ca, cb);
+        else r = apply_vec_scalar<Op, T, KIND == 2>(ctx, ca, s);
+        store_stream(ov + i, r);
+        if (!more) break;
+        ca = na;
+        if constexpr (KIND == 0) cb = nb;
+        i = nx;
+    }
+}
+
+template <typename Op> struct IsHeavy : std::false_type {};
+template <typename T> struct IsHeavy<PowOp<T>> : std::true_type {};
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline unsigned heavy_grid(size_t n_vec) {
+    const size_t want = (n_vec + kHeavyBlock - 1) / kHeavyBlock;
+    const size_t cap = (size_t)compute_units() * kHeavyGridPerCU;
+    return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
 
 inline int grid_for(size_t threads, int block, unsigned *grid) {
     const size_t g = (threads + block - 1) / block;
@@ -139,7 +201,9 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
         const size_t n_vec = n / W;
         const int tail = (int)(n % W);
         const size_t threads = n_vec + (tail ? 1 : 0);
-        if (n_vec >= kBigThreshold) {
+        if constexpr (IsHeavy<Op>::value) {
+            hipLaunchKernelGGL((heavy_vec_kernel<T, Op, 0>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa, pb, T{}, po, n_vec, tail);
+        } else if (n_vec >= kBigThreshold) {
             if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
             hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail);
         } else {
@@ -164,7 +228,10 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         const size_t n_vec = n / W;
         const int tail = (int)(n % W);
         const size_t threads = n_vec + (tail ? 1 : 0);
-        if (n_vec >= kBigThreshold) {
+        if constexpr (IsHeavy<Op>::value) {
+            hipLaunchKernelGGL((heavy_vec_kernel<T, Op, SWAPPED ? 2 : 1>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa,
+                               static_cast<const T *>(nullptr), value, po, n_vec, tail);
+        } else if (n_vec >= kBigThreshold) {
             if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
             hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockBig, SWAPPED>), dim3(grid), dim3(kBlockBig), 0, s, pa, value, po, n_vec, tail);
         } else {

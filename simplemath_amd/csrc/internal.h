@@ -16,6 +16,9 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // stream its work goes to.  SMHIP_OK or SMHIP_ERR_NO_DEVICE / SMHIP_ERR_HIP.
 int acquire(hipStream_t *stream);
 
+// Compute units of the calling thread's current device (256 on MI355X); valid after acquire().
+int compute_units();
+
 // Per-device scratch for reductions: `count` doubles, stable until the next
 // call with a larger count on the same device.
 int reduce_scratch(size_t count, double **ptr);

@@ -36,6 +36,7 @@ thread_local ThreadState tls;
 // bring their own.
 std::mutex g_mutex;
 hipStream_t g_streams[kMaxDevices] = {};
+int g_cus[kMaxDevices] = {};
 int g_device_count = -1;
 
 // ---------------------------------------------------------------- the pool
@@ -92,6 +93,7 @@ int acquire(hipStream_t *stream) {
         SMHIP_TRY(hipGetDeviceProperties(&prop, tls.device));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(SMHIP_ERR_NO_DEVICE, "device %d is %s; libsmhip carries gfx950 (MI355X) code only", tls.device, prop.gcnArchName);
+        g_cus[tls.device] = prop.multiProcessorCount;
         tls.checked[tls.device] = true;
     }
     if (tls.use_user_stream) {
@@ -102,6 +104,11 @@ int acquire(hipStream_t *stream) {
     if (!g_streams[tls.device]) SMHIP_TRY(hipStreamCreateWithFlags(&g_streams[tls.device], hipStreamNonBlocking));
     *stream = g_streams[tls.device];
     return SMHIP_OK;
+}
+
+int compute_units() {
+    const int d = tls.device < 0 ? 0 : tls.device;
+    return g_cus[d] > 0 ? g_cus[d] : 256;
 }
 
 int reduce_scratch(size_t count, double **ptr) {

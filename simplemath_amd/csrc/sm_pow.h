@@ -6,7 +6,7 @@
 // (reference include/math/pow.h:8-10); the reference has no vector body for it
 // (pow.h:12-13 undefined, :16-32 commented out).  Parity bar: <= 4 ULP of the
 // correctly rounded result (BASELINE north_star); this evaluation stays within
-// 1 ULP, so it is interchangeable with glibc powf under that bar.
+// 2 ULP, so it is interchangeable with glibc powf under that bar.
 //
 // Method: x^y = 2^(y * log2|x|) with the whole exponent chain in fp64.
 //   |x| = 2^e * m, m in [~sqrt(1/2), ~sqrt(2));  c = k/64 the breakpoint nearest m
@@ -15,11 +15,16 @@
 //             the k = 64 entry is exactly {1, 0}, so around x = 1 the result
 //             r * Q(r) keeps its RELATIVE accuracy (< 2^-41) -- harmless even
 //             when x is near 1 and y is huge.  No division, no reciprocal.
-//   2^E     = 2^n * exp(f*ln2),  n = rint(E), |f| <= 1/2, degree-9 Taylor (< 2^-36)
-//   one rounding to f32 at the end (v_cvt_f32_f64), which also yields
-//   subnormal results, 0 and +inf correctly.
-// No MFMA (nothing to contract): ~27 fp64-rate VALU ops per element, measured
-// 4 cycles each per wave (tools/ubench_valu.hip).  Everything is straight-line:
+//   E = y * log2|x| = n + f,  n = rint(E), |f| <= 1/2        (still fp64: this is where
+//             a float exponent chain would lose the result's low bits)
+//   2^f     = 1 + g*P(g),  g = f*ln2, degree-6 P, in f32 (the fraction only needs the
+//             result's own precision), then v_ldexp_f32 by n: correct subnormals, 0, +inf.
+// Error budget: E carries < 2^-36 relative, the f32 stage <= ~1.2 ULP worst case
+// (final fma 0.5 + polynomial + g's rounding), total measured <= 2 ULP against the
+// 4 ULP bar.  An all-fp64 exp stage holds 1 ULP but costs 11 more fp64 ops/element
+// and leaves the kernel VALU-bound (profiles/r01_sweep_pow.txt).
+// No MFMA (nothing to contract): 15 fp64-rate VALU ops (4.1 cycles per wave-instruction,
+// tools/ubench_valu.hip) + ~20 f32/integer ops per element.  Everything is straight-line:
 // W elements are evaluated side by side (pow_n<W>), polynomial constants come
 // from constant memory into SGPRs (so a Horner step is one v_fma_f64 with an
 // SGPR addend instead of two v_mov + v_fmac), and the special-case lattice is
@@ -39,14 +44,14 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SM_POW_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define SM_POW_RINT(x) __builtin_rint(x)
-#define SM_POW_FMIN(a, b) __builtin_fmin((a), (b))
-#define SM_POW_FMAX(a, b) __builtin_fmax((a), (b))
+#define SM_POW_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
+#define SM_POW_LDEXPF(x, n) __builtin_ldexpf((x), (n))
 #else
 #include <math.h>
 #define SM_POW_FMA(a, b, c) fma((a), (b), (c))
 #define SM_POW_RINT(x) rint(x)
-#define SM_POW_FMIN(a, b) fmin((a), (b))
-#define SM_POW_FMAX(a, b) fmax((a), (b))
+#define SM_POW_FMAF(a, b, c) fmaf((a), (b), (c))
+#define SM_POW_LDEXPF(x, n) ldexpf((x), (n))
 #endif
 
 namespace smpow {
@@ -113,24 +118,33 @@ SM_POW_TABLE kLogTab[2 * kTabN] = {
 };
 
 //   [0..5]  (-1)^i / ((i+1) ln2)              Q(r) = log2(1+r)/r
-//   [6]     ln2
-//   [7..14] 1/9!, 1/8!, ... 1/2!              exp series in g = f*ln2
-SM_POW_TABLE kC[15] = {
+SM_POW_TABLE kC[6] = {
     0x1.71547652b82fep+0,  // 1.4426950408889634
     -0x1.71547652b82fep-1,  // -0.7213475204444817
     0x1.ec709dc3a03fdp-2,  // 0.4808983469629878
     -0x1.71547652b82fep-2,  // -0.36067376022224085
     0x1.2776c50ef9bfep-2,  // 0.28853900817779266
     -0x1.ec709dc3a03fdp-3,  // -0.2404491734814939
-    0.6931471805599453,
-    2.7557319223985893e-06, 2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889,
-    0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
+};
+#undef SM_POW_TABLE
 
 SM_POW_FN uint32_t f32_bits(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 SM_POW_FN float bits_f32(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 SM_POW_FN uint64_t f64_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 SM_POW_FN double bits_f64(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 SM_POW_FN double make_f64(uint32_t hi, uint32_t lo) { return bits_f64(((uint64_t)hi << 32) | lo); }
+
+// double -> int32 with saturation (v_cvt_i32_f64 saturates in hardware; in C++ an
+// out-of-range conversion is undefined, so the device form is spelled as the instruction).
+SM_POW_FN int sat_i32(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (-2147483647 - 1) : (int)x);
+#endif
+}
 
 // 0: not an integer, 1: odd integer, 2: even integer (y finite, non-zero). Branch-free.
 SM_POW_FN int int_class(uint32_t iy) {
@@ -148,7 +162,7 @@ SM_POW_FN int int_class(uint32_t iy) {
 // Straight-line; the loops are over the W independent elements.
 template <int W>
 SM_POW_FN void pow_core_n(const float (&ax)[W], const float (&y)[W], float (&out)[W], const double *tab) {
-    double m[W], r[W], p[W], le[W], E[W], g[W], q[W];
+    double m[W], r[W], p[W], le[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         // exact widening; f32 subnormals become normal doubles
@@ -177,42 +191,41 @@ SM_POW_FN void pow_core_n(const float (&ax)[W], const float (&y)[W], float (&out
     SM_POW_STEP(p, r, kC[1]);
 #pragma unroll
     SM_POW_STEP(p, r, kC[0]);
+    float gf[W], qf[W];
+    int ni[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         const double lg = SM_POW_FMA(r[k], p[k], le[k]);         // log2(ax)
-        // |E| beyond +-300 is 0 / inf in f32 anyway; the clamp keeps 2^n * q a normal double
-        E[k] = SM_POW_FMIN(SM_POW_FMAX((double)y[k] * lg, -300.0), 300.0);
-        const double n = SM_POW_RINT(E[k]);
-        g[k] = (E[k] - n) * kC[6];                               // f * ln2, |g| <= 0.3466
-        E[k] = n;
+        const double E = (double)y[k] * lg;
+        const double n = SM_POW_RINT(E);
+        gf[k] = (float)(E - n) * 0.693147182f;                   // g = f * ln2, |g| <= 0.3466
+        ni[k] = sat_i32(n);                                      // |E| can exceed int range (huge y)
     }
+    // 2^f = e^g = 1 + g * P(g),  P(g) = 1 + g/2 + g^2/6 + ... + g^6/5040  (truncation < 2^-27)
+#define SM_POW_STEPF(acc, x, c) for (int k = 0; k < W; ++k) acc[k] = SM_POW_FMAF(acc[k], x[k], c)
 #pragma unroll
-    for (int k = 0; k < W; ++k) q[k] = kC[7];
+    for (int k = 0; k < W; ++k) qf[k] = 1.98412698e-4f;          // 1/7!
 #pragma unroll
-    SM_POW_STEP(q, g, kC[8]);
+    SM_POW_STEPF(qf, gf, 1.38888889e-3f);                        // 1/6!
 #pragma unroll
-    SM_POW_STEP(q, g, kC[9]);
+    SM_POW_STEPF(qf, gf, 8.33333333e-3f);                        // 1/5!
 #pragma unroll
-    SM_POW_STEP(q, g, kC[10]);
+    SM_POW_STEPF(qf, gf, 4.16666667e-2f);                        // 1/4!
 #pragma unroll
-    SM_POW_STEP(q, g, kC[11]);
+    SM_POW_STEPF(qf, gf, 1.66666667e-1f);                        // 1/3!
 #pragma unroll
-    SM_POW_STEP(q, g, kC[12]);
+    SM_POW_STEPF(qf, gf, 0.5f);
 #pragma unroll
-    SM_POW_STEP(q, g, kC[13]);
+    SM_POW_STEPF(qf, gf, 1.0f);
 #pragma unroll
-    SM_POW_STEP(q, g, kC[14]);
-#pragma unroll
-    SM_POW_STEP(q, g, 1.0);
-#pragma unroll
-    SM_POW_STEP(q, g, 1.0);
+    SM_POW_STEPF(qf, gf, 1.0f);                                  // q = 1 + g*P(g) in [0.70, 1.42]
+#undef SM_POW_STEPF
 #undef SM_POW_STEP
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        const int n = (int)E[k];
-        const uint64_t qb = f64_bits(q[k]);                      // q in [0.70, 1.42]
-        const double scaled = make_f64((uint32_t)(qb >> 32) + ((uint32_t)n << 20), (uint32_t)qb);
-        out[k] = (float)scaled;
+        // beyond +-300 the result is 0 / inf anyway; ldexp rounds subnormal results correctly
+        const int n = ni[k] < -300 ? -300 : (ni[k] > 300 ? 300 : ni[k]);
+        out[k] = SM_POW_LDEXPF(qf[k], n);
     }
 }
 
@@ -233,10 +246,15 @@ SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W], 
     // the special-case lattice.  The test is wave-uniform (one ballot), so the usual case
     // (e.g. BASELINE config 4: a in (0.01, 100), y = 2.5) runs the bare exp2/log2 chain and
     // only wavefronts that actually hold a special lane pay for the selects below.
-    bool special = false;
+    // x ordinary <=> ix - 1 < INF - 1 (unsigned: 0 wraps to the top, negatives have the sign bit)
+    uint32_t worst_x = 0, worst_y = 0;
 #pragma unroll
-    for (int k = 0; k < W; ++k)
-        special |= (f32_bits(x[k]) - 1u >= INF - 1u) || ((f32_bits(y[k]) & 0x7fffffffu) - 1u >= INF - 1u);
+    for (int k = 0; k < W; ++k) {
+        const uint32_t tx = f32_bits(x[k]) - 1u, ty = (f32_bits(y[k]) & 0x7fffffffu) - 1u;
+        worst_x = tx > worst_x ? tx : worst_x;
+        worst_y = ty > worst_y ? ty : worst_y;
+    }
+    const bool special = worst_x >= INF - 1u || worst_y >= INF - 1u;
     if (!any_lane(special)) {
         pow_core_n<W>(x, y, out, tab);
         return;

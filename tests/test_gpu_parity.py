@@ -5,7 +5,7 @@ properties at BASELINE.json's full sizes, (5) edge cases.
 
 Bars (BASELINE north_star): int32/int64 bit-exact; f32/f64 + - * / bit-exact
 (one correctly rounded IEEE op on both sides; a NaN result's payload is not
-compared); f32 pow within 4 ULP of the correctly rounded value (measured: 1);
+compared); f32 pow within 4 ULP of the correctly rounded value (budget 2, measured 1);
 reductions against the fp64 oracle with the tolerance stated at each test.
 """
 import numpy as np
@@ -150,7 +150,7 @@ def test_golden_powf(smhip):
         nn = sp & ~np.isnan(ref)
         util.assert_same_bits(got[nn], ref[nn], c["id"] + " specials")
         worst = max(worst, int(d_exact.max()))
-    assert worst <= 1  # what the fp64 exp2/log2 chain actually achieves
+    assert worst <= 2  # sm_pow.h's own error budget (fp64 log2 chain + f32 exp stage); 1 observed
 
 
 # ---------------------------------------------- 3. oracle on seeded random inputs
@@ -218,6 +218,29 @@ def test_random_broadcast_vs_oracle(smhip, oracle):
         got = smhip.binary(sma.OPS[op], da.view_like(av, a), db.view_like(bv, b)).numpy()
         want = oracle.binary(orc.OPS[op], av, bv)
         util.assert_same_bits(got, want, f"trial {trial} {dtn} {op} {av.shape} {bv.shape}")
+
+
+def test_broadcast_pow_vs_oracle(smhip, oracle):
+    """pow through the row / gather / device-scalar kernels (elementwise exponents, not just sm::pow's scalar)."""
+    base = gen.gen(np.float32, 37 * 64, 21, "positive").reshape(37, 64)
+    for eshape in ((1, 64), (37, 1), (37, 64), (1,), (64,)):
+        e = gen.gen(np.float32, int(np.prod(eshape)), 22, "uniform").reshape(eshape)
+        got = smhip.binary(sma.OP_POW, smhip.to_device(base), smhip.to_device(e)).numpy()
+        with np.errstate(all="ignore"):
+            exact = np.power(base.astype(np.float64), e.astype(np.float64)).astype(np.float32)
+        assert orc.ulp_diff_f32(got, exact).max() <= POW_ULP, eshape
+        assert orc.ulp_diff_f32(got, oracle.binary(orc.POW, base, e)).max() <= POW_ULP, eshape
+    bt = base.T  # transposed base: gather kernel
+    db = smhip.to_device(base)
+    e = gen.gen(np.float32, 37, 23, "uniform").reshape(1, 37)
+    got = smhip.binary(sma.OP_POW, db.view_like(bt, base), smhip.to_device(e)).numpy()
+    with np.errstate(all="ignore"):
+        exact = np.power(bt.astype(np.float64), e.astype(np.float64)).astype(np.float32)
+    assert orc.ulp_diff_f32(got, exact).max() <= POW_ULP
+    ib = (gen.gen(np.int32, 37 * 64, 24, "uniform") % 20).astype(np.int32).reshape(37, 64)
+    ie = (gen.gen(np.int32, 64, 25, "uniform") % 9 - 2).astype(np.int32).reshape(1, 64)
+    got = smhip.binary(sma.OP_POW, smhip.to_device(ib), smhip.to_device(ie)).numpy()
+    assert np.array_equal(got, oracle.binary(orc.POW, ib, ie))
 
 
 def test_1d_strided_is_walked_not_assumed_dense(smhip):
