@@ -43,6 +43,7 @@ WORKLOADS = {
     "bcast_mul": (None, "2D float32 (4096x4096) * (1x4096) broadcast multiply (BASELINE config 3)"),
     "pow": (8, "1D float32 pow(a, 2.5), N=2^26 (BASELINE config 4)"),
     "add_sum": (12, "1D float32 fused add + sum, 2^28 per GPU (BASELINE config 5 shard)"),
+    "transpose_add": (12, "2D float32 (8192x8192).T + (8192x8192): a transpose() view operand (SURVEY 8f rank 1)"),
 }
 
 
@@ -171,6 +172,17 @@ def main():
         step = lambda: lib.binary(sma.OP_MUL, A2, r2, out=out)
         kernel = "row_kernel<float, MultiplyOp<float>, VEC, 1, 1, false, true, 256, 4>"
         workload = "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident"
+    elif wl == "transpose_add":
+        rows = cols = 8192
+        A = lib.uniform_f32(rows * cols, 8, -1.0, 1.0)
+        B = lib.uniform_f32(rows * cols, 9, -1.0, 1.0)
+        AT = sma.DeviceArray(lib, A.base_ptr, F32, (cols, rows), (1, cols), 0, A._owner)  # A.transpose()
+        B2 = sma.DeviceArray(lib, B.base_ptr, F32, (cols, rows), (rows, 1), 0, B._owner)
+        out = lib.empty((cols, rows), F32)
+        units, alg_bytes = rows * cols, 12 * rows * cols
+        step = lambda: lib.binary(sma.OP_ADD, AT, B2, out=out)
+        kernel = "tile_kernel<float, AddOp<float>, true>"
+        workload = "2D float32 A.T + B, 8192x8192, A read through a transposed view, HBM-resident"
     else:  # pow
         log2n = args.log2n or 26
         n = 1 << log2n

@@ -13,7 +13,15 @@
 //                  is one scalar per row, and an operand with all-zero outer
 //                  strides (the (1 x 4096) row of BASELINE config 3) is loaded
 //                  once per workgroup and kept in registers across its rows;
-//   gather kernel  anything else (transposed views, tiny inner extents): W
+//   tile kernel    an operand whose own contiguous axis is NOT the output's inner
+//                  axis (transpose() views, permuted 3-D+ views): 64 x 64 patches of
+//                  the (p, q) plane -- p = the operand's contiguous axis, q = the
+//                  output's inner axis -- are read coalesced along p, turned through
+//                  a padded LDS tile, and consumed coalesced along q.  The reference
+//                  walks such operands with a div/mod chain and a strided scalar load
+//                  per element; a naive GPU gather would touch one 64-byte line per
+//                  lane (16x read amplification).
+//   gather kernel  whatever is left (tiny extents, irregular strides): W
 //                  consecutive outputs per lane so the store is still a
 //                  coalesced 16-byte vector; operand loads are per-element
 //                  gathers through fast-division unravel.
@@ -161,6 +169,112 @@ __global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, co
     }
 }
 
+// ------------------------------------------------------------------ tile kernel
+constexpr int kTile = 64;
+
+struct TileParams {
+    // plane axes: p (operand-contiguous axis), q (output inner axis)
+    uint32_t np, nq;            // extents
+    int64_t a_p, a_q, b_p, b_q; // operand strides along p and q (elements)
+    int64_t o_p;                // output stride along p (its q stride is 1)
+    int mode_a, mode_b;         // 0: read along q (stride 0/1 there, or anything: direct); 1: through LDS (contiguous along p)
+    // remaining axes, innermost first
+    int n_rest;
+    FastDiv rest[SMHIP_MAX_NDIM - 2];
+    int64_t a_r[SMHIP_MAX_NDIM - 2], b_r[SMHIP_MAX_NDIM - 2], o_r[SMHIP_MAX_NDIM - 2];
+    uint32_t tiles_p, tiles_q;
+};
+
+// One workgroup = one 64 x 64 patch (i along p, j along q) of one slice of the remaining axes.
+// VEC: every global access is a 16-byte vector (W elements) -- along p for the operands that
+// are turned through LDS, along q for direct operands and the output.  LDS tiles are stored
+// already transposed ([i][j], pitch 65 words: the 4-byte scatter of phase 1 and the row reads
+// of phase 2 are both at most 2-way bank conflicted).  !VEC: one element per access, for
+// extents / pitches / bases that are not multiples of 16 bytes.
+template <typename T, typename Op, bool VEC>
+__global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                   TileParams p) {
+    constexpr int W = VEC ? VecTraits<T>::width : 1;
+    constexpr int VPR = kTile / W;             // vector slots per patch row
+    constexpr int STEPS = kTile * VPR / 256;   // per thread
+    typedef typename VecTraits<T>::vec_t V;
+    __shared__ T lds_a[kTile][kTile + 1];      // [i][j]
+    __shared__ T lds_b[kTile][kTile + 1];
+    OpCtx<Op> ctx;
+    ctx.init();
+    uint32_t bid = blockIdx.x;
+    const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;
+    const uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;
+    int64_t offA = 0, offB = 0, offO = 0;
+    for (int k = 0; k < p.n_rest; ++k) {
+        uint32_t qd, idx;
+        p.rest[k].divmod(bid, qd, idx);
+        bid = qd;
+        offA += (int64_t)idx * p.a_r[k];
+        offB += (int64_t)idx * p.b_r[k];
+        offO += (int64_t)idx * p.o_r[k];
+    }
+    const uint32_t i0 = tp * kTile, j0 = tq * kTile;
+    auto stage = [&](const T *src, int64_t off, int64_t s_q, T (&lds)[kTile][kTile + 1]) {
+        // coalesced along p: slot ig covers i = ig*W .. ig*W+W-1 of row j
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const uint32_t v = threadIdx.x + 256 * s, jl = v / VPR, ig = v % VPR;
+            const uint32_t i = i0 + ig * W, j = j0 + jl;
+            if (i < p.np && j < p.nq) {
+                const T *g = src + off + (int64_t)i + (int64_t)j * s_q;
+                if constexpr (VEC) {
+                    const V val = *reinterpret_cast<const V *>(g);
+#pragma unroll
+                    for (int k = 0; k < W; ++k) lds[ig * W + k][jl] = val[k];
+                } else {
+                    lds[ig][jl] = *g;
+                }
+            }
+        }
+    };
+    if (p.mode_a == 1) stage(a, offA, p.a_q, lds_a);
+    if (p.mode_b == 1) stage(b, offB, p.b_q, lds_b);
+    if (p.mode_a == 1 || p.mode_b == 1) __syncthreads();
+    auto fetch = [&](const T *src, int64_t off, int64_t s_p, int64_t s_q, int mode, const T (&lds)[kTile][kTile + 1],
+                     uint32_t il, uint32_t jg, uint32_t i, uint32_t j, T (&dst)[W]) {
+        if (mode == 1) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = lds[il][jg * W + k];
+        } else {
+            const T *g = src + off + (int64_t)i * s_p + (int64_t)j * s_q;
+            if (VEC && s_q == 1) {
+                const V val = *reinterpret_cast<const V *>(g);
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst[k] = val[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst[k] = g[(int64_t)k * s_q];
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, il = v / VPR, jg = v % VPR;
+        const uint32_t i = i0 + il, j = j0 + jg * W;
+        if (i < p.np && j < p.nq) {
+            T xa[W], xb[W], xr[W];
+            fetch(a, offA, p.a_p, p.a_q, p.mode_a, lds_a, il, jg, i, j, xa);
+            fetch(b, offB, p.b_p, p.b_q, p.mode_b, lds_b, il, jg, i, j, xb);
+            apply_n<Op, T, W>(ctx, xa, xb, xr);
+            T *dst = out + offO + (int64_t)i * p.o_p + j;
+            if constexpr (VEC) {
+                V val;
+#pragma unroll
+                for (int k = 0; k < W; ++k) val[k] = xr[k];
+                store_stream(reinterpret_cast<V *>(dst), val);
+            } else {
+                *dst = xr[0];
+            }
+        }
+    }
+}
+
 struct Plan {
     int ndim;
     int64_t shape[SMHIP_MAX_NDIM], sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];
@@ -272,6 +386,60 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         }
         p.vpr = (uint32_t)inner;
         return launch_row<T, Op, false>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
+    }
+
+    // An operand that is contiguous along some OTHER axis p (a transposed / permuted view): tile the
+    // (p, inner) plane through LDS.  Taken when both plane extents are worth a 64 x 64 patch.
+    if (nd >= 2 && inner >= 16) {
+        auto contiguous_axis = [&](const int64_t *st) {
+            for (int d = nd - 2; d >= 0; --d)
+                if (st[d] == 1 && pl.shape[d] >= 16) return d;
+            return -1;
+        };
+        const bool a_strided = ia != 0 && ia != 1, b_strided = ib != 0 && ib != 1;
+        int pa = a_strided ? contiguous_axis(pl.sa) : -1, pb = b_strided ? contiguous_axis(pl.sb) : -1;
+        const int paxis = pa >= 0 ? pa : pb;
+        if (paxis >= 0) {
+            TileParams t{};
+            t.np = (uint32_t)pl.shape[paxis];
+            t.nq = (uint32_t)inner;
+            t.a_p = pl.sa[paxis]; t.a_q = ia;
+            t.b_p = pl.sb[paxis]; t.b_q = ib;
+            t.mode_a = (a_strided && pl.sa[paxis] == 1) ? 1 : 0;
+            t.mode_b = (b_strided && pl.sb[paxis] == 1) ? 1 : 0;
+            // dense output strides
+            int64_t ostride[SMHIP_MAX_NDIM];
+            ostride[nd - 1] = 1;
+            for (int d = nd - 2; d >= 0; --d) ostride[d] = ostride[d + 1] * pl.shape[d + 1];
+            t.o_p = ostride[paxis];
+            size_t slices = 1;
+            for (int d = nd - 2; d >= 0; --d) {  // innermost remaining axis first
+                if (d == paxis) continue;
+                t.rest[t.n_rest] = FastDiv((uint32_t)pl.shape[d]);
+                t.a_r[t.n_rest] = pl.sa[d];
+                t.b_r[t.n_rest] = pl.sb[d];
+                t.o_r[t.n_rest] = ostride[d];
+                ++t.n_rest;
+                slices *= (size_t)pl.shape[d];
+            }
+            t.tiles_p = (t.np + kTile - 1) / kTile;
+            t.tiles_q = (t.nq + kTile - 1) / kTile;
+            const size_t blocks = slices * t.tiles_p * t.tiles_q;
+            if (blocks < 0x7fffffffull && pl.shape[paxis] < 0x7fffffffll && inner < 0x7fffffffll) {
+                // 16-byte accesses need every vector to start on a 16-byte boundary: bases, both plane
+                // extents, and every stride that moves a vector's start (all but the unit ones)
+                bool vec = aligned16(a) && aligned16(b) && aligned16(out) && t.np % W == 0 && t.nq % W == 0;
+                auto mult = [&](int64_t v) { return v % W == 0; };
+                if (t.mode_a == 1) vec &= mult(t.a_q); else vec &= mult(t.a_p);
+                if (t.mode_b == 1) vec &= mult(t.b_q); else vec &= mult(t.b_p);
+                vec &= mult(t.o_p);
+                for (int k = 0; k < t.n_rest; ++k) vec &= mult(t.a_r[k]) && mult(t.b_r[k]) && mult(t.o_r[k]);
+                if (vec) hipLaunchKernelGGL((tile_kernel<T, Op, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, t);
+                else hipLaunchKernelGGL((tile_kernel<T, Op, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, t);
+                SMHIP_LAUNCH_CHECK("tile_kernel");
+                return SMHIP_OK;
+            }
+        }
     }
 
     if (pl.n >= 0x7fffffffull)

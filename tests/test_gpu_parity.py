@@ -243,6 +243,51 @@ def test_broadcast_pow_vs_oracle(smhip, oracle):
     assert np.array_equal(got, oracle.binary(orc.POW, ib, ie))
 
 
+def test_transposed_and_permuted_views(smhip, oracle):
+    """Operands whose contiguous axis is not the output's inner axis go through the LDS tile
+    kernel; patch edges, both operands transposed, permuted 3-D / 4-D views,
+    broadcasting on top, every dtype."""
+    for dtn, op in (("f32", "add"), ("f64", "mul"), ("i32", "sub"), ("i64", "add"), ("f32", "div"), ("f32", "pow")):
+        dt = DT[dtn]
+        kind = "positive" if op == "pow" else "uniform"
+        for (r, c) in ((100, 70), (64, 64), (65, 129), (16, 1000), (257, 33)):
+            a = gen.gen(dt, r * c, 31, kind).reshape(r, c)
+            b = gen.gen(dt, r * c, 32, "nonzero" if (dtn[0] == "i") else "uniform").reshape(c, r)
+            da, db = smhip.to_device(a), smhip.to_device(b)
+            for av, bv in ((a.T, b), (a, b.T), (a.T, b.T.T.T)):
+                if av.shape != bv.shape:
+                    continue
+                got = smhip.binary(sma.OPS[op], da.view_like(av, a), db.view_like(bv, b)).numpy()
+                want = oracle.binary(orc.OPS[op], av, bv)
+                if op == "pow":
+                    assert orc.ulp_diff_f32(got, want).max() <= POW_ULP
+                else:
+                    util.assert_same_bits(got, want, f"{dtn} {op} {av.shape}")
+        # both transposed (a.T op c.T), same storage order
+        a = gen.gen(dt, 90 * 75, 33, kind).reshape(90, 75)
+        c = gen.gen(dt, 90 * 75, 34, "nonzero" if dtn[0] == "i" else "uniform").reshape(90, 75)
+        got = smhip.binary(sma.OPS[op], smhip.to_device(a).view_like(a.T, a), smhip.to_device(c).view_like(c.T, c)).numpy()
+        want = oracle.binary(orc.OPS[op], a.T, c.T)
+        if op == "pow":
+            assert orc.ulp_diff_f32(got, want).max() <= POW_ULP
+        else:
+            util.assert_same_bits(got, want, f"{dtn} {op} both-T")
+    # permuted 3-D / 4-D views (beyond transpose()'s full reversal) with broadcasting on top
+    a = gen.gen(np.float32, 20 * 48 * 33, 35, "uniform").reshape(20, 48, 33)
+    da = smhip.to_device(a)
+    for perm in ((1, 0, 2), (2, 1, 0), (0, 2, 1), (2, 0, 1), (1, 2, 0)):
+        av = np.transpose(a, perm)
+        bshape = [1 if k == 1 else d for k, d in enumerate(av.shape)]
+        b = gen.gen(np.float32, int(np.prod(bshape)), 36, "uniform").reshape(bshape)
+        got = smhip.binary(sma.OP_MUL, da.view_like(av, a), smhip.to_device(b)).numpy()
+        util.assert_same_bits(got, oracle.binary(orc.MUL, av, b), f"perm {perm}")
+    a4 = gen.gen(np.int32, 3 * 40 * 5 * 36, 37, "uniform").reshape(3, 40, 5, 36)
+    av = np.transpose(a4, (0, 3, 2, 1))
+    b4 = gen.gen(np.int32, 36 * 40, 38, "uniform").reshape(36, 1, 40)
+    got = smhip.binary(sma.OP_ADD, smhip.to_device(a4).view_like(av, a4), smhip.to_device(b4)).numpy()
+    assert np.array_equal(got, oracle.binary(orc.ADD, av, b4))
+
+
 def test_1d_strided_is_walked_not_assumed_dense(smhip):
     """SURVEY 8a quirk 1: the reference reads any 1-D operand as dense (calculate.h:10);
     the HIP path honours the strides (checked against numpy, the reference being UB here)."""
