@@ -224,24 +224,45 @@ public:
         return v;
     }
 
-    // NumPy semantics: every element repeated `numberOfRepeats` times, flattened.
+    // NumPy semantics: every element repeated `numberOfRepeats` times, flattened.  On the
+    // device: a (N, r) view with strides (s, 0) gathered densely (the reference's host loop at
+    // SMArray.h:138-159 writes newData[i + j], which is not a repeat -- SURVEY 8a quirk 7).
     SMArray repeat(int numberOfRepeats) const {
         assert(numberOfRepeats >= 1);
+        const std::size_t r = static_cast<std::size_t>(numberOfRepeats);
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            if (_shape.size() + 1 <= MAX_NDIM) {
+                std::vector<std::size_t> vshape = _shape, vstrides = _strides;
+                vshape.push_back(r);
+                vstrides.push_back(0);
+                return gather(vshape, vstrides, {totalSize * r});
+            }
+        }
         std::vector<T> flat(totalSize ? totalSize : 1);
         copy_dense_to(flat.data());
-        T *out = new T[totalSize * numberOfRepeats ? totalSize * numberOfRepeats : 1];
+        T *out = new T[totalSize * r ? totalSize * r : 1];
         for (std::size_t i = 0, o = 0; i < totalSize; ++i)
-            for (int r = 0; r < numberOfRepeats; ++r) out[o++] = flat[i];
-        return SMArray(out, {totalSize * static_cast<std::size_t>(numberOfRepeats)});
+            for (std::size_t k = 0; k < r; ++k) out[o++] = flat[i];
+        return SMArray(out, {totalSize * r});
     }
 
+    // Repeat along one axis: shape[axis] *= numberOfRepeats (a stride-0 axis inserted after `axis`).
     SMArray repeat(int numberOfRepeats, int axis) const {
         assert(axis >= 0 && axis < static_cast<int>(ndim) && numberOfRepeats >= 1);
         if (ndim == 1) return repeat(numberOfRepeats);
+        const std::size_t r = static_cast<std::size_t>(numberOfRepeats);
+        std::vector<std::size_t> newShape = _shape;
+        newShape[axis] *= r;
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            if (_shape.size() + 1 <= MAX_NDIM) {
+                std::vector<std::size_t> vshape = _shape, vstrides = _strides;
+                vshape.insert(vshape.begin() + axis + 1, r);
+                vstrides.insert(vstrides.begin() + axis + 1, 0);
+                return gather(vshape, vstrides, std::move(newShape));
+            }
+        }
         std::vector<T> flat(totalSize ? totalSize : 1);
         copy_dense_to(flat.data());
-        std::vector<std::size_t> newShape = _shape;
-        newShape[axis] *= numberOfRepeats;
         std::size_t inner = 1, outer = 1;
         for (std::size_t i = axis + 1; i < ndim; ++i) inner *= _shape[i];
         for (int i = 0; i < axis; ++i) outer *= _shape[i];
@@ -249,7 +270,7 @@ public:
         T *dst = out;
         for (std::size_t o = 0; o < outer; ++o)
             for (std::size_t j = 0; j < _shape[axis]; ++j)
-                for (int r = 0; r < numberOfRepeats; ++r) {
+                for (std::size_t k = 0; k < r; ++k) {
                     std::memcpy(dst, flat.data() + (o * _shape[axis] + j) * inner, inner * sizeof(T));
                     dst += inner;
                 }
@@ -386,7 +407,7 @@ public:
     // Dense copy of a (possibly strided) array, made on the device.
     SMArray contiguous() const {
         if constexpr (hip::dtype_of<T>::id >= 0) {
-            return apply_scalar<MultiplyOp<T>>(T{1});
+            return gather(_shape, _strides, std::vector<std::size_t>(_shape));
         } else {
             T *out = new T[totalSize ? totalSize : 1];
             copy_dense_to(out);
@@ -447,6 +468,19 @@ private:
         const T *base = data.read();
         if (is_dense()) std::copy(base, base + totalSize, dst);
         else for_each_offset([&](std::size_t linear, std::size_t off) { dst[linear] = base[off]; });
+    }
+
+    // Dense device copy of this array's storage seen through (vshape, vstrides), labelled `outShape`
+    // (same element count): SMHIP_OP_LEFT through the broadcast kernels.
+    SMArray gather(const std::vector<std::size_t> &vshape, const std::vector<std::size_t> &vstrides,
+                   std::vector<std::size_t> &&outShape) const {
+        SMArray out = device_empty(std::move(outShape));
+        const auto sh = hip::to_i64(vshape), st = hip::to_i64(vstrides);
+        const std::vector<std::int64_t> zeros(sh.size(), 0);
+        const T *src = device_data();
+        hip::check(smhip_elementwise(SMHIP_OP_LEFT, hip::dtype_of<T>::id, src, st.data(), src, zeros.data(), sh.data(),
+                                     static_cast<int>(sh.size()), out.device_data_mut()));
+        return out;
     }
 
     // Device pointer to a dense version of this array (itself when already dense).

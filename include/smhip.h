@@ -49,7 +49,10 @@ typedef enum smhip_status {
 /* Op policy ids: AddOp, SubtractOp, MultiplyOp, DivideOp, PowOp
  * (include/math/{add,subtract,multiply,division,pow}.h). */
 typedef enum smhip_op {
-    SMHIP_OP_ADD = 0, SMHIP_OP_SUB = 1, SMHIP_OP_MUL = 2, SMHIP_OP_DIV = 3, SMHIP_OP_POW = 4
+    SMHIP_OP_ADD = 0, SMHIP_OP_SUB = 1, SMHIP_OP_MUL = 2, SMHIP_OP_DIV = 3, SMHIP_OP_POW = 4,
+    /* out = a, b ignored: the dense copy of a strided / broadcast view (gather). No reference
+     * Op; it is what SMArray::contiguous() and repeat() are made of. */
+    SMHIP_OP_LEFT = 5
 } smhip_op;
 
 /* Element types: the SimdTraits<T> specialisations (helpers.h:23-119) plus

@@ -19,8 +19,8 @@ ROOT = os.path.dirname(PKG)
 LIB_PATH = os.path.join(PKG, "lib", "libsmhip.so")
 HEADER = os.path.join(ROOT, "include", "smhip.h")
 
-OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_POW = range(5)
-OPS = {"add": OP_ADD, "sub": OP_SUB, "mul": OP_MUL, "div": OP_DIV, "pow": OP_POW}
+OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_POW, OP_LEFT = range(6)
+OPS = {"add": OP_ADD, "sub": OP_SUB, "mul": OP_MUL, "div": OP_DIV, "pow": OP_POW, "left": OP_LEFT}
 F32, F64, I32, I64 = range(4)
 DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int32): I32, np.dtype(np.int64): I64}
 MAX_NDIM = 6

@@ -483,6 +483,7 @@ int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const 
         case SMHIP_OP_MUL: return run_broadcast<T, MultiplyOp<T>>(a, b, out, pl, s);           \
         case SMHIP_OP_DIV: return run_broadcast<T, DivideOp<T>>(a, b, out, pl, s);             \
         case SMHIP_OP_POW: return run_broadcast<T, PowOp<T>>(a, b, out, pl, s);                \
+        case SMHIP_OP_LEFT: return run_broadcast<T, LeftOp<T>>(a, b, out, pl, s);                \
     }                                                                                          \
     break;
     switch (dtype) {

@@ -274,6 +274,7 @@ int run_devscalar(const void *a, const void *sp, size_t n, void *out, hipStream_
         case SMHIP_OP_MUL: return F(T, MultiplyOp<T>);           \
         case SMHIP_OP_DIV: return F(T, DivideOp<T>);             \
         case SMHIP_OP_POW: return F(T, PowOp<T>);                \
+        case SMHIP_OP_LEFT: return F(T, LeftOp<T>);                \
     }                                                            \
     break;
 #define SMHIP_DISPATCH(F)                                        \

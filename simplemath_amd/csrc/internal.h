@@ -39,7 +39,7 @@ int reduce_scratch(size_t count, double **ptr);
 
 inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }
 inline bool valid_dtype(int dtype) { return dtype >= SMHIP_F32 && dtype <= SMHIP_I64; }
-inline bool valid_op(int op) { return op >= SMHIP_OP_ADD && op <= SMHIP_OP_POW; }
+inline bool valid_op(int op) { return op >= SMHIP_OP_ADD && op <= SMHIP_OP_LEFT; }
 
 // Kernel launchers (one translation unit each).
 int launch_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);

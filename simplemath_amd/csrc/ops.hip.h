@@ -49,6 +49,8 @@ template <typename T> struct SubtractOp { static __device__ __forceinline__ T ap
 template <typename T> struct MultiplyOp { static __device__ __forceinline__ T apply(T a, T b) { return a * b; } };
 template <typename T> struct DivideOp { static __device__ __forceinline__ T apply(T a, T b) { return a / b; } };
 template <typename T> struct PowOp;
+// out = a: dense copy of a strided / broadcast view (SMHIP_OP_LEFT)
+template <typename T> struct LeftOp { static __device__ __forceinline__ T apply(T a, T) { return a; } };
 
 #define SMHIP_INT_OPS(T)                                                                             \
     template <> struct AddOp<T> { static __device__ __forceinline__ T apply(T a, T b) {             \

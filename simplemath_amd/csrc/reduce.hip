@@ -252,6 +252,7 @@ int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void 
         case SMHIP_OP_MUL: return run_reduce<T, MultiplyOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);            \
         case SMHIP_OP_DIV: return run_reduce<T, DivideOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);              \
         case SMHIP_OP_POW: return run_reduce<T, PowOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);                 \
+        case SMHIP_OP_LEFT: return run_reduce<T, LeftOp<T>, kFused>(a, b, out, n, sum_dev, nullptr, s);                 \
     }                                                                                                                 \
     break;
     switch (dtype) {

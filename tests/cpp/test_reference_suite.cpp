@@ -370,6 +370,18 @@ TEST(Repeat) {
     CHECK_EQ(r0(1, 1), 2); CHECK_EQ(r0(2, 0), 3);
     auto r1 = m.repeat(3, 1);
     CHECK_EQ(r1(0, 2), 1); CHECK_EQ(r1(0, 3), 2); CHECK_EQ(r1(1, 5), 4);
+    // a transposed view repeated along its first axis, and a dense copy of a view
+    auto mt = m.transpose();  // [[1,3],[2,4]]
+    auto rt = mt.repeat(2, 0);
+    CHECK_EQ(rt(0, 1), 3); CHECK_EQ(rt(1, 1), 3); CHECK_EQ(rt(2, 0), 2); CHECK_EQ(rt(3, 1), 4);
+    auto dense = mt.contiguous();
+    CHECK(dense.is_dense());
+    CHECK_EQ(dense(0, 1), 3); CHECK_EQ(dense(1, 0), 2);
+    auto big = sm::ones<float>(300, 200) * 3.0f;
+    auto br = big.repeat(4, 1);
+    std::vector<size_t> bs = {300, 800};
+    CHECK_EQ(br.shape(), bs);
+    CHECK_EQ(sm::sum(br), 3.0 * 300 * 800);
 }
 TEST(HostPointerLoops) {
     // calling the loop templates directly with host pointers, as the README's recipe does

@@ -288,6 +288,21 @@ def test_transposed_and_permuted_views(smhip, oracle):
     assert np.array_equal(got, oracle.binary(orc.ADD, av, b4))
 
 
+def test_left_op_gathers_views(smhip):
+    """SMHIP_OP_LEFT (out = a): the dense copy of strided / broadcast views that contiguous() and repeat()
+    are built from; bit-exact including NaN payloads (nothing is computed)."""
+    for dtn in ("f32", "f64", "i32", "i64"):
+        a = gen.gen(DT[dtn], 24 * 40, 41, "wide").reshape(24, 40)
+        da = smhip.to_device(a)
+        dummy = smhip.to_device(np.zeros(1, dtype=DT[dtn]))
+        for view in (a.T, a[3:19, 5:37], a[:, ::1], np.broadcast_to(a[:, None, :], (24, 3, 40))):
+            dv = sma.DeviceArray(smhip, da.base_ptr, DT[dtn], view.shape, [s // a.itemsize for s in view.strides],
+                                 (view.__array_interface__["data"][0] - a.__array_interface__["data"][0]) // a.itemsize, da._owner)
+            got = smhip.binary(sma.OP_LEFT, dv, dummy).numpy()
+            u = {4: np.uint32, 8: np.uint64}[a.itemsize]
+            assert np.array_equal(got.view(u), np.ascontiguousarray(view).view(u)), (dtn, view.shape)
+
+
 def test_1d_strided_is_walked_not_assumed_dense(smhip):
     """SURVEY 8a quirk 1: the reference reads any 1-D operand as dense (calculate.h:10);
     the HIP path honours the strides (checked against numpy, the reference being UB here)."""
