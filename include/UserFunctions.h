@@ -37,6 +37,38 @@ SMArray<T> pow(const SMArray<T> &arr, T val) {
     return arr.template apply_scalar<PowOp<T>>(val);
 }
 
+// Fusion hook: (a Op1 b) Op2 c in ONE pass over HBM (the reference makes two passes and a
+// temporary).  Dense, equal-shaped operands take the fused kernel; anything else is evaluated
+// as the two operator calls it abbreviates -- same values either way.
+//   auto r = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, c);   // (a + b) * c
+template <typename Op1, typename Op2, typename T>
+SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, const SMArray<T> &c) {
+    if constexpr (hip::on_device_v<T, Op1> && hip::on_device_v<T, Op2>) {
+        constexpr int o1 = hip::device_op<Op1>::id, o2 = hip::device_op<Op2>::id;
+        if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV && a.shape() == b.shape() && a.shape() == c.shape() && a.is_dense() &&
+            b.is_dense() && c.is_dense()) {
+            SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(a.shape()));
+            hip::check(smhip_fused_contiguous(o1, o2, hip::dtype_of<T>::id, a.device_data(), b.device_data(), c.device_data(),
+                                              nullptr, out.device_data_mut(), a.totalSize));
+            return out;
+        }
+    }
+    return a.template apply<Op1>(b).template apply<Op2>(c);
+}
+template <typename Op1, typename Op2, typename T>
+SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, T c) {
+    if constexpr (hip::on_device_v<T, Op1> && hip::on_device_v<T, Op2>) {
+        constexpr int o1 = hip::device_op<Op1>::id, o2 = hip::device_op<Op2>::id;
+        if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV && a.shape() == b.shape() && a.is_dense() && b.is_dense()) {
+            SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(a.shape()));
+            hip::check(smhip_fused_contiguous(o1, o2, hip::dtype_of<T>::id, a.device_data(), b.device_data(), nullptr, &c,
+                                              out.device_data_mut(), a.totalSize));
+            return out;
+        }
+    }
+    return a.template apply<Op1>(b).template apply_scalar<Op2>(c);
+}
+
 // Sum of all elements in fp64 (BASELINE config 5's reduction; no reference counterpart).
 template <typename T>
 double sum(const SMArray<T> &arr) {

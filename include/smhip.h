@@ -127,6 +127,13 @@ int smhip_dot_async(int dtype, const void *a, const void *b, size_t n, double *o
 int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, void *out, size_t n,
                                double *sum_dev);
 
+/* Fusion hook: out[i] = (a[i] op1 b[i]) op2 c[i] in ONE pass over dense arrays; pass c = NULL
+ * and c_scalar_host -> one T for (a op1 b) op2 scalar.  op1, op2 in {ADD, SUB, MUL, DIV}; each
+ * stage rounds as the separate Ops do, so the result is bit-identical to two operator calls
+ * (SMArray.h:217-305 x 2) at 2/3 (array c) or 1/2 (scalar c) of their HBM traffic. */
+int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const void *b, const void *c,
+                           const void *c_scalar_host, void *out, size_t n);
+
 /* -------------------------------------------------------------- timing */
 /* HIP events on the calling thread's stream (what bench.py brackets the
  * timed region with). */

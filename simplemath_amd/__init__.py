@@ -239,6 +239,19 @@ class Smhip:
                                            v.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_void_p(out.ptr)))
         return out
 
+    def fused(self, op1, op2, a: DeviceArray, b: DeviceArray, c, out: DeviceArray | None = None):
+        """(a op1 b) op2 c in one pass; c a DeviceArray or a scalar."""
+        if out is None:
+            out = self.empty(a.shape, a.dtype)
+        if isinstance(c, DeviceArray):
+            cp, sp = C.c_void_p(c.ptr), C.c_void_p(0)
+        else:
+            v = np.array([c], dtype=a.dtype)
+            cp, sp = C.c_void_p(0), v.ctypes.data_as(C.c_void_p)
+        self._ck(self.c.smhip_fused_contiguous(C.c_int(op1), C.c_int(op2), C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr),
+                                               C.c_void_p(b.ptr), cp, sp, C.c_void_p(out.ptr), C.c_size_t(a.size)))
+        return out
+
     def dot(self, a: DeviceArray, b: DeviceArray):
         out = np.zeros(1, dtype=a.dtype)
         self._ck(self.c.smhip_dot(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),

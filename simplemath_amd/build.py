@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libsmhip.so")
-SOURCES = ["runtime.hip", "contiguous.hip", "broadcast.hip", "reduce.hip", "fill.hip"]
+SOURCES = ["runtime.hip", "contiguous.hip", "broadcast.hip", "reduce.hip", "fill.hip", "fused.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every float op is the single IEEE operation the reference's
 # intrinsic performs; fusions are written explicitly (__builtin_fma).

@@ -50,6 +50,8 @@ int launch_array_devscalar(int op, int dtype, const void *a, const void *value_d
                            bool swapped, hipStream_t s);
 int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
                      const int64_t *shape, int ndim, void *out, hipStream_t s);
+int launch_fused(int op1, int op2, int dtype, const void *a, const void *b, const void *c, const void *c_scalar_host, void *out,
+                 size_t n, hipStream_t s);
 int launch_fill(int dtype, void *dst, const void *value_host, size_t n, hipStream_t s);
 int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi, hipStream_t s);
 int launch_sum(int dtype, const void *a, size_t n, double *out_dev, hipStream_t s);

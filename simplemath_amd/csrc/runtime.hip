@@ -384,6 +384,15 @@ int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host,
     return launch_array_scalar(op, dtype, a, value_host, n, out, s);
 }
 
+int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const void *b, const void *c, const void *c_scalar_host,
+                           void *out, size_t n) {
+    if (!valid_op(op1) || !valid_op(op2) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fused: bad op %d/%d or dtype %d", op1, op2, dtype);
+    if (n == 0) return SMHIP_OK;
+    if (!a || !b || !out || (!c && !c_scalar_host)) return fail(SMHIP_ERR_INVALID, "fused: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_fused(op1, op2, dtype, a, b, c, c_scalar_host, out, n, s);
+}
+
 int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev) {
     if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "sum: bad dtype %d", dtype);
     if (!out_dev || (n && !a)) return fail(SMHIP_ERR_INVALID, "sum: null buffer");

@@ -383,6 +383,18 @@ TEST(Repeat) {
     CHECK_EQ(br.shape(), bs);
     CHECK_EQ(sm::sum(br), 3.0 * 300 * 800);
 }
+TEST(FusionHook) {
+    auto a = sm::ones<float>(1000) * 2.0f, b = sm::ones<float>(1000) * 3.0f, c = sm::ones<float>(1000) * 4.0f;
+    auto r = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, c);  // (a + b) * c in one pass
+    CHECK_EQ(r(0), 20.0f); CHECK_EQ(r(999), 20.0f);
+    auto two_pass = (a + b) * c;
+    CHECK_EQ(sm::sum(r), sm::sum(two_pass));
+    auto rs = sm::fused<SubtractOp<float>, DivideOp<float>>(a, b, 2.0f);
+    CHECK_EQ(rs(5), -0.5f);
+    sm::SMArray<float> m = {{1, 2}, {3, 4}}, row = {{10, 20}};
+    auto rb = sm::fused<AddOp<float>, MultiplyOp<float>>(m, row, m);  // broadcast: evaluated as two calls, same values
+    CHECK_EQ(rb(1, 1), (4.0f + 20.0f) * 4.0f);
+}
 TEST(HostPointerLoops) {
     // calling the loop templates directly with host pointers, as the README's recipe does
     float a[5] = {1, 2, 3, 4, 5}, b[5] = {10, 20, 30, 40, 50}, r[5] = {};
@@ -419,7 +431,7 @@ int main() {
                          run_DivisionBySelf, run_ScalarPow, run_OneDimensionalPow, run_TwoDimensionalPow, run_NonSquareShape,
                          run_TestLargeArrays, run_TestLargeArraysWithNegatives, run_NegativeExponent_disabled_in_reference,
                          run_TestLargeArraysDifferentValues_disabled_in_reference, run_ReadmeExample, run_BroadcastError, run_DotProduct,
-                         run_ScalarOps, run_Residency, run_Repeat, run_HostPointerLoops, run_PluginWithoutDeviceFunctorIsRefused};
+                         run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_HostPointerLoops, run_PluginWithoutDeviceFunctorIsRefused};
     int n = 0;
     for (auto t : tests) {
         try {

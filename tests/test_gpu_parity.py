@@ -288,6 +288,25 @@ def test_transposed_and_permuted_views(smhip, oracle):
     assert np.array_equal(got, oracle.binary(orc.ADD, av, b4))
 
 
+def test_fused_equals_two_passes(smhip, oracle):
+    """smhip_fused_contiguous: (a op1 b) op2 c in one pass is bit-identical to the two operator calls."""
+    for dtn in ("f32", "f64", "i32", "i64"):
+        for n in (1, 7, 1000, (1 << 20) + 3):
+            a = gen.gen(DT[dtn], n, 51, "mixed")
+            b = gen.gen(DT[dtn], n, 52, "nonzero" if dtn[0] == "i" else "mixed")
+            c = gen.gen(DT[dtn], n, 53, "nonzero" if dtn[0] == "i" else "mixed")
+            da, db, dc = smhip.to_device(a), smhip.to_device(b), smhip.to_device(c)
+            for o1 in ("add", "sub", "mul", "div"):
+                for o2 in ("add", "mul", "div", "sub"):
+                    want = oracle.contiguous(orc.OPS[o2], oracle.contiguous(orc.OPS[o1], a, b), c)
+                    util.assert_same_bits(smhip.fused(sma.OPS[o1], sma.OPS[o2], da, db, dc).numpy(), want, f"{dtn} {o1} {o2} {n}")
+                    sv = 3 if dtn[0] == "i" else 1.5
+                    want = oracle.array_scalar(orc.OPS[o2], oracle.contiguous(orc.OPS[o1], a, b), sv)
+                    util.assert_same_bits(smhip.fused(sma.OPS[o1], sma.OPS[o2], da, db, sv).numpy(), want, f"{dtn} {o1} {o2} s {n}")
+    with pytest.raises(sma.SmhipError):
+        smhip.fused(sma.OP_POW, sma.OP_ADD, da, db, dc)
+
+
 def test_left_op_gathers_views(smhip):
     """SMHIP_OP_LEFT (out = a): the dense copy of strided / broadcast views that contiguous() and repeat()
     are built from; bit-exact including NaN payloads (nothing is computed)."""
