@@ -284,6 +284,11 @@ public:
             std::unique_ptr<SMArray> lhs_holder, rhs_holder;
             const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
             return hip::dot_device<T>(pa, pb, totalSize);
+        } else if constexpr (std::is_same_v<T, std::complex<double>>) {
+            std::vector<T> fa(totalSize ? totalSize : 1), fb(totalSize ? totalSize : 1);
+            copy_dense_to(fa.data());
+            arr.copy_dense_to(fb.data());
+            return dot_product<T>(fa.data(), fb.data(), totalSize);  // staged: complex arrays have no resident form yet
         } else {
             throw std::runtime_error("operator%: this element type has no gfx950 kernels yet (no CPU fallback)");
         }

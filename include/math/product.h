@@ -5,8 +5,9 @@
 // kernels (smhip_dot): wavefront shuffle tree + LDS across waves, accumulating in
 // fp64 for float/double (the reference's 8 f32 lane accumulators stop absorbing
 // addends at 2^24 each) and in wrapping integers for int32/int64 (bit-identical
-// to the reference in any order).  std::complex<double> is a "next" row
-//  and is refused for now.
+// to the reference in any order).  std::complex<double> (product.h:168-224) runs
+// smhip_dot_c64: sum a[i]*b[i], unconjugated, separate fp64 fma chains for the real
+// and imaginary parts.
 #pragma once
 
 #include <complex>
@@ -28,7 +29,15 @@ T dot_device(const T *a, const T *b, std::size_t n) {
 template <typename T>
 T dot_product(const T *a, const T *b, std::size_t n) {
     using namespace sm::hip;
-    if constexpr (dtype_of<T>::id >= 0) {
+    if constexpr (std::is_same_v<T, std::complex<double>>) {
+        if (n == 0) return T{};
+        DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T));
+        check(smhip_upload(da.get(), a, n * sizeof(T)));
+        check(smhip_upload(db.get(), b, n * sizeof(T)));
+        double out[2] = {0, 0};
+        check(smhip_dot_c64(da.get(), db.get(), n, out));
+        return T(out[0], out[1]);
+    } else if constexpr (dtype_of<T>::id >= 0) {
         if (n == 0) return T{};
         DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T));
         check(smhip_upload(da.get(), a, n * sizeof(T)));

@@ -117,6 +117,10 @@ int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host,
  * f32/f64 accumulate in fp64 (the reference's f32 lane accumulators saturate,
  * SURVEY section 0); i32/i64 wrap exactly like the reference. Synchronous. */
 int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host);
+/* dot_product<std::complex<double>> (product.h:168-224): a, b hold n {re, im} pairs of doubles (16-byte
+ * aligned); writes {re, im} of sum a[i]*b[i] (unconjugated, as the reference's scalar tail computes
+ * it) to out2_host.  Synchronous. */
+int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host);
 /* Whole-array sum in fp64 (no reference counterpart; BASELINE config 5). Synchronous. */
 int smhip_sum(int dtype, const void *a, size_t n, double *out_host);
 /* Asynchronous forms leaving the fp64 result in device memory so a multi-GPU

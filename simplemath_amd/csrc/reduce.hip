@@ -195,6 +195,43 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(const typename Ac
 
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// std::complex<double> dot (reference product.h:168-224): sum a[i] * b[i], unconjugated, as the
+// reference's scalar tail defines it (its AVX body adds every real/imaginary product twice --
+// _mm256_permute_pd(va, 0x0) duplicates lanes, rbuf[0..3] are then all summed -- which is taken as a
+// bug, not as semantics).  One complex = one 16-byte vector {re, im}; separate fp64 fma chains for
+// the real and imaginary sums, grid-stride, then the same wave / LDS / partials tree.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a, const dbl2 *__restrict__ b, size_t n,
+                                                      double *__restrict__ partials) {
+    double re = 0.0, im = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const dbl2 x = load_stream(a + i), y = load_stream(b + i);
+        re = __builtin_fma(x[0], y[0], re);
+        re = __builtin_fma(-x[1], y[1], re);
+        im = __builtin_fma(x[0], y[1], im);
+        im = __builtin_fma(x[1], y[0], im);
+    }
+    __shared__ double lds[2][kBlock / 64];
+    re = wave_reduce(re);
+    im = wave_reduce(im);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { lds[0][wave] = re; lds[1][wave] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0, m = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) { r += lds[0][w]; m += lds[1][w]; }
+        partials[2 * blockIdx.x] = r;
+        partials[2 * blockIdx.x + 1] = m;
+    }
+}
+__global__ __launch_bounds__(64) void cdot_finalize_kernel(const double *__restrict__ partials, size_t blocks, double *__restrict__ out2) {
+    double re = 0.0, im = 0.0;
+    for (size_t i = threadIdx.x; i < blocks; i += 64) { re += partials[2 * i]; im += partials[2 * i + 1]; }
+    re = wave_reduce(re);
+    im = wave_reduce(im);
+    if (threadIdx.x == 0) { out2[0] = re; out2[1] = im; }
+}
+
 template <typename T, typename Op, int MODE>
 int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8, void *out_native, hipStream_t s) {
     typedef typename AccOf<T>::type A;
@@ -242,6 +279,19 @@ int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out8_d
         case SMHIP_I64: return run_reduce<int64_t, AddOp<int64_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
     }
     return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
+}
+
+int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s) {
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    double *scratch;
+    if (int rc = reduce_scratch(2 * blocks, &scratch)) return rc;
+    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch);
+    SMHIP_LAUNCH_CHECK("cdot");
+    hipLaunchKernelGGL(cdot_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, out2_dev);
+    SMHIP_LAUNCH_CHECK("cdot finalize");
+    return SMHIP_OK;
 }
 
 int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev, hipStream_t s) {

@@ -11,6 +11,7 @@
 #include <sm.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -325,6 +326,14 @@ TEST(DotProduct) {  // SMArray.h:213-215 -> product.h
     auto mt = m.transpose();
     CHECK_EQ(m % mt, 1.0f * 1 + 2 * 3 + 3 * 2 + 4 * 4);  // a view operand is gathered first
 }
+TEST(ComplexDot) {  // product.h:168-224
+    using C = std::complex<double>;
+    sm::SMArray<C> a = {C(1, 2), C(3, -1), C(0.5, 0.25)}, b = {C(2, 1), C(-1, 4), C(8, 0)};
+    const C want = C(1, 2) * C(2, 1) + C(3, -1) * C(-1, 4) + C(0.5, 0.25) * C(8, 0);
+    const C got = a % b;
+    CHECK_DOUBLE_EQ(got.real(), want.real()); CHECK_DOUBLE_EQ(got.imag(), want.imag());
+    CHECK_EQ(a(1), C(3, -1));  // construction and indexing of complex arrays work as in the reference
+}
 TEST(ScalarOps) {  // SMArray.h:226-305
     sm::SMArray<int> a = {{7, -7}, {8, 9}};
     auto q = a / 2;
@@ -431,7 +440,7 @@ int main() {
                          run_DivisionBySelf, run_ScalarPow, run_OneDimensionalPow, run_TwoDimensionalPow, run_NonSquareShape,
                          run_TestLargeArrays, run_TestLargeArraysWithNegatives, run_NegativeExponent_disabled_in_reference,
                          run_TestLargeArraysDifferentValues_disabled_in_reference, run_ReadmeExample, run_BroadcastError, run_DotProduct,
-                         run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_HostPointerLoops, run_PluginWithoutDeviceFunctorIsRefused};
+                         run_ComplexDot, run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_HostPointerLoops, run_PluginWithoutDeviceFunctorIsRefused};
     int n = 0;
     for (auto t : tests) {
         try {

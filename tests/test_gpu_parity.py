@@ -307,6 +307,20 @@ def test_fused_equals_two_passes(smhip, oracle):
         smhip.fused(sma.OP_POW, sma.OP_ADD, da, db, dc)
 
 
+def test_complex_dot(smhip):
+    """dot_product<std::complex<double>> (product.h:168-224): unconjugated sum a[i]*b[i]."""
+    for n in (1, 2, 3, 1000, 100003):
+        ar, ai = gen.gen(np.float64, n, 61, "uniform"), gen.gen(np.float64, n, 62, "uniform")
+        br, bi = gen.gen(np.float64, n, 63, "uniform"), gen.gen(np.float64, n, 64, "uniform")
+        a, b = ar + 1j * ai, br + 1j * bi
+        da = smhip.to_device(a.view(np.float64))
+        db = smhip.to_device(b.view(np.float64))
+        got = smhip.dot_c64(da.ptr, db.ptr, n)
+        want = complex(np.sum(a.astype(np.clongdouble) * b.astype(np.clongdouble)))
+        scale = float(np.sum(np.abs(a) * np.abs(b)))
+        assert abs(got - want) <= 4 * n * 2.0 ** -53 * scale + 1e-300, n
+
+
 def test_left_op_gathers_views(smhip):
     """SMHIP_OP_LEFT (out = a): the dense copy of strided / broadcast views that contiguous() and repeat()
     are built from; bit-exact including NaN payloads (nothing is computed)."""
