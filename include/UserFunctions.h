@@ -44,7 +44,7 @@ SMArray<T> pow(const SMArray<T> &arr, T val) {
 template <typename Op1, typename Op2, typename T>
 SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, const SMArray<T> &c) {
     if constexpr (hip::on_device_v<T, Op1> && hip::on_device_v<T, Op2>) {
-        constexpr int o1 = hip::device_op<Op1>::id, o2 = hip::device_op<Op2>::id;
+        const int o1 = hip::device_op<Op1>::id(), o2 = hip::device_op<Op2>::id();
         if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV && a.shape() == b.shape() && a.shape() == c.shape() && a.is_dense() &&
             b.is_dense() && c.is_dense()) {
             SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(a.shape()));
@@ -58,7 +58,7 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, const SMArray<T> &c) 
 template <typename Op1, typename Op2, typename T>
 SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, T c) {
     if constexpr (hip::on_device_v<T, Op1> && hip::on_device_v<T, Op2>) {
-        constexpr int o1 = hip::device_op<Op1>::id, o2 = hip::device_op<Op2>::id;
+        const int o1 = hip::device_op<Op1>::id(), o2 = hip::device_op<Op2>::id();
         if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV && a.shape() == b.shape() && a.is_dense() && b.is_dense()) {
             SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(a.shape()));
             hip::check(smhip_fused_contiguous(o1, o2, hip::dtype_of<T>::id, a.device_data(), b.device_data(), nullptr, &c,

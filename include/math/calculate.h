@@ -20,7 +20,9 @@
 // a failing device call throws std::runtime_error, the library's single
 // exception type (SMUtils.h:76-78).
 //
-// User-defined Ops: an Op with no device functor (sm::hip::device_op<Op>::id < 0)
+// User-defined Ops: SM_DEVICE_OP(MyOp, "(a + b) * 2") (math/ops.h) gives an Op its device form -- the
+// expression is compiled for gfx950 with hipRTC on first use -- and it then runs through the same
+// entry points as the built-ins.  An Op with no device functor (sm::hip::device_op<Op>::available == false)
 // is refused with a std::runtime_error naming it.  Defining
 // SM_ENABLE_HOST_PLUGIN_OPS before including this header instead runs such an
 // Op's own `apply` in a plain host loop -- the plugin's code executing where it
@@ -82,22 +84,23 @@ void element_wise_op_device(const T *a, const std::vector<std::size_t> &stride_a
                             const std::vector<std::size_t> &stride_b, T *result, const std::vector<std::size_t> &shape) {
     static_assert(on_device_v<T, Op>, "no gfx950 functor for this Op / element type");
     const auto sa = to_i64(stride_a), sb = to_i64(stride_b), sh = to_i64(shape);
-    check(smhip_elementwise(device_op<Op>::id, dtype_of<T>::id, a, sa.data(), b, sb.data(), sh.data(),
+    check(smhip_elementwise(device_op<Op>::id(), dtype_of<T>::id, a, sa.data(), b, sb.data(), sh.data(),
                             static_cast<int>(sh.size()), result));
 }
 
 template <typename T, typename Op>
 void array_scalar_op_device(const T *a, T value, std::size_t n, T *result) {
     static_assert(on_device_v<T, Op>, "no gfx950 functor for this Op / element type");
-    check(smhip_array_scalar(device_op<Op>::id, dtype_of<T>::id, a, &value, n, result));
+    check(smhip_array_scalar(device_op<Op>::id(), dtype_of<T>::id, a, &value, n, result));
 }
 
 template <typename T, typename Op>
 [[noreturn]] void refuse_host_op() {
     throw std::runtime_error(std::string("simpleMath/MI355X: Op '") + typeid(Op).name() +
-                             "' has no device functor (sm::hip::device_op<Op>::id < 0) or its element type has no "
-                             "kernels; there is no silent CPU fallback. Define SM_ENABLE_HOST_PLUGIN_OPS to run a "
-                             "user-defined Op's own apply() on the host.");
+                             "' has no device functor (sm::hip::device_op<Op>::available == false) or its element type has no "
+                             "kernels; there is no silent CPU fallback. Give the Op its device form with "
+                             "SM_DEVICE_OP(MyOp, \"<HIP expression in a and b>\") (math/ops.h), or define "
+                             "SM_ENABLE_HOST_PLUGIN_OPS to run its own apply() on the host.");
 }
 
 }  // namespace sm::hip
@@ -148,7 +151,7 @@ void handle_contiguous_arrays(const T *a, const T *b, T *result, std::size_t n) 
         DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T)), dr(n * sizeof(T));
         check(smhip_upload(da.get(), a, n * sizeof(T)));
         check(smhip_upload(db.get(), b, n * sizeof(T)));
-        check(smhip_contiguous(device_op<Operation>::id, dtype_of<T>::id, da.get(), db.get(), dr.get(), n));
+        check(smhip_contiguous(device_op<Operation>::id(), dtype_of<T>::id, da.get(), db.get(), dr.get(), n));
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
 #if defined(SM_ENABLE_HOST_PLUGIN_OPS)

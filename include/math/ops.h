@@ -15,6 +15,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <stdexcept>
+#include <string>
 #include <type_traits>
 
 #include "helpers.h"
@@ -61,16 +63,43 @@ template <typename T> struct dtype_of {
                                                                                                  : -1;
 };
 
-// Op -> device functor.  Specialise for your own Op once libsmhip carries a
-// functor for it; id < 0 means "no device implementation".
-template <typename Op> struct device_op { static constexpr int id = -1; };
-template <typename T> struct device_op<AddOp<T>> { static constexpr int id = SMHIP_OP_ADD; };
-template <typename T> struct device_op<SubtractOp<T>> { static constexpr int id = SMHIP_OP_SUB; };
-template <typename T> struct device_op<MultiplyOp<T>> { static constexpr int id = SMHIP_OP_MUL; };
-template <typename T> struct device_op<DivideOp<T>> { static constexpr int id = SMHIP_OP_DIV; };
-template <typename T> struct device_op<PowOp<T>> { static constexpr int id = SMHIP_OP_POW; };
+// Op -> device functor.  `available` says whether the Op can run on the GPU, `id()` names the
+// functor: a constant for the five built-ins (AOT kernels in libsmhip), a registered id for a user
+// Op whose arithmetic was handed over as a HIP expression (SM_DEVICE_OP below).
+template <typename Op> struct device_op {
+    static constexpr bool available = false;
+    static int id() { return -1; }
+};
+template <typename T> struct device_op<AddOp<T>> { static constexpr bool available = true; static int id() { return SMHIP_OP_ADD; } };
+template <typename T> struct device_op<SubtractOp<T>> { static constexpr bool available = true; static int id() { return SMHIP_OP_SUB; } };
+template <typename T> struct device_op<MultiplyOp<T>> { static constexpr bool available = true; static int id() { return SMHIP_OP_MUL; } };
+template <typename T> struct device_op<DivideOp<T>> { static constexpr bool available = true; static int id() { return SMHIP_OP_DIV; } };
+template <typename T> struct device_op<PowOp<T>> { static constexpr bool available = true; static int id() { return SMHIP_OP_POW; } };
+
+inline int register_expr(const char *hip_expression) {
+    int id = -1;
+    if (smhip_register_op(hip_expression, &id) < 0) throw std::runtime_error(std::string("smhip: ") + smhip_last_error());
+    return id;
+}
 
 template <typename T, typename Op>
-inline constexpr bool on_device_v = (dtype_of<T>::id >= 0) && (device_op<Op>::id >= 0);
+inline constexpr bool on_device_v = (dtype_of<T>::id >= 0) && device_op<Op>::available;
 
 }  // namespace sm::hip
+
+// Give a user-defined Op template its device form (the gfx950 counterpart of writing an
+// apply_simd<__m256> specialisation, README.md:105-117): the same arithmetic as apply(), as a HIP
+// expression in `a` and `b`.  At global scope, after the Op:
+//     template <typename T> struct MyOp { static T apply(const T& a, const T& b) { return (a + b) * 2; } ... };
+//     SM_DEVICE_OP(MyOp, "(a + b) * 2")
+// The expression is compiled for gfx950 by hipRTC on first use and cached.
+#define SM_DEVICE_OP(OpTemplate, hip_expression)                                   \
+    namespace sm::hip {                                                            \
+    template <typename T> struct device_op<OpTemplate<T>> {                        \
+        static constexpr bool available = true;                                    \
+        static int id() {                                                          \
+            static const int v = register_expr(hip_expression);                    \
+            return v;                                                              \
+        }                                                                          \
+    };                                                                             \
+    }

@@ -55,6 +55,15 @@ typedef enum smhip_op {
     SMHIP_OP_LEFT = 5
 } smhip_op;
 
+/* User-defined Ops (the README's "Extending with Custom Operations", README.md:86-133): on gfx950 an
+ * Op's device form is its arithmetic as a HIP expression in `a` and `b` of the element type, e.g.
+ * "(a + b) * 2".  smhip_register_op returns an id >= SMHIP_OP_USER_BASE that smhip_elementwise,
+ * smhip_contiguous and smhip_array_scalar accept as `op`; kernels are compiled for gfx950 with hipRTC on
+ * first use per element type and cached for the life of the process.  A string that does not compile
+ * fails that first use with SMHIP_ERR_INVALID and the compiler's message. */
+#define SMHIP_OP_USER_BASE 100
+int smhip_register_op(const char *hip_expression, int *op_id);
+
 /* Element types: the SimdTraits<T> specialisations (helpers.h:23-119) plus
  * int64 (declared TODO at helpers.h:122-127). */
 typedef enum smhip_dtype {

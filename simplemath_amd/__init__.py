@@ -206,6 +206,12 @@ class Smhip:
     def is_contiguous(self, shape, strides):
         return bool(self.c.smhip_is_contiguous(C.c_int(len(shape)), _i64(shape), _i64(strides)))
 
+    def register_op(self, hip_expression: str) -> int:
+        """User-defined Op: a HIP expression in `a` and `b`; returns the op id to pass as `op`."""
+        oid = C.c_int(0)
+        self._ck(self.c.smhip_register_op(hip_expression.encode(), C.byref(oid)))
+        return oid.value
+
     # -- hot path -------------------------------------------------------------
     def elementwise_raw(self, op, dtype, a_ptr, sa, b_ptr, sb, shape, out_ptr):
         self._ck(self.c.smhip_elementwise(C.c_int(op), C.c_int(DTYPES[np.dtype(dtype)]), C.c_void_p(a_ptr), _i64(sa),

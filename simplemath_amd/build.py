@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libsmhip.so")
-SOURCES = ["runtime.hip", "contiguous.hip", "broadcast.hip", "reduce.hip", "fill.hip", "fused.hip"]
+SOURCES = ["runtime.hip", "contiguous.hip", "broadcast.hip", "reduce.hip", "fill.hip", "fused.hip", "jit.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every float op is the single IEEE operation the reference's
 # intrinsic performs; fusions are written explicitly (__builtin_fma).
@@ -66,7 +66,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 if warn.strip() and verbose:
                     print(warn, file=sys.stderr)
     if jobs or force or _newer(LIB, objs):
-        run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)
+        run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lhiprtc"])
     return LIB
 
 

@@ -50,6 +50,13 @@ int launch_array_devscalar(int op, int dtype, const void *a, const void *value_d
                            bool swapped, hipStream_t s);
 int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
                      const int64_t *shape, int ndim, void *out, hipStream_t s);
+// run-time compiled user Ops (jit.hip)
+int jit_register(const char *expr, int *op_id);
+int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);
+int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s);
+int jit_elementwise(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb, const int64_t *shape,
+                    int ndim, void *out, hipStream_t s);
+inline bool user_op(int op) { return op >= SMHIP_OP_USER_BASE; }
 int launch_fused(int op1, int op2, int dtype, const void *a, const void *b, const void *c, const void *c_scalar_host, void *out,
                  size_t n, hipStream_t s);
 int launch_fill(int dtype, void *dst, const void *value_host, size_t n, hipStream_t s);

@@ -349,11 +349,16 @@ int smhip_is_contiguous(int ndim, const int64_t *shape, const int64_t *strides) 
     return 1;
 }
 
+int smhip_register_op(const char *hip_expression, int *op_id) {
+    if (!hip_expression || !*hip_expression || !op_id) return fail(SMHIP_ERR_INVALID, "register_op: null / empty expression");
+    return jit_register(hip_expression, op_id);
+}
+
 /* -------------------------------------------------------------- hot path */
 
 int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a, const void *b, const int64_t *stride_b,
                       const int64_t *shape, int ndim, void *out) {
-    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype);
+    if ((!valid_op(op) && !user_op(op)) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype);
     if (ndim < 1 || ndim > SMHIP_MAX_NDIM)
         return fail(SMHIP_ERR_INVALID, "elementwise: ndim %d outside 1..%d (the reference's MAX_NDIM, helpers.h:4)", ndim, SMHIP_MAX_NDIM);
     if (!stride_a || !stride_b || !shape) return fail(SMHIP_ERR_INVALID, "elementwise: null shape/stride");
@@ -365,22 +370,25 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
     SMHIP_ACQUIRE(s);
+    if (user_op(op)) return jit_elementwise(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
 }
 
 int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n) {
-    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
+    if ((!valid_op(op) && !user_op(op)) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "contiguous: null buffer");
     SMHIP_ACQUIRE(s);
+    if (user_op(op)) return jit_contiguous(op, dtype, a, b, out, n, s);
     return launch_contiguous(op, dtype, a, b, out, n, s);
 }
 
 int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out) {
-    if (!valid_op(op) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "array_scalar: bad op %d / dtype %d", op, dtype);
+    if ((!valid_op(op) && !user_op(op)) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "array_scalar: bad op %d / dtype %d", op, dtype);
     if (n == 0) return SMHIP_OK;
     if (!a || !value_host || !out) return fail(SMHIP_ERR_INVALID, "array_scalar: null buffer");
     SMHIP_ACQUIRE(s);
+    if (user_op(op)) return jit_array_scalar(op, dtype, a, value_host, n, out, s);
     return launch_array_scalar(op, dtype, a, value_host, n, out, s);
 }
 

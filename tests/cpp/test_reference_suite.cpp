@@ -422,6 +422,28 @@ struct MyOp {  // README.md:94-103 -- a user Op with no device functor
     static T apply(const T &a, const T &b) { return (a + b) * 2; }
     template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
 };
+template <typename T>
+struct ScaledSum {  // the same plugin, given its device form: runs on the GPU through hipRTC
+    static T apply(const T &a, const T &b) { return (a + b) * 2; }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
+};
+SM_DEVICE_OP(ScaledSum, "(a + b) * 2")
+TEST(PluginWithDeviceExpression) {
+    sm::SMArray<float> a = {{1, 2, 3}, {4, 5, 6}}, b = {{10, 20, 30}};
+    auto r = a.apply<ScaledSum<float>>(b);  // broadcast (2,3) with (1,3)
+    CHECK_EQ(r(0, 0), 22.0f); CHECK_EQ(r(1, 2), 72.0f);
+    auto big = sm::ones<float>(100003);
+    auto rb = big.apply<ScaledSum<float>>(big);
+    CHECK_EQ(sm::sum(rb), 4.0 * 100003);
+    sm::SMArray<int> ia = {1, 2, 3}, ib = {4, 5, 6};
+    auto ri = ia.apply<ScaledSum<int>>(ib);
+    CHECK_EQ(ri(2), 18);
+    auto rs = a.apply_scalar<ScaledSum<float>>(0.5f);
+    CHECK_EQ(rs(1, 0), 9.0f);
+    float x[4] = {1, 2, 3, 4}, y[4] = {1, 1, 1, 1}, z[4] = {};
+    handle_contiguous_arrays<float, ScaledSum<float>>(x, y, z, 4);  // the host-pointer loop template, same Op
+    CHECK_EQ(z[3], 10.0f);
+}
 TEST(PluginWithoutDeviceFunctorIsRefused) {
     sm::SMArray<float> a = {1, 2}, b = {3, 4};
     bool refused = false;
@@ -440,7 +462,8 @@ int main() {
                          run_DivisionBySelf, run_ScalarPow, run_OneDimensionalPow, run_TwoDimensionalPow, run_NonSquareShape,
                          run_TestLargeArrays, run_TestLargeArraysWithNegatives, run_NegativeExponent_disabled_in_reference,
                          run_TestLargeArraysDifferentValues_disabled_in_reference, run_ReadmeExample, run_BroadcastError, run_DotProduct,
-                         run_ComplexDot, run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_HostPointerLoops, run_PluginWithoutDeviceFunctorIsRefused};
+                         run_ComplexDot, run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_HostPointerLoops, run_PluginWithDeviceExpression,
+                         run_PluginWithoutDeviceFunctorIsRefused};
     int n = 0;
     for (auto t : tests) {
         try {

@@ -321,6 +321,37 @@ def test_complex_dot(smhip):
         assert abs(got - want) <= 4 * n * 2.0 ** -53 * scale + 1e-300, n
 
 
+def test_user_op_via_hiprtc(smhip):
+    """The plugin contract on the device: an Op registered as a HIP expression runs through the same
+    entry points as the built-ins (contiguous, scalar, broadcast), for every element type."""
+    op = smhip.register_op("(a + b) * 2")
+    assert op >= 100 and smhip.register_op("(a + b) * 2") == op  # idempotent
+    for dtn in ("f32", "f64", "i32", "i64"):
+        for n in (1, 5, 4099):
+            a = gen.gen(DT[dtn], n, 71, "uniform")
+            b = gen.gen(DT[dtn], n, 72, "uniform")
+            got = smhip.contiguous(op, smhip.to_device(a), smhip.to_device(b)).numpy()
+            assert np.array_equal(got, ((a + b) * DT[dtn](2)).astype(DT[dtn])), (dtn, n)
+        s = smhip.array_scalar(op, smhip.to_device(a), 3).numpy()
+        assert np.array_equal(s, ((a + DT[dtn](3)) * DT[dtn](2)).astype(DT[dtn]))
+    A = gen.gen(np.float32, 37 * 64, 73, "uniform").reshape(37, 64)
+    r = gen.gen(np.float32, 64, 74, "uniform").reshape(1, 64)
+    got = smhip.binary(op, smhip.to_device(A), smhip.to_device(r)).numpy()
+    assert np.array_equal(got, (A + r) * np.float32(2))
+    dA = smhip.to_device(A)
+    got = smhip.binary(op, dA.view_like(A.T, A), smhip.to_device(np.ascontiguousarray(A.T))).numpy()
+    assert np.array_equal(got, (A.T + A.T) * np.float32(2))
+    # a second op with intrinsics, and one that does not compile
+    hyp = smhip.register_op("sqrtf((float)(a * a + b * b))")
+    a = gen.gen(np.float32, 1000, 75, "uniform"); b = gen.gen(np.float32, 1000, 76, "uniform")
+    got = smhip.contiguous(hyp, smhip.to_device(a), smhip.to_device(b)).numpy()
+    assert orc.ulp_diff_f32(got, np.sqrt(a * a + b * b)).max() <= 1
+    bad = smhip.register_op("a +* b")
+    with pytest.raises(sma.SmhipError) as e:
+        smhip.contiguous(bad, smhip.to_device(a), smhip.to_device(b))
+    assert "does not compile" in str(e.value)
+
+
 def test_left_op_gathers_views(smhip):
     """SMHIP_OP_LEFT (out = a): the dense copy of strided / broadcast views that contiguous() and repeat()
     are built from; bit-exact including NaN payloads (nothing is computed)."""
