@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--workload", default="add", choices=sorted(WORKLOADS))
     ap.add_argument("--log2n", type=int, default=None, help="elements per GPU = 2^log2n (default: the config's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 path, e.g. 2 ranks sharing one GPU")
     ap.add_argument("--cpu-log2n", type=int, default=26)
     return ap.parse_args()
 
@@ -125,8 +127,12 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank %= max(torch.cuda.device_count(), 1)  # identity on a full node; lets a rehearsal share one GPU
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import numpy as np
     import simplemath_amd as sma
@@ -207,8 +213,9 @@ def main():
     wall = t1 - t0
     kern_ms = lib.elapsed_ms(e0, e1) / args.steps  # average launch duration, back-to-back on one stream
 
+    coll_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"
     if dist is not None:
-        t = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
 
@@ -219,18 +226,27 @@ def main():
     c5 = None
     if wl == "add" and world > 1:
         part = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+        def c5_step():
+            lib.contiguous_sum_async(sma.OP_ADD, a, b, c, part.data_ptr())  # partial sum stays in HBM
+            if coll_dev == "cuda":
+                dist.all_reduce(part)  # RCCL, same stream: 8 bytes per rank
+                return part
+            host = part.cpu()  # gloo rehearsal: the collective runs on the host copy
+            dist.all_reduce(host)
+            return host
+
         for _ in range(3):
-            lib.contiguous_sum_async(sma.OP_ADD, a, b, c, part.data_ptr())
-            dist.all_reduce(part)
+            total = c5_step()
         barrier()
         tc = time.perf_counter()
         reps = 20
         for _ in range(reps):
-            lib.contiguous_sum_async(sma.OP_ADD, a, b, c, part.data_ptr())
-            dist.all_reduce(part)
+            total = c5_step()
         barrier()
         tc = (time.perf_counter() - tc) / reps
-        tt = torch.tensor([tc], dtype=torch.float64, device="cuda")
+        part = total
+        tt = torch.tensor([tc], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         c5 = {"workload": f"fused add+sum over {world} x 2^{log2n} f32 + one RCCL all-reduce (1 x fp64)",
               "ms_per_step": float(tt[0]) * 1e3, "value": world * n / float(tt[0]) / 1e9, "unit": "Gelem/s",

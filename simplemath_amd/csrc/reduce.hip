@@ -25,7 +25,8 @@ namespace {
 using namespace dev;
 
 constexpr int kBlock = 256;
-constexpr int kVecPerThread = 4;  // 4 x 16 B in flight per lane and operand; 64 KiB+ tiles keep partials few
+constexpr int kVecPerThread = 1;  // one 16-byte vector per lane and operand, like the streaming kernels:
+                                  // profiles/r01_sweep_fused_sum.txt -- 81.6 % of peak vs 79 % (4) / 72 % (8)
 constexpr int kFinalBlock = 1024;
 
 template <typename T> struct AccOf { typedef double type; };
@@ -164,7 +165,20 @@ __global__ __launch_bounds__(kBlock) void reduce_elem_kernel(const T *__restrict
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
-// Second pass: fixed-order sum of the partials.  *out8 receives 8 bytes:
+// Intermediate pass when there are many partials (one vector per lane means one partial per 4 KiB
+// of each operand): every workgroup folds kFoldSpan of them into one, in a fixed order.
+constexpr int kFoldSpan = 8192;
+template <typename A>
+__global__ __launch_bounds__(kBlock) void fold_kernel(const A *__restrict__ in, size_t count, A *__restrict__ out) {
+    const size_t base = (size_t)blockIdx.x * kFoldSpan;
+    A acc = A(0);
+    for (int k = threadIdx.x; k < kFoldSpan; k += kBlock)
+        if (base + k < count) acc += in[base + k];
+    acc = block_reduce<A, kBlock>(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+// Last pass: fixed-order sum of the partials.  *out8 receives 8 bytes:
 //   floats            the fp64 total;
 //   ints, AS_DOUBLE   (double) of the exact 64-bit total         (sum, fused op+sum);
 //   ints, !AS_DOUBLE  the total wrapped to T, sign-extended to int64 (dot: per-rank
@@ -246,14 +260,21 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     else blocks = n < (size_t)kBlock * 2048 ? (n + kBlock - 1) / kBlock : 2048;
     if (blocks == 0) blocks = 1;
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);
+    const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
     double *scratch;
-    if (int rc = reduce_scratch(blocks, &scratch)) return rc;
+    if (int rc = reduce_scratch(blocks + folded, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
     if (vec)
         hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials);
     else
         hipLaunchKernelGGL((reduce_elem_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n, partials);
     SMHIP_LAUNCH_CHECK("reduce");
+    if (blocks > (size_t)kFoldSpan) {
+        hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)folded), dim3(kBlock), 0, s, partials, blocks, partials + blocks);
+        SMHIP_LAUNCH_CHECK("reduce fold");
+        partials += blocks;
+        blocks = folded;
+    }
     hipLaunchKernelGGL((finalize_kernel<T, MODE != kDot>), dim3(1), dim3(kFinalBlock), 0, s, partials, blocks, out8, static_cast<T *>(out_native));
     SMHIP_LAUNCH_CHECK("reduce finalize");
     return SMHIP_OK;
