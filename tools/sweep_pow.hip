@@ -114,5 +114,28 @@ int main() {
         snprintf(nm, sizeof nm, "prefetch block512 grid=256x%d", mult); rep(nm, timeit([&] { prefetch<512><<<256 * mult, 512>>>(av, 2.5f, ov, nvec); }));
         snprintf(nm, sizeof nm, "prefetch block64 grid=256x%d", mult * 4); rep(nm, timeit([&] { prefetch<64><<<256 * mult * 4, 64>>>(av, 2.5f, ov, nvec); }));
     }
+    // back-to-back launches (what bench.py times): does the isolated-launch time hold?
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        auto b2b = [&](const char* name, auto launch) {
+            for (int i = 0; i < 5; ++i) launch();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 100; ++i) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("B2B x100 %-40s %.4f ms/launch %8.1f GB/s\n", name, ms / 100, 8.0 * n / (ms / 100) * 1e-6);
+        };
+        b2b("prefetch b512 x32 (nt ld+st)", [&] { prefetch<512><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch b512 x8", [&] { prefetch<512><<<256 * 8, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch b512 x4", [&] { prefetch<512><<<256 * 4, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch b256 x16", [&] { prefetch<256><<<256 * 16, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("oneshot U4 b256", [&] { oneshot<4, 256><<<nvec / 1024, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("oneshot U2 b256", [&] { oneshot<2, 256><<<nvec / 512, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("COPY oneshot U1 b1024", [&] { copy_oneshot<1, 1024><<<nvec / 1024, 1024>>>(av, ov); });
+        // alternate between two output buffers so a launch never rewrites lines the previous one left dirty
+        float* o2; CK(hipMalloc(&o2, n * 4)); f4* ov2 = (f4*)o2; int flip = 0;
+        b2b("prefetch b512 x32, alternating outputs", [&] { prefetch<512><<<256 * 32, 512>>>(av, 2.5f, (flip ^= 1) ? ov : ov2, nvec); });
+    }
     return 0;
 }
