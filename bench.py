@@ -218,7 +218,7 @@ def main():
         i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
         step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(AT.ptr), i64([1, cols]),
                      C.c_void_p(B2.ptr), i64([rows, 1]), i64([cols, rows]), C.c_int(2), C.c_void_p(out.ptr))
-        kernel = "tile_kernel<float, AddOp<float>, true>"
+        kernel = "tile_kernel<float, AddOp<float>, true, 1, 0>"
         workload = "2D float32 A.T + B, 8192x8192, A read through a transposed view, HBM-resident"
     else:  # pow
         log2n = args.log2n or 26

@@ -14,7 +14,7 @@
 //                  strides (the (1 x 4096) row of BASELINE config 3) is loaded
 //                  once per workgroup and kept in registers across its rows;
 //   tile kernel    an operand whose own contiguous axis is NOT the output's inner
-//                  axis (transpose() views, permuted 3-D+ views): 64 x 64 patches of
+//                  axis (transpose() views, permuted 3-D+ views): 64 x 128 patches of
 //                  the (p, q) plane -- p = the operand's contiguous axis, q = the
 //                  output's inner axis -- are read coalesced along p, turned through
 //                  a padded LDS tile, and consumed coalesced along q.  The reference
@@ -170,14 +170,17 @@ __global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, co
 }
 
 // ------------------------------------------------------------------ tile kernel
-constexpr int kTile = 64;
+// Patch shape from tools/sweep_transpose.hip (profiles/r01_sweep_transpose.txt): 64 along p x 128 along q --
+// 256-byte segments on the strided (transposed) side, 512-byte segments on the output side, consecutive
+// workgroups walking q -- matched the plain add's rate; 64 x 64 was 8 % behind, p-fastest ordering 15-25 %.
+constexpr int kTileP = 64, kTileQ = 128;
 
 struct TileParams {
     // plane axes: p (operand-contiguous axis), q (output inner axis)
     uint32_t np, nq;            // extents
     int64_t a_p, a_q, b_p, b_q; // operand strides along p and q (elements)
     int64_t o_p;                // output stride along p (its q stride is 1)
-    int mode_a, mode_b;         // 0: read along q (stride 0/1 there, or anything: direct); 1: through LDS (contiguous along p)
+    int mode_a, mode_b;         // 1: turned through LDS (operand contiguous along p); 0: read along q directly
     // remaining axes, innermost first
     int n_rest;
     FastDiv rest[SMHIP_MAX_NDIM - 2];
@@ -185,21 +188,24 @@ struct TileParams {
     uint32_t tiles_p, tiles_q;
 };
 
-// One workgroup = one 64 x 64 patch (i along p, j along q) of one slice of the remaining axes.
-// VEC: every global access is a 16-byte vector (W elements) -- along p for the operands that
-// are turned through LDS, along q for direct operands and the output.  LDS tiles are stored
-// already transposed ([i][j], pitch 65 words: the 4-byte scatter of phase 1 and the row reads
-// of phase 2 are both at most 2-way bank conflicted).  !VEC: one element per access, for
-// extents / pitches / bases that are not multiples of 16 bytes.
-template <typename T, typename Op, bool VEC>
+// One workgroup = one 64 x 128 patch (i along p, j along q) of one slice of the remaining axes.
+// VEC: every global access is a 16-byte vector (W elements) -- along p for operands turned through
+// LDS, along q for direct operands and the output.  LDS tiles are stored already transposed ([i][j],
+// pitch kTileQ + 1 words: the 4-byte scatter of phase 1 and the row reads of phase 2 are at most 2-way
+// bank conflicted) and only as many of them exist as there are LDS-mode operands (dynamic LDS), so a
+// single transposed operand leaves room for 4 workgroups per CU.  MA / MB are compile-time in the
+// vector form; the element form (odd extents, pitches, bases) keeps them as runtime values.
+template <typename T, typename Op, bool VEC, int MA, int MB>
 __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                    TileParams p) {
     constexpr int W = VEC ? VecTraits<T>::width : 1;
-    constexpr int VPR = kTile / W;             // vector slots per patch row
-    constexpr int STEPS = kTile * VPR / 256;   // per thread
+    constexpr int VP = kTileP / W, VQ = kTileQ / W;  // vector slots per patch row, along p / along q
+    constexpr int PITCH = kTileQ + 1;
     typedef typename VecTraits<T>::vec_t V;
-    __shared__ T lds_a[kTile][kTile + 1];      // [i][j]
-    __shared__ T lds_b[kTile][kTile + 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
+    const int mode_a = VEC ? MA : p.mode_a, mode_b = VEC ? MB : p.mode_b;
+    T *lds_a = lds, *lds_b = lds + (mode_a == 1 ? kTileP * PITCH : 0);
     OpCtx<Op> ctx;
     ctx.init();
     uint32_t bid = blockIdx.x;
@@ -214,37 +220,43 @@ __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, cons
         offB += (int64_t)idx * p.b_r[k];
         offO += (int64_t)idx * p.o_r[k];
     }
-    const uint32_t i0 = tp * kTile, j0 = tq * kTile;
-    auto stage = [&](const T *src, int64_t off, int64_t s_q, T (&lds)[kTile][kTile + 1]) {
-        // coalesced along p: slot ig covers i = ig*W .. ig*W+W-1 of row j
+    const uint32_t i0 = tp * kTileP, j0 = tq * kTileQ;
+    const bool full = i0 + kTileP <= p.np && j0 + kTileQ <= p.nq;  // workgroup-uniform
+    // patch origins
+    const T *a0 = a + offA + (int64_t)i0 * p.a_p + (int64_t)j0 * p.a_q;
+    const T *b0 = b + offB + (int64_t)i0 * p.b_p + (int64_t)j0 * p.b_q;
+    T *o0 = out + offO + (int64_t)i0 * p.o_p + j0;
+
+    // phase 1: LDS-mode operands, coalesced along p (slot ig covers i = ig*W .. +W-1 of row jl)
+    auto stage = [&](const T *src0, int64_t s_q, T *tile) {
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const uint32_t v = threadIdx.x + 256 * s, jl = v / VPR, ig = v % VPR;
-            const uint32_t i = i0 + ig * W, j = j0 + jl;
-            if (i < p.np && j < p.nq) {
-                const T *g = src + off + (int64_t)i + (int64_t)j * s_q;
+        for (int s = 0; s < kTileQ * VP / 256; ++s) {
+            const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
+            if (full || (i0 + ig * W < p.np && j0 + jl < p.nq)) {
+                const T *g = src0 + ig * W + (int64_t)jl * s_q;
                 if constexpr (VEC) {
                     const V val = *reinterpret_cast<const V *>(g);
 #pragma unroll
-                    for (int k = 0; k < W; ++k) lds[ig * W + k][jl] = val[k];
+                    for (int k = 0; k < W; ++k) tile[(ig * W + k) * PITCH + jl] = val[k];
                 } else {
-                    lds[ig][jl] = *g;
+                    tile[ig * PITCH + jl] = *g;
                 }
             }
         }
     };
-    if (p.mode_a == 1) stage(a, offA, p.a_q, lds_a);
-    if (p.mode_b == 1) stage(b, offB, p.b_q, lds_b);
-    if (p.mode_a == 1 || p.mode_b == 1) __syncthreads();
-    auto fetch = [&](const T *src, int64_t off, int64_t s_p, int64_t s_q, int mode, const T (&lds)[kTile][kTile + 1],
-                     uint32_t il, uint32_t jg, uint32_t i, uint32_t j, T (&dst)[W]) {
+    if (mode_a == 1) stage(a0, p.a_q, lds_a);
+    if (mode_b == 1) stage(b0, p.b_q, lds_b);
+    __syncthreads();
+
+    // phase 2: everything coalesced along q (slot jg covers j = jg*W .. +W-1 of row il)
+    auto fetch = [&](const T *src0, int64_t s_p, int64_t s_q, int mode, const T *tile, uint32_t il, uint32_t jg, T (&dst)[W]) {
         if (mode == 1) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = lds[il][jg * W + k];
+            for (int k = 0; k < W; ++k) dst[k] = tile[il * PITCH + jg * W + k];
         } else {
-            const T *g = src + off + (int64_t)i * s_p + (int64_t)j * s_q;
+            const T *g = src0 + (int64_t)il * s_p + (int64_t)(jg * W) * s_q;
             if (VEC && s_q == 1) {
-                const V val = *reinterpret_cast<const V *>(g);
+                const V val = load_stream(reinterpret_cast<const V *>(g));
 #pragma unroll
                 for (int k = 0; k < W; ++k) dst[k] = val[k];
             } else {
@@ -254,15 +266,14 @@ __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, cons
         }
     };
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const uint32_t v = threadIdx.x + 256 * s, il = v / VPR, jg = v % VPR;
-        const uint32_t i = i0 + il, j = j0 + jg * W;
-        if (i < p.np && j < p.nq) {
+    for (int s = 0; s < kTileP * VQ / 256; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
+        if (full || (i0 + il < p.np && j0 + jg * W < p.nq)) {
             T xa[W], xb[W], xr[W];
-            fetch(a, offA, p.a_p, p.a_q, p.mode_a, lds_a, il, jg, i, j, xa);
-            fetch(b, offB, p.b_p, p.b_q, p.mode_b, lds_b, il, jg, i, j, xb);
+            fetch(a0, p.a_p, p.a_q, mode_a, lds_a, il, jg, xa);
+            fetch(b0, p.b_p, p.b_q, mode_b, lds_b, il, jg, xb);
             apply_n<Op, T, W>(ctx, xa, xb, xr);
-            T *dst = out + offO + (int64_t)i * p.o_p + j;
+            T *dst = o0 + (int64_t)il * p.o_p + jg * W;
             if constexpr (VEC) {
                 V val;
 #pragma unroll
@@ -422,8 +433,8 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
                 ++t.n_rest;
                 slices *= (size_t)pl.shape[d];
             }
-            t.tiles_p = (t.np + kTile - 1) / kTile;
-            t.tiles_q = (t.nq + kTile - 1) / kTile;
+            t.tiles_p = (t.np + kTileP - 1) / kTileP;
+            t.tiles_q = (t.nq + kTileQ - 1) / kTileQ;
             const size_t blocks = slices * t.tiles_p * t.tiles_q;
             if (blocks < 0x7fffffffull && pl.shape[paxis] < 0x7fffffffll && inner < 0x7fffffffll) {
                 // 16-byte accesses need every vector to start on a 16-byte boundary: bases, both plane
@@ -434,8 +445,12 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
                 if (t.mode_b == 1) vec &= mult(t.b_q); else vec &= mult(t.b_p);
                 vec &= mult(t.o_p);
                 for (int k = 0; k < t.n_rest; ++k) vec &= mult(t.a_r[k]) && mult(t.b_r[k]) && mult(t.o_r[k]);
-                if (vec) hipLaunchKernelGGL((tile_kernel<T, Op, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, t);
-                else hipLaunchKernelGGL((tile_kernel<T, Op, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, t);
+                const size_t lds_bytes = (size_t)(t.mode_a + t.mode_b) * kTileP * (kTileQ + 1) * sizeof(T);
+                const dim3 grid((unsigned)blocks), block(256);
+                if (!vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0>), grid, block, lds_bytes, s, a, b, out, t);
+                else if (t.mode_a == 1 && t.mode_b == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1>), grid, block, lds_bytes, s, a, b, out, t);
+                else if (t.mode_a == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0>), grid, block, lds_bytes, s, a, b, out, t);
+                else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, lds_bytes, s, a, b, out, t);
                 SMHIP_LAUNCH_CHECK("tile_kernel");
                 return SMHIP_OK;
             }
