@@ -6,7 +6,7 @@
 //
 // Roofline: HBM-bound.  Algorithmic traffic 3 * sizeof(T) B/elem for a op b
 // (2 reads + 1 write; 12 B/elem for f32), 2 * sizeof(T) for a op scalar.
-// Shape of the launch (profiles/sweep_r1_stream.txt, N = 2^28 f32 add):
+// Shape of the launch (profiles/r01_sweep_stream_add.txt, N = 2^28 f32 add):
 //   - one 16-byte vector per lane (float4 / double2 / int4 / long2): a wave
 //     moves 1 KiB per memory instruction, fully coalesced;
 //   - NO grid-stride loop: one vector per thread, >= 65k workgroups, so the

@@ -30,7 +30,7 @@ template <> struct VecTraits<int64_t> { typedef int64_t vec_t __attribute__((ext
 
 // Streaming accesses carry the `nt` (non-temporal) policy: every byte of the
 // contiguous path is touched once, and keeping it out of L2's replacement
-// order is worth ~8 % on the 2R+1W stream (profiles/sweep_r1_stream.txt).
+// order is worth ~8 % on the 2R+1W stream (profiles/r01_sweep_stream_add.txt).
 template <typename V> __device__ __forceinline__ V load_stream(const V *p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ void store_stream(V *p, V v) { __builtin_nontemporal_store(v, p); }
 

@@ -506,6 +506,34 @@ def test_config5_shard_add_sum(smhip, oracle):
     assert abs(s - n) < 6 * np.sqrt(n / 6.0)  # E[a+b] = 1, var = 1/6: a 6-sigma sanity band
 
 
+def test_unsharded_config5_size_2p31(smhip, oracle):
+    """N = 2^31 + 3 elements in ONE array (8 GiB per operand on a 288 GB device): global indices pass
+    2^31 -- 64-bit indexing end to end (SURVEY section 7 "hard parts"), an odd tail, and the fused sum."""
+    n, w = (1 << 31) + 3, 1 << 16
+    a = smhip.uniform_f32(n, 6, 0.0, 1.0)
+    b = smhip.uniform_f32(n, 7, 0.0, 1.0)
+    c = smhip.empty((n,), np.float32)
+    sp = smhip.alloc(8)
+    smhip.contiguous_sum_async(sma.OP_ADD, a, b, c, sp)
+    s = smhip.read_f64(sp)
+    smhip.free(sp)
+    host = np.empty(w, dtype=np.float32)
+    for off in (0, 1 << 30, (1 << 31) - w - 5, n - w):  # up to and across the 2^31 boundary, incl. the 3-element tail
+        smhip.download(host, c.ptr + off * 4)
+        ha = oracle.uniform_f32(w, 6, 0.0, 1.0, first=off)
+        hb = oracle.uniform_f32(w, 7, 0.0, 1.0, first=off)
+        util.assert_same_bits(host, oracle.contiguous(orc.ADD, ha, hb), f"slice @{off}")
+    assert s == smhip.sum(c)
+    assert abs(s - n) < 6 * np.sqrt(n / 6.0)
+    d = smhip.contiguous(sma.OP_SUB, c, a)  # (a + b) - a: plain kernel at the same size
+    smhip.download(host, d.ptr + (n - w) * 4)
+    ha = oracle.uniform_f32(w, 6, 0.0, 1.0, first=n - w)
+    hb = oracle.uniform_f32(w, 7, 0.0, 1.0, first=n - w)
+    util.assert_same_bits(host, oracle.contiguous(orc.SUB, oracle.contiguous(orc.ADD, ha, hb), ha), "tail of (a+b)-a")
+    del a, b, c, d
+    smhip.pool_trim()
+
+
 # ------------------------------------------------------------------ 5. edge cases
 def test_empty_and_tiny(smhip):
     e = smhip.empty((0,), np.float32)
