@@ -10,7 +10,7 @@ timeout -k 10 600 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; e
 tail -5 $out/pytest_gpu.log
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log
 timeout -k 10 300 python bench.py --gpus 1 > $out/bench_add.json 2> $out/bench_add.err; echo "bench rc=$?"; cat $out/bench_add.json
-for wl in bcast_mul pow add_sum; do
+for wl in bcast_mul pow add_sum transpose_add; do
   timeout -k 10 120 python bench.py --workload $wl --steps 100 --warmup 10 > $out/bench_$wl.json 2> $out/bench_$wl.err; cat $out/bench_$wl.json
 done
 cd /tmp
@@ -18,3 +18,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT
 cd $GRAFT_REPO_ROOT
 find $out/prof_add -name "*stats*" | head; 
 f=$(find $out/prof_add -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
+for wl in bcast_mul pow add_sum transpose_add; do bash tools/prof_wl.sh $tag $wl > $out/prof_$wl.txt 2>&1; done
