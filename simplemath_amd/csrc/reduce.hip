@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void reduce_elem_kernel(const T *__restrict
 
 // Intermediate pass when there are many partials (one vector per lane means one partial per 4 KiB
 // of each operand): every workgroup folds kFoldSpan of them into one, in a fixed order.
-constexpr int kFoldSpan = 8192;
+constexpr int kFoldSpan = 1024;  // 2^18 partials (2^28 f32) -> 256 workgroups here, 256 values for the last pass
 template <typename A>
 __global__ __launch_bounds__(kBlock) void fold_kernel(const A *__restrict__ in, size_t count, A *__restrict__ out) {
     const size_t base = (size_t)blockIdx.x * kFoldSpan;
