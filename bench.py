@@ -154,7 +154,12 @@ def main():
     lib = sma.load()  # raises if the HIP library is missing: no CPU fallback
     lib.set_device(local_rank)
     if torch is not None:
-        lib.set_stream(torch.cuda.current_stream().cuda_stream)
+        # One explicit side stream shared by libsmhip's kernels and torch's collectives, so the all-reduce of
+        # a partial sum is ordered after the kernel that produced it.  (torch's default stream is the null
+        # stream, whose handle 0 libsmhip reads as "use your own stream" -- hence a real stream object.)
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        lib.set_stream(side.cuda_stream)
 
     def barrier():
         lib.synchronize()
