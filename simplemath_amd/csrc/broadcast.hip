@@ -46,6 +46,7 @@ struct RowParams {
     uint32_t rows;    // product of outer extents
     uint32_t inner;   // inner extent in elements
     uint32_t vpr;     // vector slots per row = ceil(inner / W)
+    uint32_t grid_x;  // workgroups along the row; the launch is 1-D (grid y is limited to 65 535)
 };
 
 // INNER_x: 1 = dense along the inner axis, 0 = broadcast along it.
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
     OpCtx<Op> ctx;
     ctx.init();
     const uint32_t tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const uint32_t col = blockIdx.x * TX + tx;  // vector slot within the row
+    const uint32_t bx = blockIdx.x % p.grid_x, by = blockIdx.x / p.grid_x;
+    const uint32_t col = bx * TX + tx;  // vector slot within the row
     if (col >= p.vpr) return;
     const size_t col_elem = (size_t)col * W;
 
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
     if constexpr (CONST_A) load(a, 0, INNER_A, ca);
     if constexpr (CONST_B) load(b, 0, INNER_B, cb);
 
-    const uint32_t row0 = (blockIdx.y * ROWS) * TY + ty;
+    const uint32_t row0 = (by * ROWS) * TY + ty;
     uint32_t rows_here = 0;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -323,20 +325,25 @@ Plan normalise(const int64_t *shape, const int64_t *sa, const int64_t *sb, int n
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T, typename Op, bool VEC, int IA, int IB, bool CA, bool CB>
-int launch_row_tx(const T *a, const T *b, T *out, const RowParams &p, hipStream_t s) {
+int launch_row_tx(const T *a, const T *b, T *out, const RowParams &p_in, hipStream_t s) {
     constexpr int ROWS = 4;
+    RowParams p = p_in;
+    bool too_big = false;
     auto go = [&](auto tx_tag) {
         constexpr int TX = decltype(tx_tag)::value;
         constexpr int TY = 256 / TX;
-        const unsigned gx = (p.vpr + TX - 1) / TX;
-        const unsigned gy = (p.rows + TY * ROWS - 1) / (TY * ROWS);
-        hipLaunchKernelGGL((row_kernel<T, Op, VEC, IA, IB, CA, CB, TX, ROWS>), dim3(gx, gy), dim3(256), 0, s, a, b, out, p);
+        const size_t gx = (p.vpr + TX - 1) / TX;
+        const size_t gy = ((size_t)p.rows + TY * ROWS - 1) / (TY * ROWS);
+        if (gx * gy > 0x7fffffffull) { too_big = true; return; }
+        p.grid_x = (uint32_t)gx;
+        hipLaunchKernelGGL((row_kernel<T, Op, VEC, IA, IB, CA, CB, TX, ROWS>), dim3((unsigned)(gx * gy)), dim3(256), 0, s, a, b, out, p);
     };
     if (p.vpr > 128) go(std::integral_constant<int, 256>{});
     else if (p.vpr > 64) go(std::integral_constant<int, 128>{});
     else if (p.vpr > 32) go(std::integral_constant<int, 64>{});
     else if (p.vpr > 16) go(std::integral_constant<int, 32>{});
     else go(std::integral_constant<int, 16>{});
+    if (too_big) return fail(SMHIP_ERR_UNSUPPORTED, "row kernel: more than 2^31 workgroups");
     SMHIP_LAUNCH_CHECK("row_kernel");
     return SMHIP_OK;
 }

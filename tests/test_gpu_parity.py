@@ -506,6 +506,23 @@ def test_config5_shard_add_sum(smhip, oracle):
     assert abs(s - n) < 6 * np.sqrt(n / 6.0)  # E[a+b] = 1, var = 1/6: a 6-sigma sanity band
 
 
+def test_many_short_rows(smhip, oracle):
+    """2^22 rows of 64 floats against a (1 x 64) row: more workgroups along the row axis than a grid's y
+    dimension (65 535) allows -- the row kernel's launch is 1-D."""
+    rows, cols = 1 << 22, 64
+    A = smhip.uniform_f32(rows * cols, 81, -1.0, 1.0)
+    r = smhip.uniform_f32(cols, 82, -1.0, 1.0)
+    A2 = sma.DeviceArray(smhip, A.base_ptr, np.float32, (rows, cols), (cols, 1), 0, A._owner)
+    r2 = sma.DeviceArray(smhip, r.base_ptr, np.float32, (1, cols), (cols, 1), 0, r._owner)
+    out = smhip.binary(sma.OP_MUL, A2, r2)
+    hr = oracle.uniform_f32(cols, 82, -1.0, 1.0).reshape(1, cols)
+    host = np.empty((1024, cols), dtype=np.float32)
+    for row0 in (0, 70000 * 64 // 64, rows // 2 + 17, rows - 1024):
+        smhip.download(host, out.ptr + row0 * cols * 4)
+        ha = oracle.uniform_f32(1024 * cols, 81, -1.0, 1.0, first=row0 * cols).reshape(1024, cols)
+        util.assert_same_bits(host, oracle.binary(orc.MUL, ha, hr), f"rows @{row0}")
+
+
 def test_unsharded_config5_size_2p31(smhip, oracle):
     """N = 2^31 + 3 elements in ONE array (8 GiB per operand on a 288 GB device): global indices pass
     2^31 -- 64-bit indexing end to end (SURVEY section 7 "hard parts"), an odd tail, and the fused sum."""
