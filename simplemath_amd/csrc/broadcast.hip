@@ -21,6 +21,12 @@
 //                  walks such operands with a div/mod chain and a strided scalar load
 //                  per element; a naive GPU gather would touch one 64-byte line per
 //                  lane (16x read amplification).
+//   LDS kernel     one operand dense in output order, the other small (<= 32 KiB once every stride-0
+//                  axis is dropped) but broadcast along the INNER axis or with a tiny inner extent
+//                  -- the reference tests' own pattern, (N,224,224,3) op (1,224,1,3): the small
+//                  operand is staged whole into LDS once per workgroup, the dense one streams
+//                  as 16-byte vectors, and the per-element unravel (fast division) only feeds
+//                  an LDS read.
 //   gather kernel  whatever is left (tiny extents, irregular strides): W
 //                  consecutive outputs per lane so the store is still a
 //                  coalesced 16-byte vector; operand loads are per-element
@@ -169,6 +175,56 @@ __global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, co
     } else {
         out[first] = res[0];
     }
+}
+
+// ------------------------------------------------------------------- LDS kernel
+struct LdsParams {
+    int64_t sy[SMHIP_MAX_NDIM];       // the small operand's strides, innermost first
+    FastDiv shape[SMHIP_MAX_NDIM];    // innermost first
+    int ndim;
+    uint32_t n, n_vec;                // outputs, and whole vectors among them
+    uint32_t y_span;                  // elements of the small operand to stage
+};
+
+// x: the operand that is dense in output order (streams as vectors); y: the small one, gathered
+// from its LDS copy.  SWAPPED: x is the Op's right operand.
+template <typename T, typename Op, bool SWAPPED>
+__global__ __launch_bounds__(256) void dense_lds_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out,
+                                                        LdsParams p) {
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *ylds = reinterpret_cast<T *>(lds_raw);
+    OpCtx<Op> ctx;
+    ctx.init();
+    for (uint32_t i = threadIdx.x; i < p.y_span; i += 256) ylds[i] = y[i];
+    __syncthreads();
+    auto y_at = [&](uint32_t linear) {
+        uint32_t rem = linear;
+        int64_t off = 0;
+        for (int d = 0; d < p.ndim; ++d) {
+            uint32_t q, idx;
+            p.shape[d].divmod(rem, q, idx);
+            rem = q;
+            off += (int64_t)idx * p.sy[d];
+        }
+        return ylds[off];
+    };
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < p.n_vec; v += stride) {
+        const V xv = load_stream(reinterpret_cast<const V *>(x) + v);
+        T xa[W], ya[W], r[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { xa[k] = xv[k]; ya[k] = y_at(v * W + k); }
+        if (SWAPPED) apply_n<Op, T, W>(ctx, ya, xa, r);
+        else apply_n<Op, T, W>(ctx, xa, ya, r);
+        V rv;
+#pragma unroll
+        for (int k = 0; k < W; ++k) rv[k] = r[k];
+        store_stream(reinterpret_cast<V *>(out) + v, rv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint32_t e = p.n_vec * W; e < p.n; ++e) out[e] = SWAPPED ? Op::apply(y_at(e), x[e]) : Op::apply(x[e], y_at(e));
 }
 
 // ------------------------------------------------------------------ tile kernel
@@ -404,6 +460,49 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         }
         p.vpr = (uint32_t)inner;
         return launch_row<T, Op, false>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
+    }
+
+    // One operand dense in output order, the other small: stage the small one in LDS.
+    if (pl.n < 0x7fffffffull && aligned16(out)) {
+        auto dense_in_output_order = [&](const int64_t *st) {
+            int64_t expect = 1;
+            for (int d = nd - 1; d >= 0; --d) {
+                if (st[d] != expect) return false;
+                expect *= pl.shape[d];
+            }
+            return true;
+        };
+        auto span_of = [&](const int64_t *st) {
+            int64_t last = 0;
+            for (int d = 0; d < nd; ++d) last += (pl.shape[d] - 1) * st[d];
+            return last + 1;
+        };
+        constexpr int64_t kLdsBytes = 32 << 10;
+        const bool a_dense = dense_in_output_order(pl.sa), b_dense = dense_in_output_order(pl.sb);
+        const int64_t span_a = span_of(pl.sa), span_b = span_of(pl.sb);
+        int pick = -1;  // 0: a streams, b staged;  1: b streams, a staged
+        if (a_dense && !b_dense && aligned16(a) && span_b * (int64_t)sizeof(T) <= kLdsBytes) pick = 0;
+        else if (b_dense && !a_dense && aligned16(b) && span_a * (int64_t)sizeof(T) <= kLdsBytes) pick = 1;
+        if (pick >= 0) {
+            LdsParams lp{};
+            lp.ndim = nd;
+            lp.n = (uint32_t)pl.n;
+            lp.n_vec = (uint32_t)(pl.n / W);
+            lp.y_span = (uint32_t)(pick == 0 ? span_b : span_a);
+            for (int d = 0; d < nd; ++d) {
+                const int src = nd - 1 - d;
+                lp.shape[d] = FastDiv((uint32_t)pl.shape[src]);
+                lp.sy[d] = pick == 0 ? pl.sb[src] : pl.sa[src];
+            }
+            const size_t want = ((size_t)lp.n_vec + 255) / 256;
+            const size_t cap = (size_t)compute_units() * 8;
+            const unsigned grid = (unsigned)(want < cap ? (want ? want : 1) : cap);
+            const size_t lds = (size_t)lp.y_span * sizeof(T);
+            if (pick == 0) hipLaunchKernelGGL((dense_lds_kernel<T, Op, false>), dim3(grid), dim3(256), lds, s, a, b, out, lp);
+            else hipLaunchKernelGGL((dense_lds_kernel<T, Op, true>), dim3(grid), dim3(256), lds, s, b, a, out, lp);
+            SMHIP_LAUNCH_CHECK("dense_lds_kernel");
+            return SMHIP_OK;
+        }
     }
 
     // An operand that is contiguous along some OTHER axis p (a transposed / permuted view): tile the
