@@ -79,6 +79,50 @@ __global__ __launch_bounds__(BLOCK) void copy_stride(const f4* __restrict__ a, f
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), o + i);
 }
 
+// persistent, prefetch TWO vectors ahead
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void prefetch2(const f4* __restrict__ a, float s, f4* __restrict__ o, size_t nvec) {
+    const double* tab = stage_table();
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nvec) return;
+    f4 c0[1] = {__builtin_nontemporal_load(a + i)};
+    f4 c1[1];
+    bool have1 = i + stride < nvec;
+    if (have1) c1[0] = __builtin_nontemporal_load(a + i + stride);
+    for (;;) {
+        const size_t n2 = i + 2 * stride;
+        const bool have2 = n2 < nvec;
+        f4 c2[1];
+        if (have2) c2[0] = __builtin_nontemporal_load(a + n2);
+        f4 r[1];
+        pow_vecs<1>(tab, c0, s, r);
+        __builtin_nontemporal_store(r[0], o + i);
+        if (!have1) break;
+        c0[0] = c1[0]; c1[0] = c2[0]; have1 = have2; i += stride;
+    }
+}
+// persistent, two vectors per iteration (evaluated together: 8 elements side by side), prefetch the next pair
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void prefetch_pair(const f4* __restrict__ a, float s, f4* __restrict__ o, size_t nvec) {
+    const double* tab = stage_table();
+    const size_t stride = (size_t)gridDim.x * BLOCK * 2;
+    size_t i = (size_t)blockIdx.x * BLOCK * 2 + threadIdx.x;   // pair: i, i + BLOCK   (nvec multiple of 2*BLOCK assumed)
+    if (i >= nvec) return;
+    f4 cur[2] = {__builtin_nontemporal_load(a + i), __builtin_nontemporal_load(a + i + BLOCK)};
+    for (;;) {
+        const size_t nx = i + stride;
+        const bool more = nx < nvec;
+        f4 nxt[2];
+        if (more) { nxt[0] = __builtin_nontemporal_load(a + nx); nxt[1] = __builtin_nontemporal_load(a + nx + BLOCK); }
+        f4 r[2];
+        pow_vecs<2>(tab, cur, s, r);
+        __builtin_nontemporal_store(r[0], o + i); __builtin_nontemporal_store(r[1], o + i + BLOCK);
+        if (!more) break;
+        cur[0] = nxt[0]; cur[1] = nxt[1]; i = nx;
+    }
+}
+
 __global__ void init_k(float* p, size_t n) { for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.01f + (float)((i * 2654435761u) & 0xffffff) * (99.99f / 16777216.0f); }
 
 template <typename F> double timeit(F launch) {
@@ -127,6 +171,15 @@ int main() {
             printf("B2B x100 %-40s %.4f ms/launch %8.1f GB/s\n", name, ms / 100, 8.0 * n / (ms / 100) * 1e-6);
         };
         b2b("prefetch b512 x32 (nt ld+st)", [&] { prefetch<512><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch2 b512 x32", [&] { prefetch2<512><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch2 b512 x8", [&] { prefetch2<512><<<256 * 8, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch2 b256 x16", [&] { prefetch2<256><<<256 * 16, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch2 b256 x64", [&] { prefetch2<256><<<256 * 64, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch_pair b512 x16", [&] { prefetch_pair<512><<<256 * 16, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch_pair b256 x16", [&] { prefetch_pair<256><<<256 * 16, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch_pair b256 x32", [&] { prefetch_pair<256><<<256 * 32, 256>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch b1024 x16", [&] { prefetch<1024><<<256 * 16, 1024>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch b512 x64", [&] { prefetch<512><<<256 * 64, 512>>>(av, 2.5f, ov, nvec); });
         b2b("prefetch b512 x8", [&] { prefetch<512><<<256 * 8, 512>>>(av, 2.5f, ov, nvec); });
         b2b("prefetch b512 x4", [&] { prefetch<512><<<256 * 4, 512>>>(av, 2.5f, ov, nvec); });
         b2b("prefetch b256 x16", [&] { prefetch<256><<<256 * 16, 256>>>(av, 2.5f, ov, nvec); });
