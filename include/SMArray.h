@@ -231,19 +231,16 @@ public:
         assert(numberOfRepeats >= 1);
         const std::size_t r = static_cast<std::size_t>(numberOfRepeats);
         if constexpr (hip::dtype_of<T>::id >= 0) {
-            if (_shape.size() + 1 <= MAX_NDIM) {
-                std::vector<std::size_t> vshape = _shape, vstrides = _strides;
-                vshape.push_back(r);
-                vstrides.push_back(0);
-                return gather(vshape, vstrides, {totalSize * r});
-            }
+            if (!is_dense()) return contiguous().repeat(numberOfRepeats);
+            return gather({totalSize, r}, {1, 0}, {totalSize * r});  // a dense array seen as (N, r) with strides (1, 0)
+        } else {  // element types without kernels (std::complex): plain host data movement
+            std::vector<T> flat(totalSize ? totalSize : 1);
+            copy_dense_to(flat.data());
+            T *out = new T[totalSize * r ? totalSize * r : 1];
+            for (std::size_t i = 0, o = 0; i < totalSize; ++i)
+                for (std::size_t k = 0; k < r; ++k) out[o++] = flat[i];
+            return SMArray(out, {totalSize * r});
         }
-        std::vector<T> flat(totalSize ? totalSize : 1);
-        copy_dense_to(flat.data());
-        T *out = new T[totalSize * r ? totalSize * r : 1];
-        for (std::size_t i = 0, o = 0; i < totalSize; ++i)
-            for (std::size_t k = 0; k < r; ++k) out[o++] = flat[i];
-        return SMArray(out, {totalSize * r});
     }
 
     // Repeat along one axis: shape[axis] *= numberOfRepeats (a stride-0 axis inserted after `axis`).
@@ -253,28 +250,26 @@ public:
         const std::size_t r = static_cast<std::size_t>(numberOfRepeats);
         std::vector<std::size_t> newShape = _shape;
         newShape[axis] *= r;
-        if constexpr (hip::dtype_of<T>::id >= 0) {
-            if (_shape.size() + 1 <= MAX_NDIM) {
-                std::vector<std::size_t> vshape = _shape, vstrides = _strides;
-                vshape.insert(vshape.begin() + axis + 1, r);
-                vstrides.insert(vstrides.begin() + axis + 1, 0);
-                return gather(vshape, vstrides, std::move(newShape));
-            }
-        }
-        std::vector<T> flat(totalSize ? totalSize : 1);
-        copy_dense_to(flat.data());
         std::size_t inner = 1, outer = 1;
         for (std::size_t i = axis + 1; i < ndim; ++i) inner *= _shape[i];
         for (int i = 0; i < axis; ++i) outer *= _shape[i];
-        T *out = new T[calculateTotalSize(newShape) ? calculateTotalSize(newShape) : 1];
-        T *dst = out;
-        for (std::size_t o = 0; o < outer; ++o)
-            for (std::size_t j = 0; j < _shape[axis]; ++j)
-                for (std::size_t k = 0; k < r; ++k) {
-                    std::memcpy(dst, flat.data() + (o * _shape[axis] + j) * inner, inner * sizeof(T));
-                    dst += inner;
-                }
-        return SMArray(out, std::move(newShape));
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            if (!is_dense()) return contiguous().repeat(numberOfRepeats, axis);
+            // dense: (outer, d, inner) seen as (outer, d, r, inner) with strides (d*inner, inner, 0, 1) -- rank 4 whatever ndim is
+            return gather({outer, _shape[axis], r, inner}, {_shape[axis] * inner, inner, 0, 1}, std::move(newShape));
+        } else {
+            std::vector<T> flat(totalSize ? totalSize : 1);
+            copy_dense_to(flat.data());
+            T *out = new T[calculateTotalSize(newShape) ? calculateTotalSize(newShape) : 1];
+            T *dst = out;
+            for (std::size_t o = 0; o < outer; ++o)
+                for (std::size_t j = 0; j < _shape[axis]; ++j)
+                    for (std::size_t k = 0; k < r; ++k) {
+                        std::memcpy(dst, flat.data() + (o * _shape[axis] + j) * inner, inner * sizeof(T));
+                        dst += inner;
+                    }
+            return SMArray(out, std::move(newShape));
+        }
     }
 
     // Dot product over all elements (reference SMArray.h:213-215 -> dot_product<T>).

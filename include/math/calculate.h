@@ -23,10 +23,7 @@
 // User-defined Ops: SM_DEVICE_OP(MyOp, "(a + b) * 2") (math/ops.h) gives an Op its device form -- the
 // expression is compiled for gfx950 with hipRTC on first use -- and it then runs through the same
 // entry points as the built-ins.  An Op with no device functor (sm::hip::device_op<Op>::available == false)
-// is refused with a std::runtime_error naming it.  Defining
-// SM_ENABLE_HOST_PLUGIN_OPS before including this header instead runs such an
-// Op's own `apply` in a plain host loop -- the plugin's code executing where it
-// was written for; the five built-in Ops can never take that route.
+// is refused with a std::runtime_error naming it: there is no host arithmetic path in this library.
 #pragma once
 
 #include <cstddef>
@@ -98,9 +95,8 @@ template <typename T, typename Op>
 [[noreturn]] void refuse_host_op() {
     throw std::runtime_error(std::string("simpleMath/MI355X: Op '") + typeid(Op).name() +
                              "' has no device functor (sm::hip::device_op<Op>::available == false) or its element type has no "
-                             "kernels; there is no silent CPU fallback. Give the Op its device form with "
-                             "SM_DEVICE_OP(MyOp, \"<HIP expression in a and b>\") (math/ops.h), or define "
-                             "SM_ENABLE_HOST_PLUGIN_OPS to run its own apply() on the host.");
+                             "kernels; there is no CPU fallback. Give the Op its device form with "
+                             "SM_DEVICE_OP(MyOp, \"<HIP expression in a and b>\") (math/ops.h).");
 }
 
 }  // namespace sm::hip
@@ -124,22 +120,8 @@ void element_wise_op(const T *a, const std::vector<std::size_t> &stride_a, const
                                              dr.template as<T>(), shape);
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
-#if defined(SM_ENABLE_HOST_PLUGIN_OPS)
-        // a user plugin without a device functor: its own apply(), where it was written for
-        std::vector<std::size_t> idx(shape.size(), 0);
-        for (std::size_t linear = 0; linear < n; ++linear) {
-            std::size_t oa = 0, ob = 0;
-            for (std::size_t k = 0; k < shape.size(); ++k) { oa += idx[k] * stride_a[k]; ob += idx[k] * stride_b[k]; }
-            result[linear] = Operation::apply(a[oa], b[ob]);
-            for (std::size_t k = shape.size(); k-- > 0;) {
-                if (++idx[k] < shape[k]) break;
-                idx[k] = 0;
-            }
-        }
-#else
         (void)a; (void)stride_a; (void)b; (void)stride_b; (void)n; (void)result; (void)shape;
         refuse_host_op<T, Operation>();
-#endif
     }
 }
 
@@ -154,12 +136,8 @@ void handle_contiguous_arrays(const T *a, const T *b, T *result, std::size_t n) 
         check(smhip_contiguous(device_op<Operation>::id(), dtype_of<T>::id, da.get(), db.get(), dr.get(), n));
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
-#if defined(SM_ENABLE_HOST_PLUGIN_OPS)
-        for (std::size_t i = 0; i < n; ++i) result[i] = Operation::apply(a[i], b[i]);
-#else
         (void)a; (void)b; (void)result; (void)n;
         refuse_host_op<T, Operation>();
-#endif
     }
 }
 
@@ -173,11 +151,7 @@ void array_scalar_op(const T *a, T value, const std::size_t n, T *result) {
         array_scalar_op_device<T, Operation>(da.template as<T>(), value, n, dr.template as<T>());
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
-#if defined(SM_ENABLE_HOST_PLUGIN_OPS)
-        for (std::size_t i = 0; i < n; ++i) result[i] = Operation::apply(a[i], value);
-#else
         (void)a; (void)value; (void)n; (void)result;
         refuse_host_op<T, Operation>();
-#endif
     }
 }

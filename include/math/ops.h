@@ -8,9 +8,8 @@
 // `apply` stays the definition of what the Op means.  What changes is where the
 // loop runs: sm::hip::device_op<Op>::id names the functor libsmhip's gfx950
 // kernels instantiate for it (simplemath_amd/csrc/ops.hip.h).  The five
-// built-in Ops always run on the device; a user Op without a device functor is
-// refused loudly unless the build opts into running it on the host (see
-// math/calculate.h, SM_ENABLE_HOST_PLUGIN_OPS).
+// built-in Ops always run on the device; a user Op gets its device form from
+// SM_DEVICE_OP (below) and is refused loudly without one -- nothing computes on the host.
 #pragma once
 
 #include <cmath>
