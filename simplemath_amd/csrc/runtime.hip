@@ -29,6 +29,10 @@ struct ThreadState {
     std::string error;
     double *scratch[kMaxDevices] = {};
     size_t scratch_count[kMaxDevices] = {};
+    // pinned staging ring for small uploads (per thread and device): copy in, enqueue, return
+    unsigned char *ring[kMaxDevices] = {};
+    size_t ring_head[kMaxDevices] = {};
+    hipStream_t ring_stream[kMaxDevices] = {};
 };
 thread_local ThreadState tls;
 
@@ -274,6 +278,25 @@ int smhip_upload(void *dst, const void *src_host, size_t bytes) {
     if (bytes == 0) return SMHIP_OK;
     if (!dst || !src_host) return fail(SMHIP_ERR_INVALID, "upload: null");
     SMHIP_ACQUIRE(s);
+    // Small uploads (the reference's simple_check builds 25-element arrays per iteration) go through a
+    // pinned ring: the caller's buffer is free again on return and nothing waits for the GPU.  The
+    // stream is drained only when the ring wraps (every kRingBytes of small uploads) or changes stream.
+    constexpr size_t kRingBytes = 4u << 20, kSmall = 64u << 10;
+    if (bytes <= kSmall) {
+        const int d = tls.device;
+        if (!tls.ring[d]) SMHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&tls.ring[d]), kRingBytes, hipHostMallocDefault));
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (tls.ring_head[d] + need > kRingBytes || tls.ring_stream[d] != s) {
+            if (tls.ring_stream[d]) SMHIP_TRY(hipStreamSynchronize(tls.ring_stream[d]));
+            tls.ring_head[d] = 0;
+            tls.ring_stream[d] = s;
+        }
+        unsigned char *slot = tls.ring[d] + tls.ring_head[d];
+        tls.ring_head[d] += need;
+        memcpy(slot, src_host, bytes);
+        SMHIP_TRY(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, s));
+        return SMHIP_OK;
+    }
     SMHIP_TRY(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, s));
     SMHIP_TRY(hipStreamSynchronize(s));  // pageable source: the caller may reuse it at once
     return SMHIP_OK;
