@@ -74,6 +74,7 @@ HOST_PROGRAMS = {
     # output (under simplemath_amd/bin/)  ->  source
     "test_reference_suite": os.path.join(ROOT, "tests", "cpp", "test_reference_suite.cpp"),
     "pow_host_check": os.path.join(ROOT, "tests", "cpp", "pow_host_check.cpp"),
+    "pow64_host_check": os.path.join(ROOT, "tests", "cpp", "pow64_host_check.cpp"),
     "benchmark_add": os.path.join(PKG, "benchmark", "add.cpp"),
     "benchmark_pow": os.path.join(PKG, "benchmark", "pow.cpp"),
 }
@@ -88,14 +89,14 @@ def build_host_programs(force: bool = False) -> dict:
     hdrs = []
     for dp, _, fs in os.walk(inc):
         hdrs += [os.path.join(dp, f) for f in fs]
-    hdrs += [os.path.join(CSRC, "sm_pow.h"), os.path.join(PKG, "benchmark", "minibench.h")]
+    hdrs += [os.path.join(CSRC, "sm_pow.h"), os.path.join(CSRC, "sm_pow64.h"), os.path.join(PKG, "benchmark", "minibench.h")]
     out = {}
     for name, src in HOST_PROGRAMS.items():
         exe = os.path.join(BINDIR, name)
         out[name] = exe
         if not (force or _newer(exe, [src] + hdrs)):
             continue
-        if name == "pow_host_check":  # pure host check of the pow algorithm: no GPU library involved
+        if name in ("pow_host_check", "pow64_host_check"):  # pure host check of the pow algorithm: no GPU library involved
             cmd = [CXX, "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", f"-I{CSRC}", src, "-o", exe]
         else:
             cmd = [CXX, "-std=c++20", "-O2", "-Wall", "-Wextra", f"-I{inc}", f"-I{os.path.join(PKG, 'benchmark')}", src, "-o", exe,

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "sm_pow.h"
+#include "sm_pow64.h"
 
 namespace smhip {
 namespace dev {
@@ -104,8 +105,11 @@ template <> struct PowOp<int32_t> { static __device__ __forceinline__ int32_t ap
 template <> struct PowOp<int64_t> { static __device__ __forceinline__ int64_t apply(int64_t a, int64_t b) { return powi<int64_t>(a, b); } };
 // PowOp<float>::apply = std::pow (pow.h:8-10) -> in-register fp64 exp2/log2 chain.
 template <> struct PowOp<float> { static __device__ __forceinline__ float apply(float a, float b) { return smpow::powf(a, b); } };
-// f64 pow is a "next" row: ROCm's device libm keeps the API whole meanwhile.
-template <> struct PowOp<double> { static __device__ __forceinline__ double apply(double a, double b) { return ::pow(a, b); } };
+// PowOp<double>::apply = std::pow -> double-double log / table exp (sm_pow64.h); this scalar form reads
+// the tables from constant memory, the vector kernels from their LDS copies (OpCtx below).
+template <> struct PowOp<double> {
+    static __device__ __forceinline__ double apply(double a, double b) { return smpow64::pow(a, b, smpow64::kLogTab, smpow64::kExpTab); }
+};
 
 // Per-workgroup state an Op may need.  Kernels create one and call init() at
 // their top, before any early exit (init may contain a barrier).  Only
@@ -125,6 +129,18 @@ template <> struct OpCtx<PowOp<float>> {
     }
 };
 
+template <> struct OpCtx<PowOp<double>> {
+    const double *logtab, *exptab;
+    __device__ __forceinline__ void init() {
+        __shared__ __attribute__((aligned(16))) double lds_tab[smpow64::kLogTabDoubles + smpow64::kExpTabDoubles];
+        for (int i = threadIdx.x; i < smpow64::kLogTabDoubles; i += blockDim.x) lds_tab[i] = smpow64::kLogTab[i];
+        for (int i = threadIdx.x; i < smpow64::kExpTabDoubles; i += blockDim.x) lds_tab[smpow64::kLogTabDoubles + i] = smpow64::kExpTab[i];
+        __syncthreads();
+        logtab = lds_tab;
+        exptab = lds_tab + smpow64::kLogTabDoubles;
+    }
+};
+
 // apply_simd's role: the Op across W independent elements held in registers.
 // PowOp<float> evaluates them side by side (one constant per polynomial step,
 // no branches); every other Op is one instruction per element.
@@ -132,6 +148,9 @@ template <typename Op, typename T, int W>
 __device__ __forceinline__ void apply_n(const OpCtx<Op> &ctx, const T (&a)[W], const T (&b)[W], T (&r)[W]) {
     if constexpr (std::is_same<Op, PowOp<float>>::value) {
         smpow::pow_n<W>(a, b, r, ctx.tab);
+    } else if constexpr (std::is_same<Op, PowOp<double>>::value) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) r[i] = smpow64::pow(a[i], b[i], ctx.logtab, ctx.exptab);
     } else {
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);

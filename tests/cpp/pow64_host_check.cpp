@@ -1,0 +1,53 @@
+// Host check of simplemath_amd/csrc/sm_pow64.h: max ULP distance from glibc pow (< 1 ULP itself) over a
+// dense sweep incl. subnormals, values near 1 with huge exponents, results near overflow / underflow; the
+// special-case lattice against libm.  Prints "max_ulp <n> over <count>" and "lattice_mismatches <n>".
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+#include "sm_pow64.h"
+
+static int64_t ord(double f) { int64_t u; memcpy(&u, &f, 8); return u < 0 ? std::numeric_limits<int64_t>::min() - u : u; }
+static uint64_t mix(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31; return x; }
+
+int main() {
+    const double ys[] = {2.5, 2.0, 3.0, 0.5, -1.0, -2.5, 1.5, 7.0, -3.0, 1.0 / 3, 10.25, 100.0, -100.0, 1e-3, 37.75, -0.001, 1e6, -1e6,
+                         4503599627370496.0, 1.0000000000000002, 0.9999999999999999, 123456.7, 700.0, -700.0, 1e-300, 0.1};
+    int64_t worst = 0; uint64_t count = 0; double wx = 0, wy = 0;
+    for (double y : ys) {
+        for (uint64_t i = 0; i < 150000; ++i) {
+            uint64_t h = mix(i * 0x9E3779B97F4A7C15ULL + (uint64_t)(int64_t)(y * 1000));
+            double x;
+            switch (i % 5) {
+                case 0: { uint64_t u = h & 0x7fffffffffffffffULL; memcpy(&x, &u, 8); break; }                 // any positive bit pattern
+                case 1: x = 0.01 + (double)(h >> 11) * 0x1.0p-53 * 99.99; break;                             // config-4 range
+                case 2: x = 1.0 + ((double)(h >> 11) * 0x1.0p-53 - 0.5) * 1e-3; break;                       // near 1
+                case 3: { uint64_t u = h & 0x000fffffffffffffULL; memcpy(&x, &u, 8); break; }                 // subnormal
+                default: x = std::exp2((double)((int64_t)(h % 2000) - 1000) / 10.0) * (1.0 + (double)(h >> 40) * 0x1p-24); break;
+            }
+            if (!(x == x) || std::isinf(x)) continue;
+            const double got = smpow64::pow(x, y, smpow64::kLogTab, smpow64::kExpTab), want = std::pow(x, y);
+            int64_t d = ord(got) - ord(want); if (d < 0) d = -d;
+            if (d > worst) { worst = d; wx = x; wy = y; }
+            ++count;
+        }
+    }
+    printf("max_ulp %lld over %llu (x=%a y=%a)\n", (long long)worst, (unsigned long long)count, wx, wy);
+    const double inf = std::numeric_limits<double>::infinity(), nan = std::numeric_limits<double>::quiet_NaN();
+    const double sp[] = {0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 0.5, -0.5, 2.0, -2.0, 3.0, -3.0, 4.0, -4.0, 5e-324, -5e-324, 1.7976931348623157e308,
+                         -1.7976931348623157e308, 1.5, -1.5, 4503599627370496.0, 4503599627370497.0, 9007199254740992.0, 9007199254740994.0,
+                         -4503599627370497.0, 1e10, -1e10, 0.9999999999999999, 1.0000000000000002, -0.9999999999999999, -1.0000000000000002};
+    int bad = 0;
+    for (double x : sp) for (double y : sp) {
+        const double got = smpow64::pow(x, y, smpow64::kLogTab, smpow64::kExpTab), want = std::pow(x, y);
+        int64_t d = ord(got) - ord(want); if (d < 0) d = -d;
+        const bool ok = (got != got && want != want) || (ord(got) == ord(want) && std::signbit(got) == std::signbit(want)) ||
+                        (d <= 1 && std::isfinite(want) && want != 0.0);
+        if (!ok) { ++bad; printf("lattice x=%a y=%a got=%a want=%a\n", x, y, got, want); }
+    }
+    printf("lattice_mismatches %d\n", bad);
+    return 0;
+}

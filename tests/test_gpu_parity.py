@@ -157,8 +157,6 @@ def test_golden_powf(smhip):
 @pytest.mark.parametrize("dt", ["f32", "f64", "i32", "i64"])
 @pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "pow"])
 def test_contiguous_vs_oracle(smhip, oracle, dt, op):
-    if op == "pow" and dt == "f64":
-        pytest.skip("f64 pow is a next-row item (device libm stand-in); covered loosely below")
     for n in (1, 3, 4, 5, 257, 4096, 100003, 1 << 20):
         a = gen.gen(DT[dt], n, 100 + n, "mixed")
         kind_b = "nonzero" if (op == "div" and dt[0] == "i") else "mixed"
@@ -170,7 +168,9 @@ def test_contiguous_vs_oracle(smhip, oracle, dt, op):
                 a, b = gen.gen(DT[dt], n, 100 + n, "positive"), gen.gen(DT[dt], n, 200 + n, "uniform")
         got = smhip.contiguous(sma.OPS[op], smhip.to_device(a), smhip.to_device(b)).numpy()
         want = oracle.contiguous(orc.OPS[op], a, b)
-        if op == "pow" and dt == "f32":
+        if op == "pow" and dt == "f64":
+            assert orc.ulp_diff_f64(got, want).max() <= 1  # vs glibc pow, itself < 1 ULP
+        elif op == "pow" and dt == "f32":
             with np.errstate(all="ignore"):
                 exact = np.power(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
             assert orc.ulp_diff_f32(got, exact).max() <= POW_ULP
@@ -179,10 +179,18 @@ def test_contiguous_vs_oracle(smhip, oracle, dt, op):
             util.assert_same_bits(got, want, f"{dt} {op} n={n}")
 
 
-def test_f64_pow_loose(smhip, oracle):
-    a = gen.gen(np.float64, 4096, 1, "positive")
-    got = smhip.array_scalar(sma.OP_POW, smhip.to_device(a), 2.5).numpy()
-    assert orc.ulp_diff_f64(got, oracle.array_scalar(orc.POW, a, 2.5)).max() <= 4
+def test_f64_pow(smhip, oracle):
+    """PowOp<double> (sm_pow64.h): within 1 ULP of glibc pow (the reference's arithmetic) incl. specials."""
+    for kind, n in (("positive", 100003), ("mixed", 4096), ("wide", 65536)):
+        a = gen.gen(np.float64, n, 1, kind)
+        for e in (2.5, -1.5, 0.5, 3.0, 700.0, -0.001, 0.0, float("inf"), float("nan")):
+            got = smhip.array_scalar(sma.OP_POW, smhip.to_device(a), e).numpy()
+            want = oracle.array_scalar(orc.POW, a, e)
+            assert orc.ulp_diff_f64(got, want).max() <= 1, (kind, e)
+    b = gen.gen(np.float64, 4096, 2, "uniform") * 10
+    a = gen.gen(np.float64, 4096, 3, "positive")
+    got = smhip.contiguous(sma.OP_POW, smhip.to_device(a), smhip.to_device(b)).numpy()
+    assert orc.ulp_diff_f64(got, oracle.contiguous(orc.POW, a, b)).max() <= 1
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "i32", "i64"])

@@ -15,3 +15,14 @@ def test_pow_algorithm_on_host():
     assert m and int(m.group(2)) > 8_000_000
     assert int(m.group(1)) <= 1, out          # parity bar is 4 ULP; the fp64 chain achieves 1
     assert "lattice_mismatches 0" in out, out
+
+
+def test_pow64_algorithm_on_host():
+    """sm_pow64.h (double pow: double-double log, table exp) against glibc pow over 3.9 M pairs + the lattice."""
+    from simplemath_amd import build
+    exe = build.build_host_programs()["pow64_host_check"]
+    out = subprocess.run([exe], capture_output=True, text=True, check=True, timeout=300).stdout
+    m = re.search(r"max_ulp (\d+) over (\d+)", out)
+    assert m and int(m.group(2)) > 3_500_000
+    assert int(m.group(1)) <= 1, out
+    assert "lattice_mismatches 0" in out, out
