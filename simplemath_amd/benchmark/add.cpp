@@ -6,6 +6,8 @@
 // 2's size (N = 2^28) with the achieved HBM rate.
 #include <sm.h>
 
+#include <vector>
+
 #include "minibench.h"
 
 int main() {
@@ -44,6 +46,20 @@ int main() {
         char extra[96];
         std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s (12 B/elem)", n / r.ns_per_iter, 12.0 * n / r.ns_per_iter);
         print(r, extra);
+    }
+    {
+        // The host-pointer loop template (include/math/calculate.h), i.e. the boundary handing over HOST buffers:
+        // upload a and b, run the kernel, download the result -- the PCIe-inclusive rate DESIGN.md quotes.
+        const std::size_t n = std::size_t(1) << 24;
+        std::vector<float> a(n, 1.0f), b(n, 2.0f), r(n);
+        auto res = run("host_pointer_check/2^24", [&] {
+            handle_contiguous_arrays<float, AddOp<float>>(a.data(), b.data(), r.data(), n);
+            DoNotOptimize(r[n / 2]);
+            ClobberMemory();
+        }, sync, 10);
+        char extra[96];
+        std::snprintf(extra, sizeof extra, "%.2f Gelem/s  %.1f GB/s over PCIe (12 B/elem)", n / res.ns_per_iter, 12.0 * n / res.ns_per_iter);
+        print(res, extra);
     }
     return 0;
 }
