@@ -100,7 +100,7 @@ def build_host_programs(force: bool = False) -> dict:
             cmd = [CXX, "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", f"-I{CSRC}", src, "-o", exe]
         else:
             cmd = [CXX, "-std=c++20", "-O2", "-Wall", "-Wextra", f"-I{inc}", f"-I{os.path.join(PKG, 'benchmark')}", src, "-o", exe,
-                   f"-L{LIBDIR}", "-lsmhip", "-Wl,-rpath,$ORIGIN/../lib"]
+                   f"-L{LIBDIR}", "-lsmhip", "-pthread", "-Wl,-rpath,$ORIGIN/../lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

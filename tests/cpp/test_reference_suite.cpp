@@ -17,6 +17,8 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
+#include <vector>
 
 static int g_failures = 0, g_checks = 0;
 static const char *g_test = "";
@@ -404,6 +406,29 @@ TEST(FusionHook) {
     auto rb = sm::fused<AddOp<float>, MultiplyOp<float>>(m, row, m);  // broadcast: evaluated as two calls, same values
     CHECK_EQ(rb(1, 1), (4.0f + 20.0f) * 4.0f);
 }
+TEST(ThreadsShareTheLibrary) {
+    // the C ABI is callable from any host thread (per-thread device/stream selection, locked allocator)
+    std::vector<std::thread> pool;
+    std::vector<int> ok(6, 0);
+    for (int t = 0; t < 6; ++t)
+        pool.emplace_back([t, &ok] {
+            try {
+                auto a = sm::ones<float>(200000 + t) * float(t + 1);
+                auto b = sm::ones<float>(200000 + t) * 2.0f;
+                bool good = true;
+                for (int it = 0; it < 20; ++it) {
+                    auto c = (a + b) * b - a;  // (t+1+2)*2 - (t+1) = t + 5
+                    good &= sm::sum(c) == double(t + 5) * (200000 + t);
+                    good &= (a % b) == float(2 * (t + 1)) * (200000 + t);
+                }
+                ok[t] = good;
+            } catch (const std::exception &e) {
+                std::printf("thread %d threw: %s\n", t, e.what());
+            }
+        });
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < 6; ++t) CHECK(ok[t]);
+}
 TEST(HostPointerLoops) {
     // calling the loop templates directly with host pointers, as the README's recipe does
     float a[5] = {1, 2, 3, 4, 5}, b[5] = {10, 20, 30, 40, 50}, r[5] = {};
@@ -462,7 +487,7 @@ int main() {
                          run_DivisionBySelf, run_ScalarPow, run_OneDimensionalPow, run_TwoDimensionalPow, run_NonSquareShape,
                          run_TestLargeArrays, run_TestLargeArraysWithNegatives, run_NegativeExponent_disabled_in_reference,
                          run_TestLargeArraysDifferentValues_disabled_in_reference, run_ReadmeExample, run_BroadcastError, run_DotProduct,
-                         run_ComplexDot, run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_HostPointerLoops, run_PluginWithDeviceExpression,
+                         run_ComplexDot, run_ScalarOps, run_Residency, run_Repeat, run_FusionHook, run_ThreadsShareTheLibrary, run_HostPointerLoops, run_PluginWithDeviceExpression,
                          run_PluginWithoutDeviceFunctorIsRefused};
     int n = 0;
     for (auto t : tests) {
