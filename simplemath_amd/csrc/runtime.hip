@@ -44,22 +44,78 @@ int g_cus[kMaxDevices] = {};
 int g_device_count = -1;
 
 // ---------------------------------------------------------------- the pool
-// Size-class free lists per device.  Classes: powers of two from 256 B up to
-// 2 MiB, then multiples of 2 MiB -- so a freed 1 GiB operand buffer is reused
-// as-is by the next same-sized result, which is what turns the reference's
-// per-operator `new T[n]` + first-touch page faults into a pointer pop.
-struct Block { size_t cls; int device; hipStream_t last_stream; };
-std::unordered_map<void *, Block> g_live;                       // allocated, handed out
-std::map<std::pair<int, size_t>, std::vector<std::pair<void *, hipStream_t>>> g_free;  // cached
+// Two tiers, both per device:
+//   small (< 1 MiB)  size-class free lists (powers of two from 256 B); each block is its own hipMalloc.
+//   large (>= 1 MiB) carved, 2 MiB-aligned and first-fit, out of ARENAS -- single hipMalloc'd slabs of
+//                    max(4 x request, 256 MiB) (a request above 4 GiB gets a slab of its own size).
+// Why arenas: (1) a freed 1 GiB operand buffer is reused as-is by the next same-sized result, which turns
+// the reference's per-operator `new T[n]` + first-touch page faults (SMArray.h:219) into a pointer bump;
+// (2) placement.  The 2R+1W stream's rate follows the RELATIVE physical placement of its three buffers:
+// three separate hipMallocs land anywhere between 6.27 and 6.66 TB/s from one process to the next, three
+// carvings of one slab are at 6.49-6.51 TB/s every time (profiles/r01_placement_notes.txt).
+// Stream-ordered reuse: every free extent remembers the stream its last owner worked on; handing it to a
+// different stream waits for that stream first.
+constexpr size_t kLargeMin = (size_t)1 << 20, kLargeAlign = (size_t)2 << 20;
+constexpr size_t kArenaFloor = (size_t)256 << 20, kArenaSolo = (size_t)4 << 30;
+hipStream_t const kMixedStreams = reinterpret_cast<hipStream_t>(~(uintptr_t)0);  // extent merged from owners on different streams
+
+struct Extent { size_t off, size; hipStream_t stream; };
+struct Arena {
+    char *base = nullptr;
+    size_t size = 0, used = 0;
+    int device = 0;
+    std::vector<Extent> free;  // sorted by offset, coalesced
+};
+struct Block { size_t cls; int device; Arena *arena; size_t off; };
+std::unordered_map<void *, Block> g_live;                                              // handed out
+std::map<std::pair<int, size_t>, std::vector<std::pair<void *, hipStream_t>>> g_free;  // small blocks, cached
+std::vector<Arena *> g_arenas;
 size_t g_bytes_live = 0, g_bytes_cached = 0;
 
 size_t size_class(size_t bytes) {
     if (bytes <= 256) return 256;
-    constexpr size_t big = (size_t)2 << 20;
-    if (bytes >= big) return (bytes + big - 1) / big * big;
+    if (bytes >= kLargeMin) return (bytes + kLargeAlign - 1) / kLargeAlign * kLargeAlign;
     size_t c = 256;
     while (c < bytes) c <<= 1;
     return c;
+}
+
+// First fit in this device's arenas.  Caller holds g_mutex.
+bool carve(int dev, size_t need, Arena **arena, size_t *off, hipStream_t *last) {
+    for (Arena *a : g_arenas) {
+        if (a->device != dev) continue;
+        for (size_t i = 0; i < a->free.size(); ++i) {
+            Extent &e = a->free[i];
+            if (e.size < need) continue;
+            *arena = a;
+            *off = e.off;
+            *last = e.stream;
+            if (e.size == need) a->free.erase(a->free.begin() + i);
+            else { e.off += need; e.size -= need; }
+            a->used += need;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Return [off, off + size) to its arena, merging with neighbours.  Caller holds g_mutex.
+void release(Arena *a, size_t off, size_t size, hipStream_t stream) {
+    size_t i = 0;
+    while (i < a->free.size() && a->free[i].off < off) ++i;
+    a->free.insert(a->free.begin() + i, Extent{off, size, stream});
+    auto merge = [&](size_t lo) {  // merge free[lo] and free[lo + 1] if adjacent
+        if (lo + 1 >= a->free.size()) return false;
+        Extent &x = a->free[lo], &y = a->free[lo + 1];
+        if (x.off + x.size != y.off) return false;
+        x.size += y.size;
+        if (x.stream != y.stream) x.stream = kMixedStreams;
+        a->free.erase(a->free.begin() + lo + 1);
+        return true;
+    };
+    merge(i);
+    if (i > 0) merge(i - 1);
+    a->used -= size;
 }
 
 }  // namespace
@@ -199,50 +255,89 @@ int smhip_alloc(void **dptr, size_t bytes) {
     const size_t cls = size_class(bytes);
     const int dev = tls.device;
     void *p = nullptr;
-    hipStream_t last = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        auto it = g_free.find({dev, cls});
-        if (it != g_free.end() && !it->second.empty()) {
-            p = it->second.back().first;
-            last = it->second.back().second;
-            it->second.pop_back();
-            g_bytes_cached -= cls;
+    hipStream_t last = s;
+    Arena *arena = nullptr;
+    size_t off = 0;
+    if (cls >= kLargeMin) {
+        bool found;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            found = carve(dev, cls, &arena, &off, &last);
         }
-    }
-    if (p) {
-        // stream-ordered reuse: work queued by the previous owner on another
-        // stream must drain before the new owner writes
-        if (last != s) SMHIP_TRY(hipStreamSynchronize(last));
+        if (!found) {
+            // a new slab: room for the request and the operands that usually come with it
+            size_t want = cls > kArenaSolo ? cls : (4 * cls > kArenaFloor ? 4 * cls : kArenaFloor);
+            void *base = nullptr;
+            hipError_t e = hipMalloc(&base, want);
+            if (e == hipErrorOutOfMemory && want > cls) {
+                (void)hipGetLastError();
+                want = cls;
+                e = hipMalloc(&base, want);
+            }
+            if (e == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                smhip_pool_trim();
+                e = hipMalloc(&base, want);
+            }
+            if (e != hipSuccess) return fail(SMHIP_ERR_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+            std::lock_guard<std::mutex> lock(g_mutex);
+            Arena *a = new Arena;
+            a->base = static_cast<char *>(base);
+            a->size = want;
+            a->device = dev;
+            a->free.push_back(Extent{0, want, s});
+            g_arenas.push_back(a);
+            g_bytes_cached += want;
+            found = carve(dev, cls, &arena, &off, &last);
+            if (!found) return fail(SMHIP_ERR_HIP, "pool: fresh arena could not satisfy %zu bytes", cls);
+        }
+        p = arena->base + off;
     } else {
-        hipError_t e = hipMalloc(&p, cls);
-        if (e == hipErrorOutOfMemory) {
-            (void)hipGetLastError();
-            smhip_pool_trim();
-            e = hipMalloc(&p, cls);
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            auto it = g_free.find({dev, cls});
+            if (it != g_free.end() && !it->second.empty()) {
+                p = it->second.back().first;
+                last = it->second.back().second;
+                it->second.pop_back();
+            }
         }
-        if (e != hipSuccess) return fail(SMHIP_ERR_HIP, "hipMalloc(%zu): %s", cls, hipGetErrorString(e));
+        if (!p) {
+            hipError_t e = hipMalloc(&p, cls);
+            if (e == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                smhip_pool_trim();
+                e = hipMalloc(&p, cls);
+            }
+            if (e != hipSuccess) return fail(SMHIP_ERR_HIP, "hipMalloc(%zu): %s", cls, hipGetErrorString(e));
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_bytes_cached += cls;
+        }
     }
+    // stream-ordered reuse: work queued by the previous owner on another stream must drain first
+    if (last == kMixedStreams) SMHIP_TRY(hipDeviceSynchronize());
+    else if (last != s) SMHIP_TRY(hipStreamSynchronize(last));
     std::lock_guard<std::mutex> lock(g_mutex);
-    g_live[p] = Block{cls, dev, s};
+    g_live[p] = Block{cls, dev, arena, off};
     g_bytes_live += cls;
+    g_bytes_cached -= cls;
     *dptr = p;
     return SMHIP_OK;
 }
 
 int smhip_free(void *dptr) {
     if (!dptr) return SMHIP_OK;
-    hipStream_t s = nullptr;
-    if (tls.use_user_stream) s = tls.user_stream;
     std::lock_guard<std::mutex> lock(g_mutex);
     auto it = g_live.find(dptr);
     if (it == g_live.end()) return fail(SMHIP_ERR_INVALID, "free: %p was not allocated by smhip_alloc", dptr);
     const Block b = it->second;
     g_live.erase(it);
     g_bytes_live -= b.cls;
-    if (!tls.use_user_stream) s = g_streams[b.device];
-    g_free[{b.device, b.cls}].push_back({dptr, s});
     g_bytes_cached += b.cls;
+    // the stream this thread's work (and so the block's last use) went to
+    hipStream_t s = tls.use_user_stream ? tls.user_stream : g_streams[b.device];
+    if (b.arena) release(b.arena, b.off, b.cls, s);
+    else g_free[{b.device, b.cls}].push_back({dptr, s});
     return SMHIP_OK;
 }
 
@@ -251,10 +346,23 @@ int smhip_pool_trim(void) {
     {
         std::lock_guard<std::mutex> lock(g_mutex);
         for (auto &kv : g_free) {
-            for (auto &e : kv.second) victims.push_back({kv.first.first, e.first});
+            for (auto &e : kv.second) {
+                victims.push_back({kv.first.first, e.first});
+                g_bytes_cached -= kv.first.second;
+            }
             kv.second.clear();
         }
-        g_bytes_cached = 0;
+        for (size_t i = 0; i < g_arenas.size();) {  // slabs nobody is using any more
+            Arena *a = g_arenas[i];
+            if (a->used == 0) {
+                victims.push_back({a->device, a->base});
+                g_bytes_cached -= a->size;
+                delete a;
+                g_arenas.erase(g_arenas.begin() + i);
+            } else {
+                ++i;
+            }
+        }
     }
     int cur = 0;
     (void)hipGetDevice(&cur);

@@ -8,6 +8,8 @@ Bars (BASELINE north_star): int32/int64 bit-exact; f32/f64 + - * / bit-exact
 compared); f32 pow within 4 ULP of the correctly rounded value (budget 2, measured 1);
 reductions against the fp64 oracle with the tolerance stated at each test.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -609,6 +611,52 @@ def test_int_division_definitions(smhip):
     b = np.array([2, 2, -2, -2, -1, 0, 0, 1], dtype=np.int32)
     got = smhip.contiguous(sma.OP_DIV, smhip.to_device(a), smhip.to_device(b)).numpy()
     assert got.tolist() == [3, -3, -3, 3, -2147483648, 0, 0, -2147483648]
+
+
+def test_pool_arenas_do_not_overlap(smhip):
+    """Large blocks are carved out of shared slabs: random alloc / free traffic must never hand out
+    overlapping ranges, extents must coalesce, and trimming must return empty slabs to the driver."""
+    import random
+    rnd = random.Random(7)
+    smhip.synchronize()
+    smhip.pool_trim()
+    base_use, _ = smhip.pool_stats()
+    live = {}  # ptr -> (nbytes, tag)
+    tag = 0
+    for step in range(300):
+        if live and (rnd.random() < 0.45 or len(live) > 24):
+            p = rnd.choice(list(live))
+            nbytes, t = live.pop(p)
+            host = np.empty(4, dtype=np.int32)
+            smhip.download(host, p)
+            assert (host == t).all(), "block was overwritten while live"
+            smhip.download(host, p + nbytes - 16)
+            assert (host == t).all(), "block tail was overwritten while live"
+            smhip.free(p)
+        else:
+            nbytes = rnd.choice([1 << 20, 3 << 20, (5 << 20) + 4096, 17 << 20, 64 << 20, 100 << 20, 257 << 20, 1000, 70000])
+            nbytes = (nbytes + 15) // 16 * 16
+            p = smhip.alloc(nbytes)
+            tag += 1
+            for q, sz in live.items():
+                assert p + nbytes <= q or q + sz[0] <= p, "overlapping allocations"
+            v = np.array([tag], dtype=np.int32)
+            smhip.c.smhip_fill(2, C.c_void_p(p), v.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes // 4))
+            live[p] = (nbytes, tag)
+    for p in list(live):
+        smhip.free(p)
+    smhip.synchronize()
+    use, cached_before = smhip.pool_stats()
+    assert use == base_use and cached_before > 0
+    smhip.pool_trim()
+    use, cached = smhip.pool_stats()
+    # empty slabs went back to the driver; one that still holds a live block of an earlier test keeps its free remainder
+    assert use == base_use and cached < cached_before and cached <= (1 << 30)
+    # three same-sized operands come out of one slab, back to back (what keeps the stream's rate stable)
+    a, b, c = smhip.alloc(64 << 20), smhip.alloc(64 << 20), smhip.alloc(64 << 20)
+    assert b - a == 64 << 20 and c - b == 64 << 20
+    for p in (a, b, c):
+        smhip.free(p)
 
 
 def test_pool_reuses_buffers(smhip):
