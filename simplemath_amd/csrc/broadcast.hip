@@ -585,17 +585,36 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
     return SMHIP_OK;
 }
 
-}  // namespace
 
-int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
-                     const int64_t *shape, int ndim, void *out, hipStream_t s) {
-    const Plan pl = normalise(shape, sa, sb, ndim);
-    if (pl.n == 0) return SMHIP_OK;
+// Kernels below index one launch with 32 bits.  A problem of >= 2^31 elements (a 288 GB device holds 2^36
+// floats) is cut along its outermost dimension into pieces under that limit -- each still gigabytes, so
+// the extra launches cost nothing -- and a piece of one outer index recurses into the next dimension.
+constexpr size_t kMaxLaunchElems = 0x7fffffffull;
+
+int launch_plan(int op, int dtype, const void *a, const void *b, void *out, const Plan &pl, hipStream_t s) {
     if (pl.ndim == 1) {
         // calculate.h:10-11's fast path, decided on the normalised problem
         if (pl.sa[0] == 1 && pl.sb[0] == 1) return launch_contiguous(op, dtype, a, b, out, pl.n, s);
         if (pl.sa[0] == 1 && pl.sb[0] == 0) return launch_array_devscalar(op, dtype, a, b, pl.n, out, false, s);
         if (pl.sa[0] == 0 && pl.sb[0] == 1) return launch_array_devscalar(op, dtype, b, a, pl.n, out, true, s);
+    }
+    if (pl.n >= kMaxLaunchElems) {
+        const size_t esz = dtype_size(dtype);
+        const size_t slice = pl.n / (size_t)pl.shape[0];  // elements per index of the outermost dimension
+        size_t per = slice >= kMaxLaunchElems ? 1 : (kMaxLaunchElems - 1) / slice;
+        if (per > 4) per &= ~(size_t)3;  // keep piece starts 16-byte aligned where the strides allow
+        int64_t shape[SMHIP_MAX_NDIM];
+        for (int d = 0; d < pl.ndim; ++d) shape[d] = pl.shape[d];
+        for (size_t i0 = 0; i0 < (size_t)pl.shape[0]; i0 += per) {
+            const size_t left = (size_t)pl.shape[0] - i0;
+            shape[0] = (int64_t)(left < per ? left : per);
+            const Plan sub = normalise(shape, pl.sa, pl.sb, pl.ndim);
+            const char *pa = static_cast<const char *>(a) + (int64_t)i0 * pl.sa[0] * (int64_t)esz;
+            const char *pb = static_cast<const char *>(b) + (int64_t)i0 * pl.sb[0] * (int64_t)esz;
+            char *po = static_cast<char *>(out) + i0 * slice * esz;
+            if (int rc = launch_plan(op, dtype, pa, pb, po, sub, s)) return rc;
+        }
+        return SMHIP_OK;
     }
 #define SMHIP_DISPATCH_OP(T)                                                                   \
     switch (op) {                                                                              \
@@ -615,6 +634,15 @@ int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const 
     }
 #undef SMHIP_DISPATCH_OP
     return fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype);
+}
+
+}  // namespace
+
+int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
+                     const int64_t *shape, int ndim, void *out, hipStream_t s) {
+    const Plan pl = normalise(shape, sa, sb, ndim);
+    if (pl.n == 0) return SMHIP_OK;
+    return launch_plan(op, dtype, a, b, out, pl, s);
 }
 
 }  // namespace smhip

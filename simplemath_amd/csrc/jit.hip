@@ -194,7 +194,23 @@ int jit_elementwise(int op, int dtype, const void *a, const int64_t *sa, const v
     }
     if (n == 0) return SMHIP_OK;
     if (dense) return jit_contiguous(op, dtype, a, b, out, n, s);
-    if (n >= 0x7fffffffull) return fail(SMHIP_ERR_UNSUPPORTED, "user op: broadcast form limited to < 2^31 elements");
+    if (n >= 0x7fffffffull) {  // cut along the first dimension with an extent: pieces of < 2^31 elements
+        int d = 0;
+        while (shape[d] == 1) ++d;
+        const size_t esz = dtype_size(dtype), slice = n / (size_t)shape[d];
+        const size_t per = slice >= 0x7fffffffull ? 1 : 0x7ffffffeull / slice;
+        int64_t sub[SMHIP_MAX_NDIM];
+        for (int i = 0; i < ndim; ++i) sub[i] = shape[i];
+        for (size_t i0 = 0; i0 < (size_t)shape[d]; i0 += per) {
+            const size_t left = (size_t)shape[d] - i0;
+            sub[d] = (int64_t)(left < per ? left : per);
+            if (int rc = jit_elementwise(op, dtype, static_cast<const char *>(a) + (int64_t)i0 * sa[d] * (int64_t)esz, sa,
+                                         static_cast<const char *>(b) + (int64_t)i0 * sb[d] * (int64_t)esz, sb, sub, ndim,
+                                         static_cast<char *>(out) + i0 * slice * esz, s))
+                return rc;
+        }
+        return SMHIP_OK;
+    }
     UserOp *u;
     if (int rc = lookup(op, dtype, &u)) return rc;
     GatherParamsHost p{};

@@ -561,6 +561,59 @@ def test_unsharded_config5_size_2p31(smhip, oracle):
     smhip.pool_trim()
 
 
+def test_broadcast_forms_past_2p31(smhip):
+    """Broadcast problems of more than 2^31 elements: the library cuts them along the outermost dimension into
+    launches of < 2^31 (row kernel, LDS-tile kernel for a transposed operand, gather kernel for a stride-2 view,
+    and a hipRTC user Op).  Blocks of rows around the cut (row 32764) and at the end are recomputed on the host from
+    the downloaded operands; add / mul are one IEEE operation, so numpy is bit-exact."""
+    R, Cc = (1 << 15) + 8, 1 << 16  # out: R x Cc = 2^31 + 2^19 elements
+    n = R * Cc
+    rows = (0, 32760, R - 8)
+
+    def block(dev, pitch, row0, nrows):  # rows [row0, row0+nrows) of a dense (?, pitch) device matrix
+        h = np.empty((nrows, pitch), dtype=np.float32)
+        smhip.download(h, dev.base_ptr + row0 * pitch * 4)
+        return h
+
+    B = smhip.uniform_f32(n, 91, -1.0, 1.0)
+    r = smhip.uniform_f32(Cc, 92, -1.0, 1.0)
+    B2 = sma.DeviceArray(smhip, B.base_ptr, np.float32, (R, Cc), (Cc, 1), 0, B._owner)
+    r2 = sma.DeviceArray(smhip, r.base_ptr, np.float32, (1, Cc), (Cc, 1), 0, r._owner)
+    hr = r.numpy().reshape(1, Cc)
+    # 1. row kernel
+    out = smhip.binary(sma.OP_MUL, B2, r2)
+    assert out.shape == (R, Cc)
+    for row0 in rows:
+        util.assert_same_bits(block(out, Cc, row0, 8), block(B, Cc, row0, 8) * hr, f"row kernel rows @{row0}")
+    del out
+    # 2. tile kernel: A stored (Cc, R), used transposed
+    A = smhip.uniform_f32(n, 93, -1.0, 1.0)
+    At = sma.DeviceArray(smhip, A.base_ptr, np.float32, (R, Cc), (1, R), 0, A._owner)
+    out = smhip.binary(sma.OP_ADD, At, B2)
+    c0 = 4096
+    hA = block(A, R, c0, 64)  # A_store[c0:c0+64, :]
+    for row0 in rows:
+        got = block(out, Cc, row0, 8)[:, c0:c0 + 64]
+        want = hA[:, row0:row0 + 8].T + block(B, Cc, row0, 8)[:, c0:c0 + 64]
+        util.assert_same_bits(got, want, f"tile kernel rows @{row0}")
+    del out, At
+    # 3. gather kernel: every second element of A's first n (as an (R, Cc/2) matrix of stride-2 elements), times a column
+    half = Cc // 2
+    Av = sma.DeviceArray(smhip, A.base_ptr, np.float32, (R, half, 2), (Cc, 2, 0), 1, A._owner)   # value repeated twice
+    Bv = sma.DeviceArray(smhip, B.base_ptr, np.float32, (R, half, 2), (Cc, 2, 1), 0, B._owner)   # B itself, dense
+    out = smhip.binary(sma.OP_MUL, Av, Bv)
+    assert out.size == n
+    user = smhip.register_op("a * b")
+    out_u = smhip.binary(user, Av, Bv)
+    for row0 in rows:
+        ha = block(A, Cc, row0, 8)
+        want = np.repeat(ha[:, 1::2], 2, axis=1) * block(B, Cc, row0, 8)
+        util.assert_same_bits(block(out, Cc, row0, 8), want, f"gather kernel rows @{row0}")
+        util.assert_same_bits(block(out_u, Cc, row0, 8), want, f"user-op gather rows @{row0}")
+    del out, out_u, A, B, Av, Bv, B2
+    smhip.pool_trim()
+
+
 # ------------------------------------------------------------------ 5. edge cases
 def test_empty_and_tiny(smhip):
     e = smhip.empty((0,), np.float32)
