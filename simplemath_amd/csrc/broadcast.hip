@@ -57,11 +57,12 @@ struct RowParams {
 
 // INNER_x: 1 = dense along the inner axis, 0 = broadcast along it.
 // CONST_x: operand has all outer strides zero -> identical for every row.
-// VEC: 16-byte accesses legal (extent, alignment and outer strides all multiples of W).
-template <typename T, typename Op, bool VEC, int INNER_A, int INNER_B, bool CONST_A, bool CONST_B, int TX, int ROWS>
+// Every lane owns one 16-byte slot of W elements of a row; accesses are element-aligned vectors (any base,
+// any pitch).  The last slot of a row whose extent is not a multiple of W is handled element by element.
+template <typename T, typename Op, int INNER_A, int INNER_B, bool CONST_A, bool CONST_B, int TX, int ROWS>
 __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                   RowParams p) {
-    constexpr int W = VEC ? VecTraits<T>::width : 1;
+    constexpr int W = VecTraits<T>::width;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int TY = 256 / TX;
     OpCtx<Op> ctx;
@@ -70,26 +71,34 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
     const uint32_t bx = blockIdx.x % p.grid_x, by = blockIdx.x / p.grid_x;
     const uint32_t col = bx * TX + tx;  // vector slot within the row
     if (col >= p.vpr) return;
-    const size_t col_elem = (size_t)col * W;
+    const uint32_t col_elem = col * W;
+    const bool whole = col_elem + W <= p.inner;          // false only for a row's ragged last slot
+    const int count = whole ? W : (int)(p.inner - col_elem);
 
     T va[ROWS][W], vb[ROWS][W];
-    auto load = [&](const T *base, int64_t off, int inner_mode, T (&dst)[W]) {
+    // streamed: the operand changes from row to row (read once, non-temporal like the contiguous kernels);
+    // a row-constant operand is read through the caches
+    auto load = [&](const T *base, int64_t off, int inner_mode, bool streamed, T (&dst)[W]) {
         if (inner_mode == 0) {
             const T s = base[off];
 #pragma unroll
             for (int k = 0; k < W; ++k) dst[k] = s;
-        } else if constexpr (VEC) {
-            const V v = *reinterpret_cast<const V *>(base + off + col_elem);
+        } else if (whole) {
+            const V *src = reinterpret_cast<const V *>(base + off + col_elem);
+            V v;
+            if (streamed) v = load_stream(src);
+            else v = *src;
 #pragma unroll
             for (int k = 0; k < W; ++k) dst[k] = v[k];
         } else {
-            dst[0] = base[off + col_elem];
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = k < count ? base[off + col_elem + k] : base[off + col_elem];
         }
     };
 
     T ca[W], cb[W];
-    if constexpr (CONST_A) load(a, 0, INNER_A, ca);
-    if constexpr (CONST_B) load(b, 0, INNER_B, cb);
+    if constexpr (CONST_A) load(a, 0, INNER_A, false, ca);
+    if constexpr (CONST_B) load(b, 0, INNER_B, false, cb);
 
     const uint32_t row0 = (by * ROWS) * TY + ty;
     uint32_t rows_here = 0;
@@ -101,16 +110,19 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
         int64_t offA = 0, offB = 0;
         if constexpr (!CONST_A || !CONST_B) {
             uint32_t rem = row;
-            for (int k = 0; k < p.n_outer; ++k) {
+            for (int k = 0; k < p.n_outer - 1; ++k) {
                 uint32_t q, idx;
                 p.shape[k].divmod(rem, q, idx);
                 rem = q;
                 if constexpr (!CONST_A) offA += (int64_t)idx * p.sa[k];
                 if constexpr (!CONST_B) offB += (int64_t)idx * p.sb[k];
             }
+            // the outermost axis needs no division: what is left IS its index
+            if constexpr (!CONST_A) offA += (int64_t)rem * p.sa[p.n_outer - 1];
+            if constexpr (!CONST_B) offB += (int64_t)rem * p.sb[p.n_outer - 1];
         }
-        if constexpr (!CONST_A) load(a, offA, INNER_A, va[r]);
-        if constexpr (!CONST_B) load(b, offB, INNER_B, vb[r]);
+        if constexpr (!CONST_A) load(a, offA, INNER_A, INNER_B == 1, va[r]);
+        if constexpr (!CONST_B) load(b, offB, INNER_B, INNER_A == 1, vb[r]);
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -119,13 +131,15 @@ __global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const
         T res[W];
         apply_n<Op, T, W>(ctx, CONST_A ? ca : va[r], CONST_B ? cb : vb[r], res);
         T *dst = out + (size_t)row * p.inner + col_elem;
-        if constexpr (VEC) {
+        if (whole) {
             V v;
 #pragma unroll
             for (int k = 0; k < W; ++k) v[k] = res[k];
             store_stream(reinterpret_cast<V *>(dst), v);
         } else {
-            __builtin_nontemporal_store(res[0], dst);
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+                if (k < count) dst[k] = res[k];
         }
     }
 }
@@ -137,49 +151,78 @@ struct GatherParams {
     uint32_t n;
 };
 
-// OUTVEC: `out` is 16-byte aligned -> each lane stores one vector; otherwise
-// one element per lane.
-template <typename T, typename Op, bool OUTVEC>
+// W consecutive outputs per lane: the store is one (element-aligned) 16-byte vector.  The N-D index of the lane's
+// first output comes from one fast-division chain (none for the outermost axis); the other W-1 follow by
+// increment-and-carry, which is full-rate integer work instead of W more chains of quarter-rate mul-hi / mul-lo.
+template <typename T, typename Op, int W>
 __global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                      GatherParams p) {
-    constexpr int W = OUTVEC ? VecTraits<T>::width : 1;
+    constexpr int D = SMHIP_MAX_NDIM;
     typedef typename VecTraits<T>::vec_t V;
     const uint32_t first = (blockIdx.x * 256u + threadIdx.x) * W;
     if (first >= p.n) return;
-    T res[W];
+    uint32_t idx[D], rem = first;
+    int64_t offA = 0, offB = 0;
 #pragma unroll
-    for (int k = 0; k < W; ++k) {
-        const uint32_t linear = first + k;
-        if (linear < p.n) {
-            uint32_t rem = linear;
-            int64_t offA = 0, offB = 0;
-            for (int d = 0; d < p.ndim; ++d) {
-                uint32_t q, idx;
-                p.shape[d].divmod(rem, q, idx);
+    for (int d = 0; d < D; ++d) {
+        idx[d] = 0;
+        if (d < p.ndim) {
+            if (d == p.ndim - 1) {
+                idx[d] = rem;
+            } else {
+                uint32_t q;
+                p.shape[d].divmod(rem, q, idx[d]);
                 rem = q;
-                offA += (int64_t)idx * p.sa[d];
-                offB += (int64_t)idx * p.sb[d];
             }
-            res[k] = Op::apply(a[offA], b[offB]);
+            offA += (int64_t)idx[d] * p.sa[d];
+            offB += (int64_t)idx[d] * p.sb[d];
         }
     }
-    if constexpr (OUTVEC) {
-        if (first + W <= p.n) {
-            V v;
+    T xa[W], xb[W], res[W];
+    const int count = first + W <= p.n ? W : (int)(p.n - first);
 #pragma unroll
-            for (int k = 0; k < W; ++k) v[k] = res[k];
-            store_stream(reinterpret_cast<V *>(out + first), v);
+    for (int k = 0; k < W; ++k) {
+        if (k < count) {
+            xa[k] = a[offA];
+            xb[k] = b[offB];
         } else {
-            for (int k = 0; k < W && first + k < p.n; ++k) out[first + k] = res[k];
+            xa[k] = xa[0];
+            xb[k] = xb[0];
         }
-    } else {
+        bool carry = k + 1 < count;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < p.ndim && carry) {
+                offA += p.sa[d];
+                offB += p.sb[d];
+                if (++idx[d] == p.shape[d].d && d != p.ndim - 1) {
+                    idx[d] = 0;
+                    offA -= (int64_t)p.shape[d].d * p.sa[d];
+                    offB -= (int64_t)p.shape[d].d * p.sb[d];
+                } else {
+                    carry = false;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) res[k] = Op::apply(xa[k], xb[k]);
+    if constexpr (W == 1) {
         out[first] = res[0];
+    } else if (count == W) {
+        V v;
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = res[k];
+        store_stream(reinterpret_cast<V *>(out + first), v);
+    } else {
+        for (int k = 0; k < count; ++k) out[first + k] = res[k];
     }
 }
 
 // ------------------------------------------------------------------- LDS kernel
 struct LdsParams {
-    int64_t sy[SMHIP_MAX_NDIM];       // the small operand's strides, innermost first
+    uint32_t sy[SMHIP_MAX_NDIM];      // the small operand's strides, innermost first (its span is <= 8192 elements)
+    uint32_t rewind[SMHIP_MAX_NDIM];  // extent * stride: what a wrap of that axis takes back off the offset
     FastDiv shape[SMHIP_MAX_NDIM];    // innermost first
     int ndim;
     uint32_t n, n_vec;                // outputs, and whole vectors among them
@@ -187,51 +230,104 @@ struct LdsParams {
 };
 
 // x: the operand that is dense in output order (streams as vectors); y: the small one, gathered
-// from its LDS copy.  SWAPPED: x is the Op's right operand.
-template <typename T, typename Op, bool SWAPPED>
+// from its LDS copy.  SWAPPED: x is the Op's right operand.  Each lane keeps U vectors of x in flight
+// (all loads issued before any arithmetic).  The N-D index of a vector's first element comes from one
+// fast-division chain (none for the outermost axis); its other W-1 elements follow by increment-and-carry,
+// which is full-rate integer work instead of W more chains of quarter-rate mul-hi / mul-lo.
+template <typename T, typename Op, bool SWAPPED, int U>
 __global__ __launch_bounds__(256) void dense_lds_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out,
                                                         LdsParams p) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
+    constexpr int D = SMHIP_MAX_NDIM;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *ylds = reinterpret_cast<T *>(lds_raw);
     OpCtx<Op> ctx;
     ctx.init();
     for (uint32_t i = threadIdx.x; i < p.y_span; i += 256) ylds[i] = y[i];
     __syncthreads();
-    auto y_at = [&](uint32_t linear) {
-        uint32_t rem = linear;
-        int64_t off = 0;
-        for (int d = 0; d < p.ndim; ++d) {
-            uint32_t q, idx;
-            p.shape[d].divmod(rem, q, idx);
-            rem = q;
-            off += (int64_t)idx * p.sy[d];
+    auto unravel = [&](uint32_t linear, uint32_t (&idx)[D]) {
+        uint32_t off = 0, rem = linear;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            idx[d] = 0;
+            if (d < p.ndim) {
+                if (d == p.ndim - 1) {
+                    idx[d] = rem;
+                } else {
+                    uint32_t q;
+                    p.shape[d].divmod(rem, q, idx[d]);
+                    rem = q;
+                }
+                off += idx[d] * p.sy[d];
+            }
         }
-        return ylds[off];
+        return off;
     };
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < p.n_vec; v += stride) {
-        const V xv = load_stream(reinterpret_cast<const V *>(x) + v);
-        T xa[W], ya[W], r[W];
+    // the small operand's elements for W consecutive outputs starting at `linear` (all W must exist)
+    auto y_vec = [&](uint32_t linear, T (&dst)[W]) {
+        uint32_t idx[D];
+        uint32_t off = unravel(linear, idx);
+        dst[0] = ylds[off];
 #pragma unroll
-        for (int k = 0; k < W; ++k) { xa[k] = xv[k]; ya[k] = y_at(v * W + k); }
-        if (SWAPPED) apply_n<Op, T, W>(ctx, ya, xa, r);
-        else apply_n<Op, T, W>(ctx, xa, ya, r);
-        V rv;
+        for (int k = 1; k < W; ++k) {
+            bool carry = true;
 #pragma unroll
-        for (int k = 0; k < W; ++k) rv[k] = r[k];
-        store_stream(reinterpret_cast<V *>(out) + v, rv);
+            for (int d = 0; d < D; ++d) {
+                if (d < p.ndim && carry) {
+                    off += p.sy[d];
+                    if (++idx[d] == p.shape[d].d && d != p.ndim - 1) {
+                        idx[d] = 0;
+                        off -= p.rewind[d];
+                    } else {
+                        carry = false;
+                    }
+                }
+            }
+            dst[k] = ylds[off];
+        }
+    };
+    constexpr uint32_t kChunk = 256u * U;
+    for (uint32_t base = blockIdx.x * kChunk; base < p.n_vec; base += gridDim.x * kChunk) {
+        V xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t v = base + u * 256u + threadIdx.x;
+            if (v < p.n_vec) xv[u] = load_stream(reinterpret_cast<const V *>(x) + v);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t v = base + u * 256u + threadIdx.x;
+            if (v < p.n_vec) {
+                T xa[W], ya[W], r[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) xa[k] = xv[u][k];
+                y_vec(v * W, ya);
+                if (SWAPPED) apply_n<Op, T, W>(ctx, ya, xa, r);
+                else apply_n<Op, T, W>(ctx, xa, ya, r);
+                V rv;
+#pragma unroll
+                for (int k = 0; k < W; ++k) rv[k] = r[k];
+                store_stream(reinterpret_cast<V *>(out) + v, rv);
+            }
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (uint32_t e = p.n_vec * W; e < p.n; ++e) out[e] = SWAPPED ? Op::apply(y_at(e), x[e]) : Op::apply(x[e], y_at(e));
+    if (blockIdx.x == 0 && threadIdx.x < p.n - p.n_vec * W) {
+        const uint32_t e = p.n_vec * W + threadIdx.x;
+        uint32_t idx[D];
+        const T ye = ylds[unravel(e, idx)];
+        out[e] = SWAPPED ? Op::apply(ye, x[e]) : Op::apply(x[e], ye);
+    }
 }
 
 // ------------------------------------------------------------------ tile kernel
-// Patch shape from tools/sweep_transpose.hip (profiles/r01_sweep_transpose.txt): 64 along p x 128 along q --
-// 256-byte segments on the strided (transposed) side, 512-byte segments on the output side, consecutive
-// workgroups walking q -- matched the plain add's rate; 64 x 64 was 8 % behind, p-fastest ordering 15-25 %.
-constexpr int kTileP = 64, kTileQ = 128;
+// Patch shape from tools/sweep_transpose.hip (profiles/r01_sweep_transpose.txt): 64 along p x 128 along q for
+// 4-byte elements -- 256-byte segments on the strided (transposed) side, 512-byte segments on the output side,
+// consecutive workgroups walking q -- matched the plain add's rate; 64 x 64 was 8 % behind, p-fastest ordering
+// 15-25 %.  8-byte elements take 64 x 64: the same 512-byte output segments and the same 33 KiB of LDS per tile,
+// so four workgroups still fit a CU (64 x 128 doubles left room for two: 57 % of peak instead of 80 %).
+constexpr int kTileP = 64;
+template <typename T> constexpr int tile_q() { return 512 / (int)sizeof(T); }
 
 struct TileParams {
     // plane axes: p (operand-contiguous axis), q (output inner axis)
@@ -246,24 +342,25 @@ struct TileParams {
     uint32_t tiles_p, tiles_q;
 };
 
-// One workgroup = one 64 x 128 patch (i along p, j along q) of one slice of the remaining axes.
+// One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
 // VEC: every global access is a 16-byte vector (W elements) -- along p for operands turned through
 // LDS, along q for direct operands and the output.  LDS tiles are stored already transposed ([i][j],
-// pitch kTileQ + 1 words: the 4-byte scatter of phase 1 and the row reads of phase 2 are at most 2-way
-// bank conflicted) and only as many of them exist as there are LDS-mode operands (dynamic LDS), so a
-// single transposed operand leaves room for 4 workgroups per CU.  MA / MB are compile-time in the
+// pitch TQ + 1 elements: the scatter of phase 1 and the row reads of phase 2 are at most 2-way
+// bank conflicted).  There is ONE tile: with a single LDS-mode operand it holds that operand; when both
+// operands are contiguous along p (a.T op b.T) phase 1 loads both coalesced, applies the Op there and
+// stages the RESULT, so phase 2 is a pure transposed write-out.  MA / MB are compile-time in the
 // vector form; the element form (odd extents, pitches, bases) keeps them as runtime values.
 template <typename T, typename Op, bool VEC, int MA, int MB>
 __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                    TileParams p) {
     constexpr int W = VEC ? VecTraits<T>::width : 1;
-    constexpr int VP = kTileP / W, VQ = kTileQ / W;  // vector slots per patch row, along p / along q
-    constexpr int PITCH = kTileQ + 1;
+    constexpr int TQ = tile_q<T>();
+    constexpr int VP = kTileP / W, VQ = TQ / W;  // vector slots per patch row, along p / along q
+    constexpr int PITCH = TQ + 1;
     typedef typename VecTraits<T>::vec_t V;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T *lds = reinterpret_cast<T *>(lds_raw);
+    __shared__ T tile[kTileP * PITCH];
     const int mode_a = VEC ? MA : p.mode_a, mode_b = VEC ? MB : p.mode_b;
-    T *lds_a = lds, *lds_b = lds + (mode_a == 1 ? kTileP * PITCH : 0);
+    const bool both = mode_a == 1 && mode_b == 1;
     OpCtx<Op> ctx;
     ctx.init();
     uint32_t bid = blockIdx.x;
@@ -278,59 +375,77 @@ __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, cons
         offB += (int64_t)idx * p.b_r[k];
         offO += (int64_t)idx * p.o_r[k];
     }
-    const uint32_t i0 = tp * kTileP, j0 = tq * kTileQ;
-    const bool full = i0 + kTileP <= p.np && j0 + kTileQ <= p.nq;  // workgroup-uniform
+    const uint32_t i0 = tp * kTileP, j0 = tq * TQ;
+    const bool full = i0 + kTileP <= p.np && j0 + TQ <= p.nq;  // workgroup-uniform
     // patch origins
     const T *a0 = a + offA + (int64_t)i0 * p.a_p + (int64_t)j0 * p.a_q;
     const T *b0 = b + offB + (int64_t)i0 * p.b_p + (int64_t)j0 * p.b_q;
     T *o0 = out + offO + (int64_t)i0 * p.o_p + j0;
 
     // phase 1: LDS-mode operands, coalesced along p (slot ig covers i = ig*W .. +W-1 of row jl)
-    auto stage = [&](const T *src0, int64_t s_q, T *tile) {
+    auto along_p = [&](const T *src0, int64_t s_q, uint32_t jl, uint32_t ig, T (&dst)[W]) {
+        const T *g = src0 + ig * W + (int64_t)jl * s_q;
+        if constexpr (VEC) {
+            // two turned streams and no reuse: nt is worth 8 % there; with one it costs (tools/sweep_transpose.hip)
+            const V val = both ? load_stream(reinterpret_cast<const V *>(g)) : *reinterpret_cast<const V *>(g);
 #pragma unroll
-        for (int s = 0; s < kTileQ * VP / 256; ++s) {
-            const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
-            if (full || (i0 + ig * W < p.np && j0 + jl < p.nq)) {
-                const T *g = src0 + ig * W + (int64_t)jl * s_q;
-                if constexpr (VEC) {
-                    const V val = *reinterpret_cast<const V *>(g);
-#pragma unroll
-                    for (int k = 0; k < W; ++k) tile[(ig * W + k) * PITCH + jl] = val[k];
-                } else {
-                    tile[ig * PITCH + jl] = *g;
-                }
-            }
+            for (int k = 0; k < W; ++k) dst[k] = val[k];
+        } else {
+            dst[0] = *g;
         }
     };
-    if (mode_a == 1) stage(a0, p.a_q, lds_a);
-    if (mode_b == 1) stage(b0, p.b_q, lds_b);
+#pragma unroll
+    for (int s = 0; s < TQ * VP / 256; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
+        if (full || (i0 + ig * W < p.np && j0 + jl < p.nq)) {
+            T x[W];
+            if (both) {
+                T xa[W], xb[W];
+                along_p(a0, p.a_q, jl, ig, xa);
+                along_p(b0, p.b_q, jl, ig, xb);
+                apply_n<Op, T, W>(ctx, xa, xb, x);
+            } else if (mode_a == 1) {
+                along_p(a0, p.a_q, jl, ig, x);
+            } else {
+                along_p(b0, p.b_q, jl, ig, x);
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) tile[(ig * W + k) * PITCH + jl] = x[k];
+        }
+    }
     __syncthreads();
 
     // phase 2: everything coalesced along q (slot jg covers j = jg*W .. +W-1 of row il)
-    auto fetch = [&](const T *src0, int64_t s_p, int64_t s_q, int mode, const T *tile, uint32_t il, uint32_t jg, T (&dst)[W]) {
-        if (mode == 1) {
+    auto along_q = [&](const T *src0, int64_t s_p, int64_t s_q, uint32_t il, uint32_t jg, T (&dst)[W]) {
+        const T *g = src0 + (int64_t)il * s_p + (int64_t)(jg * W) * s_q;
+        if (VEC && s_q == 1) {
+            const V val = load_stream(reinterpret_cast<const V *>(g));
 #pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = tile[il * PITCH + jg * W + k];
+            for (int k = 0; k < W; ++k) dst[k] = val[k];
         } else {
-            const T *g = src0 + (int64_t)il * s_p + (int64_t)(jg * W) * s_q;
-            if (VEC && s_q == 1) {
-                const V val = load_stream(reinterpret_cast<const V *>(g));
 #pragma unroll
-                for (int k = 0; k < W; ++k) dst[k] = val[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < W; ++k) dst[k] = g[(int64_t)k * s_q];
-            }
+            for (int k = 0; k < W; ++k) dst[k] = g[(int64_t)k * s_q];
         }
     };
 #pragma unroll
     for (int s = 0; s < kTileP * VQ / 256; ++s) {
         const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
         if (full || (i0 + il < p.np && j0 + jg * W < p.nq)) {
-            T xa[W], xb[W], xr[W];
-            fetch(a0, p.a_p, p.a_q, mode_a, lds_a, il, jg, xa);
-            fetch(b0, p.b_p, p.b_q, mode_b, lds_b, il, jg, xb);
-            apply_n<Op, T, W>(ctx, xa, xb, xr);
+            T xt[W], xr[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) xt[k] = tile[il * PITCH + jg * W + k];
+            if (both) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) xr[k] = xt[k];
+            } else if (mode_a == 1) {
+                T xb[W];
+                along_q(b0, p.b_p, p.b_q, il, jg, xb);
+                apply_n<Op, T, W>(ctx, xt, xb, xr);
+            } else {
+                T xa[W];
+                along_q(a0, p.a_p, p.a_q, il, jg, xa);
+                apply_n<Op, T, W>(ctx, xa, xt, xr);
+            }
             T *dst = o0 + (int64_t)il * p.o_p + jg * W;
             if constexpr (VEC) {
                 V val;
@@ -378,22 +493,27 @@ Plan normalise(const int64_t *shape, const int64_t *sa, const int64_t *sb, int n
     return p;
 }
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-template <typename T, typename Op, bool VEC, int IA, int IB, bool CA, bool CB>
+template <typename T, typename Op, int IA, int IB, bool CA, bool CB>
 int launch_row_tx(const T *a, const T *b, T *out, const RowParams &p_in, hipStream_t s) {
-    constexpr int ROWS = 4;
     RowParams p = p_in;
     bool too_big = false;
-    auto go = [&](auto tx_tag) {
+    auto go2 = [&](auto tx_tag, auto rows_tag) {
         constexpr int TX = decltype(tx_tag)::value;
+        constexpr int ROWS = decltype(rows_tag)::value;
         constexpr int TY = 256 / TX;
         const size_t gx = (p.vpr + TX - 1) / TX;
         const size_t gy = ((size_t)p.rows + TY * ROWS - 1) / (TY * ROWS);
         if (gx * gy > 0x7fffffffull) { too_big = true; return; }
         p.grid_x = (uint32_t)gx;
-        hipLaunchKernelGGL((row_kernel<T, Op, VEC, IA, IB, CA, CB, TX, ROWS>), dim3((unsigned)(gx * gy)), dim3(256), 0, s, a, b, out, p);
+        hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, TX, ROWS>), dim3((unsigned)(gx * gy)), dim3(256), 0, s, a, b, out, p);
     };
+    // Rows per lane (tools/bcast_matrix.py, profiles/r01_bcast_matrix.txt): two when one side is a row-constant or a
+    // per-row scalar -- two independent 16-byte loads in flight per lane, 83 % of peak on config 3 against 80 % with
+    // one or four; one when both operands stream (three full streams behave like the contiguous kernel: 80 % vs
+    // 74-77 %) and for pow, whose arithmetic already overlaps the next lane's loads.
+    constexpr bool kThreeStreams = IA == 1 && IB == 1 && !CA && !CB;
+    constexpr int kRows = (kThreeStreams || std::is_same<Op, PowOp<T>>::value) ? 1 : 2;
+    auto go = [&](auto tx_tag) { go2(tx_tag, std::integral_constant<int, kRows>{}); };
     if (p.vpr > 128) go(std::integral_constant<int, 256>{});
     else if (p.vpr > 64) go(std::integral_constant<int, 128>{});
     else if (p.vpr > 32) go(std::integral_constant<int, 64>{});
@@ -404,12 +524,12 @@ int launch_row_tx(const T *a, const T *b, T *out, const RowParams &p_in, hipStre
     return SMHIP_OK;
 }
 
-template <typename T, typename Op, bool VEC>
+template <typename T, typename Op>
 int launch_row(const T *a, const T *b, T *out, const RowParams &p, int ia, int ib, bool ca, bool cb, hipStream_t s) {
     // inner (1,1): neither, one or the other operand constant over rows; (1,0)/(0,1): the
     // broadcast side may additionally be row-constant only together with being a scalar,
     // which normalise() has already folded away -- so CONST applies to dense sides only.
-#define ROW(IA, IB, CA, CB) return launch_row_tx<T, Op, VEC, IA, IB, CA, CB>(a, b, out, p, s)
+#define ROW(IA, IB, CA, CB) return launch_row_tx<T, Op, IA, IB, CA, CB>(a, b, out, p, s)
     if (ia == 1 && ib == 1) {
         if (cb && !ca) ROW(1, 1, false, true);
         if (ca && !cb) ROW(1, 1, true, false);
@@ -441,9 +561,7 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         p.n_outer = nd - 1;
         p.rows = (uint32_t)rows;
         p.inner = (uint32_t)inner;
-        // a side that is broadcast along the inner axis is read as scalars: no alignment demand
         bool ca = true, cb = true;
-        bool vec = (inner % W == 0) && aligned16(out) && (ia == 0 || aligned16(a)) && (ib == 0 || aligned16(b));
         for (int k = 0; k < nd - 1; ++k) {  // innermost-outer first
             const int src = nd - 2 - k;
             p.shape[k] = FastDiv((uint32_t)pl.shape[src]);
@@ -451,19 +569,13 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
             p.sb[k] = pl.sb[src];
             ca &= pl.sa[src] == 0;
             cb &= pl.sb[src] == 0;
-            if (ia == 1 && pl.sa[src] % W) vec = false;
-            if (ib == 1 && pl.sb[src] % W) vec = false;
         }
-        if (vec) {
-            p.vpr = (uint32_t)(inner / W);
-            return launch_row<T, Op, true>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
-        }
-        p.vpr = (uint32_t)inner;
-        return launch_row<T, Op, false>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
+        p.vpr = (uint32_t)((inner + W - 1) / W);
+        return launch_row<T, Op>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
     }
 
     // One operand dense in output order, the other small: stage the small one in LDS.
-    if (pl.n < 0x7fffffffull && aligned16(out)) {
+    if (pl.n < 0x7fffffffull) {
         auto dense_in_output_order = [&](const int64_t *st) {
             int64_t expect = 1;
             for (int d = nd - 1; d >= 0; --d) {
@@ -481,8 +593,8 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         const bool a_dense = dense_in_output_order(pl.sa), b_dense = dense_in_output_order(pl.sb);
         const int64_t span_a = span_of(pl.sa), span_b = span_of(pl.sb);
         int pick = -1;  // 0: a streams, b staged;  1: b streams, a staged
-        if (a_dense && !b_dense && aligned16(a) && span_b * (int64_t)sizeof(T) <= kLdsBytes) pick = 0;
-        else if (b_dense && !a_dense && aligned16(b) && span_a * (int64_t)sizeof(T) <= kLdsBytes) pick = 1;
+        if (a_dense && !b_dense && span_b * (int64_t)sizeof(T) <= kLdsBytes) pick = 0;
+        else if (b_dense && !a_dense && span_a * (int64_t)sizeof(T) <= kLdsBytes) pick = 1;
         if (pick >= 0) {
             LdsParams lp{};
             lp.ndim = nd;
@@ -492,14 +604,18 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
             for (int d = 0; d < nd; ++d) {
                 const int src = nd - 1 - d;
                 lp.shape[d] = FastDiv((uint32_t)pl.shape[src]);
-                lp.sy[d] = pick == 0 ? pl.sb[src] : pl.sa[src];
+                lp.sy[d] = (uint32_t)(pick == 0 ? pl.sb[src] : pl.sa[src]);
+                lp.rewind[d] = (uint32_t)pl.shape[src] * lp.sy[d];
             }
-            const size_t want = ((size_t)lp.n_vec + 255) / 256;
-            const size_t cap = (size_t)compute_units() * 8;
-            const unsigned grid = (unsigned)(want < cap ? (want ? want : 1) : cap);
+            // a small staged operand (<= 4 KiB) is re-staged by every workgroup of a one-shot launch, which lets
+            // the hardware dispatcher balance the stream; a larger one is staged once per persistent workgroup
+            constexpr int U = 4;
             const size_t lds = (size_t)lp.y_span * sizeof(T);
-            if (pick == 0) hipLaunchKernelGGL((dense_lds_kernel<T, Op, false>), dim3(grid), dim3(256), lds, s, a, b, out, lp);
-            else hipLaunchKernelGGL((dense_lds_kernel<T, Op, true>), dim3(grid), dim3(256), lds, s, b, a, out, lp);
+            const size_t want = ((size_t)lp.n_vec + 256 * U - 1) / (256 * U);
+            const size_t cap = lds <= 4096 ? want : (size_t)compute_units() * 8;
+            const unsigned grid = (unsigned)(want < cap ? (want ? want : 1) : cap);
+            if (pick == 0) hipLaunchKernelGGL((dense_lds_kernel<T, Op, false, U>), dim3(grid), dim3(256), lds, s, a, b, out, lp);
+            else hipLaunchKernelGGL((dense_lds_kernel<T, Op, true, U>), dim3(grid), dim3(256), lds, s, b, a, out, lp);
             SMHIP_LAUNCH_CHECK("dense_lds_kernel");
             return SMHIP_OK;
         }
@@ -540,23 +656,16 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
                 slices *= (size_t)pl.shape[d];
             }
             t.tiles_p = (t.np + kTileP - 1) / kTileP;
-            t.tiles_q = (t.nq + kTileQ - 1) / kTileQ;
+            t.tiles_q = (t.nq + tile_q<T>() - 1) / tile_q<T>();
             const size_t blocks = slices * t.tiles_p * t.tiles_q;
             if (blocks < 0x7fffffffull && pl.shape[paxis] < 0x7fffffffll && inner < 0x7fffffffll) {
-                // 16-byte accesses need every vector to start on a 16-byte boundary: bases, both plane
-                // extents, and every stride that moves a vector's start (all but the unit ones)
-                bool vec = aligned16(a) && aligned16(b) && aligned16(out) && t.np % W == 0 && t.nq % W == 0;
-                auto mult = [&](int64_t v) { return v % W == 0; };
-                if (t.mode_a == 1) vec &= mult(t.a_q); else vec &= mult(t.a_p);
-                if (t.mode_b == 1) vec &= mult(t.b_q); else vec &= mult(t.b_p);
-                vec &= mult(t.o_p);
-                for (int k = 0; k < t.n_rest; ++k) vec &= mult(t.a_r[k]) && mult(t.b_r[k]) && mult(t.o_r[k]);
-                const size_t lds_bytes = (size_t)(t.mode_a + t.mode_b) * kTileP * (kTileQ + 1) * sizeof(T);
+                // the 16-byte form needs whole vectors along both plane axes; bases and pitches may be anything
+                const bool vec = t.np % W == 0 && t.nq % W == 0;
                 const dim3 grid((unsigned)blocks), block(256);
-                if (!vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0>), grid, block, lds_bytes, s, a, b, out, t);
-                else if (t.mode_a == 1 && t.mode_b == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1>), grid, block, lds_bytes, s, a, b, out, t);
-                else if (t.mode_a == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0>), grid, block, lds_bytes, s, a, b, out, t);
-                else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, lds_bytes, s, a, b, out, t);
+                if (!vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0>), grid, block, 0, s, a, b, out, t);
+                else if (t.mode_a == 1 && t.mode_b == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1>), grid, block, 0, s, a, b, out, t);
+                else if (t.mode_a == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0>), grid, block, 0, s, a, b, out, t);
+                else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, 0, s, a, b, out, t);
                 SMHIP_LAUNCH_CHECK("tile_kernel");
                 return SMHIP_OK;
             }
@@ -574,12 +683,15 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         g.sa[d] = pl.sa[src];
         g.sb[d] = pl.sb[src];
     }
-    if (aligned16(out)) {
-        const unsigned grid = (unsigned)(((pl.n + W - 1) / W + 255) / 256);
-        hipLaunchKernelGGL((gather_kernel<T, Op, true>), dim3(grid), dim3(256), 0, s, a, b, out, g);
-    } else {
+    // An operand strided along the inner axis (a[:, ::2], a channel of an interleaved image): consecutive LANES on
+    // consecutive outputs keep each load instruction inside a few cache lines -- 119 us against 160 us with W outputs
+    // per lane for A[:, ::2] + B[:, ::2] at 8192 x 4096.  Inner strides 0 / 1 (tiny inner extents) keep the vector store.
+    if (ia > 1 || ib > 1) {
         const unsigned grid = (unsigned)((pl.n + 255) / 256);
-        hipLaunchKernelGGL((gather_kernel<T, Op, false>), dim3(grid), dim3(256), 0, s, a, b, out, g);
+        hipLaunchKernelGGL((gather_kernel<T, Op, 1>), dim3(grid), dim3(256), 0, s, a, b, out, g);
+    } else {
+        const unsigned grid = (unsigned)(((pl.n + W - 1) / W + 255) / 256);
+        hipLaunchKernelGGL((gather_kernel<T, Op, W>), dim3(grid), dim3(256), 0, s, a, b, out, g);
     }
     SMHIP_LAUNCH_CHECK("gather_kernel");
     return SMHIP_OK;

@@ -51,15 +51,6 @@ __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restri
     }
 }
 
-// Fallback for operands that are not 16-byte aligned (e.g. a view that starts
-// mid-row): one element per lane, still fully coalesced (256 B per wave).
-template <typename T, typename Op, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void contiguous_elem_kernel(const T *__restrict__ a, const T *__restrict__ b,
-                                                                T *__restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) __builtin_nontemporal_store(Op::apply(__builtin_nontemporal_load(a + i), __builtin_nontemporal_load(b + i)), out + i);
-}
-
 // out[i] = a[i] op s  (SWAPPED: s op a[i]); s is a kernel argument, i.e. it
 // lives in SGPRs -- the `set1` of calculate.h:141-146 costs nothing here.
 template <typename T, typename Op, int BLOCK, bool SWAPPED>
@@ -81,27 +72,8 @@ __global__ __launch_bounds__(BLOCK) void scalar_vec_kernel(const T *__restrict__
     }
 }
 
-template <typename T, typename Op, int BLOCK, bool SWAPPED>
-__global__ __launch_bounds__(BLOCK) void scalar_elem_kernel(const T *__restrict__ a, T s, T *__restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        const T x = __builtin_nontemporal_load(a + i);
-        __builtin_nontemporal_store(SWAPPED ? Op::apply(s, x) : Op::apply(x, s), out + i);
-    }
-}
-
 // Same, with the scalar fetched from device memory (a fully broadcast array
 // operand, e.g. `A + one_element_array`): a wave-uniform load.
-template <typename T, typename Op, int BLOCK, bool SWAPPED>
-__global__ __launch_bounds__(BLOCK) void devscalar_elem_kernel(const T *__restrict__ a, const T *__restrict__ sp,
-                                                               T *__restrict__ out, size_t n) {
-    const T s = *sp;
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        const T x = __builtin_nontemporal_load(a + i);
-        __builtin_nontemporal_store(SWAPPED ? Op::apply(s, x) : Op::apply(x, s), out + i);
-    }
-}
 template <typename T, typename Op, int BLOCK, bool SWAPPED>
 __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restrict__ a, const T *__restrict__ sp,
                                                               T *__restrict__ out, size_t n_vec, int tail) {
@@ -176,8 +148,6 @@ __global__ __launch_bounds__(kHeavyBlock) void heavy_vec_kernel(const T *__restr
 template <typename Op> struct IsHeavy : std::false_type {};
 template <typename T> struct IsHeavy<PowOp<T>> : std::true_type {};
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
 inline unsigned heavy_grid(size_t n_vec) {
     const size_t want = (n_vec + kHeavyBlock - 1) / kHeavyBlock;
     const size_t cap = (size_t)compute_units() * kHeavyGridPerCU;
@@ -197,22 +167,17 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     const T *pa = static_cast<const T *>(a), *pb = static_cast<const T *>(b);
     T *po = static_cast<T *>(out);
     unsigned grid;
-    if (aligned16(a) && aligned16(b) && aligned16(out)) {
-        const size_t n_vec = n / W;
-        const int tail = (int)(n % W);
-        const size_t threads = n_vec + (tail ? 1 : 0);
-        if constexpr (IsHeavy<Op>::value) {
-            hipLaunchKernelGGL((heavy_vec_kernel<T, Op, 0>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa, pb, T{}, po, n_vec, tail);
-        } else if (n_vec >= kBigThreshold) {
-            if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
-            hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail);
-        } else {
-            if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-            hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail);
-        }
+    const size_t n_vec = n / W;
+    const int tail = (int)(n % W);
+    const size_t threads = n_vec + (tail ? 1 : 0);
+    if constexpr (IsHeavy<Op>::value) {
+        hipLaunchKernelGGL((heavy_vec_kernel<T, Op, 0>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa, pb, T{}, po, n_vec, tail);
+    } else if (n_vec >= kBigThreshold) {
+        if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail);
     } else {
-        if (int rc = grid_for(n, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_elem_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n);
+        if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail);
     }
     SMHIP_LAUNCH_CHECK("contiguous");
     return SMHIP_OK;
@@ -224,23 +189,18 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
     const T *pa = static_cast<const T *>(a);
     T *po = static_cast<T *>(out);
     unsigned grid;
-    if (aligned16(a) && aligned16(out)) {
-        const size_t n_vec = n / W;
-        const int tail = (int)(n % W);
-        const size_t threads = n_vec + (tail ? 1 : 0);
-        if constexpr (IsHeavy<Op>::value) {
-            hipLaunchKernelGGL((heavy_vec_kernel<T, Op, SWAPPED ? 2 : 1>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa,
-                               static_cast<const T *>(nullptr), value, po, n_vec, tail);
-        } else if (n_vec >= kBigThreshold) {
-            if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
-            hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockBig, SWAPPED>), dim3(grid), dim3(kBlockBig), 0, s, pa, value, po, n_vec, tail);
-        } else {
-            if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-            hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail);
-        }
+    const size_t n_vec = n / W;
+    const int tail = (int)(n % W);
+    const size_t threads = n_vec + (tail ? 1 : 0);
+    if constexpr (IsHeavy<Op>::value) {
+        hipLaunchKernelGGL((heavy_vec_kernel<T, Op, SWAPPED ? 2 : 1>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa,
+                           static_cast<const T *>(nullptr), value, po, n_vec, tail);
+    } else if (n_vec >= kBigThreshold) {
+        if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
+        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockBig, SWAPPED>), dim3(grid), dim3(kBlockBig), 0, s, pa, value, po, n_vec, tail);
     } else {
-        if (int rc = grid_for(n, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((scalar_elem_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n);
+        if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
+        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail);
     }
     SMHIP_LAUNCH_CHECK("array_scalar");
     return SMHIP_OK;
@@ -253,15 +213,10 @@ int run_devscalar(const void *a, const void *sp, size_t n, void *out, hipStream_
     const T *ps = static_cast<const T *>(sp);
     T *po = static_cast<T *>(out);
     unsigned grid;
-    if (aligned16(a) && aligned16(out)) {
-        const size_t n_vec = n / W;
-        const int tail = (int)(n % W);
-        if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail);
-    } else {
-        if (int rc = grid_for(n, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((devscalar_elem_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n);
-    }
+    const size_t n_vec = n / W;
+    const int tail = (int)(n % W);
+    if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
+    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail);
     SMHIP_LAUNCH_CHECK("array_devscalar");
     return SMHIP_OK;
 }

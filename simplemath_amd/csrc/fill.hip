@@ -14,12 +14,6 @@ namespace {
 using namespace dev;
 
 template <typename T>
-__global__ __launch_bounds__(256) void fill_kernel(T *__restrict__ dst, T v, size_t n) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
-}
-
-template <typename T>
 __global__ __launch_bounds__(256) void fill_vec_kernel(T *__restrict__ dst, T v, size_t n_vec, size_t n) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
@@ -54,15 +48,10 @@ int run_fill(void *dst, const void *value_host, size_t n, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
     const T v = *static_cast<const T *>(value_host);
     T *p = static_cast<T *>(dst);
-    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
-        const size_t n_vec = n / W;
-        const size_t g = (n_vec + 1 + 255) / 256;
-        if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fill too large");
-        hipLaunchKernelGGL(fill_vec_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, p, v, n_vec, n);
-    } else {
-        const size_t g = (n + 255) / 256;
-        hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned)(g < 65536 ? g : 65536)), dim3(256), 0, s, p, v, n);
-    }
+    const size_t n_vec = n / W;
+    const size_t g = (n_vec + 1 + 255) / 256;
+    if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fill too large");
+    hipLaunchKernelGGL(fill_vec_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, p, v, n_vec, n);
     SMHIP_LAUNCH_CHECK("fill");
     return SMHIP_OK;
 }

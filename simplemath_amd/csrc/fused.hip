@@ -42,15 +42,6 @@ __global__ __launch_bounds__(kBlock) void fused_vec_kernel(const T *__restrict__
     }
 }
 
-template <typename T, typename Op1, typename Op2, bool SCALAR_C>
-__global__ __launch_bounds__(256) void fused_elem_kernel(const T *__restrict__ a, const T *__restrict__ b, const T *__restrict__ c,
-                                                         T cs, T *__restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = Op2::apply(Op1::apply(a[i], b[i]), SCALAR_C ? cs : c[i]);
-}
-
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
 template <typename T, typename Op1, typename Op2>
 int run(const void *a_, const void *b_, const void *c_, const void *cs_host, void *out_, size_t n, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
@@ -58,18 +49,11 @@ int run(const void *a_, const void *b_, const void *c_, const void *cs_host, voi
     T *out = static_cast<T *>(out_);
     const bool scalar = c_ == nullptr;
     const T cs = scalar ? *static_cast<const T *>(cs_host) : T{};
-    if (aligned16(a) && aligned16(b) && aligned16(out) && (scalar || aligned16(c))) {
-        const size_t n_vec = n / W, threads = n_vec + (n % W ? 1 : 0);
-        const size_t g = (threads + kBlock - 1) / kBlock;
-        if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused: array too large for one launch");
-        if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W));
-        else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W));
-    } else {
-        const size_t g = (n + 255) / 256;
-        if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused: array too large for one launch");
-        if (scalar) hipLaunchKernelGGL((fused_elem_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(256), 0, s, a, b, c, cs, out, n);
-        else hipLaunchKernelGGL((fused_elem_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(256), 0, s, a, b, c, cs, out, n);
-    }
+    const size_t n_vec = n / W, threads = n_vec + (n % W ? 1 : 0);
+    const size_t g = (threads + kBlock - 1) / kBlock;
+    if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused: array too large for one launch");
+    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W));
+    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W));
     SMHIP_LAUNCH_CHECK("fused");
     return SMHIP_OK;
 }

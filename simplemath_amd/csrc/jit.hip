@@ -39,7 +39,8 @@ const char *kTypeName[4] = {"float", "double", "int", "long long"};
 // The kernels' source.  TYPE, WIDTH and EXPR are -D defines.
 const char *kSource = R"SRC(
 typedef TYPE T;
-typedef T V __attribute__((ext_vector_type(WIDTH)));
+typedef T V0 __attribute__((ext_vector_type(WIDTH)));
+typedef V0 V __attribute__((aligned(sizeof(T))));   // element-aligned 16-byte accesses are legal on gfx950
 struct UserOp { static __device__ __forceinline__ T apply(T a, T b) { return (T)(EXPR); } };
 
 extern "C" __global__ __launch_bounds__(256) void smhip_user_contig(const T* __restrict__ a, const T* __restrict__ b,
@@ -136,8 +137,6 @@ int lookup(int op, int dtype, UserOp **out) {
     return compile(**out, dtype);
 }
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
 }  // namespace
 
 int jit_register(const char *expr, int *op_id) {
@@ -158,7 +157,7 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
     UserOp *u;
     if (int rc = lookup(op, dtype, &u)) return rc;
     const unsigned long long w = (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 2 : 4;
-    int vec = aligned16(a) && aligned16(b) && aligned16(out);
+    int vec = 1;
     unsigned long long n_vec = n / w, nn = n;
     const size_t threads = vec ? n_vec + 1 : n;
     const size_t grid = (threads + 255) / 256;

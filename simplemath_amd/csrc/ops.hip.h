@@ -23,17 +23,30 @@ namespace smhip {
 namespace dev {
 
 // ----------------------------------------------------------------- vectors
+// vec_t is 16 bytes wide but only ELEMENT-aligned: gfx950 takes a global_load/store_dwordx4 at any 4-byte
+// address (the HSA ABI runs the memory pipeline in unaligned mode), and a stream of such accesses that is
+// shifted off the 16-byte grid runs within 2 % of an aligned one (tools/sweep_unaligned.hip: 6.1-6.4 vs
+// 6.3 TB/s; one element per lane: 5.3).  So views that start mid-row, odd row pitches and sliced operands all
+// take the same vector kernels -- there is no per-element fallback for alignment.
 template <typename T> struct VecTraits;
-template <> struct VecTraits<float>   { typedef float   vec_t __attribute__((ext_vector_type(4))); static constexpr int width = 4; };
-template <> struct VecTraits<int32_t> { typedef int32_t vec_t __attribute__((ext_vector_type(4))); static constexpr int width = 4; };
-template <> struct VecTraits<double>  { typedef double  vec_t __attribute__((ext_vector_type(2))); static constexpr int width = 2; };
-template <> struct VecTraits<int64_t> { typedef int64_t vec_t __attribute__((ext_vector_type(2))); static constexpr int width = 2; };
+#define SMHIP_VEC(T, N)                                                       \
+    template <> struct VecTraits<T> {                                         \
+        typedef T full_t __attribute__((ext_vector_type(N)));                \
+        typedef full_t vec_t __attribute__((aligned(sizeof(T))));            \
+        static constexpr int width = N;                                       \
+    };
+SMHIP_VEC(float, 4)
+SMHIP_VEC(int32_t, 4)
+SMHIP_VEC(double, 2)
+SMHIP_VEC(int64_t, 2)
+#undef SMHIP_VEC
 
 // Streaming accesses carry the `nt` (non-temporal) policy: every byte of the
 // contiguous path is touched once, and keeping it out of L2's replacement
 // order is worth ~8 % on the 2R+1W stream (profiles/r01_sweep_stream_add.txt).
-template <typename V> __device__ __forceinline__ V load_stream(const V *p) { return __builtin_nontemporal_load(p); }
-template <typename V> __device__ __forceinline__ void store_stream(V *p, V v) { __builtin_nontemporal_store(v, p); }
+// (Macros, not function templates: a template parameter would strip vec_t's reduced alignment.)
+#define load_stream(ptr) __builtin_nontemporal_load(ptr)
+#define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
 
 // -------------------------------------------------------------- Op policies
 // f32/f64: one correctly rounded IEEE operation each (add.h:18-59 etc.);

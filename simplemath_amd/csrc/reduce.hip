@@ -77,8 +77,10 @@ template <> __device__ __forceinline__ void add_prod<double, double>(double &acc
 enum Mode { kSum = 0, kDot = 1, kFused = 2 };
 
 // One vector's contribution: MODE kSum: acc += a;  kDot: acc += a*b;  kFused: out = a op b, acc += out.
-template <typename T, typename Op, int MODE, typename A, typename V>
-__device__ __forceinline__ void consume(const OpCtx<Op> &ctx, A &acc, V va, V vb, V *out_slot) {
+template <typename T, typename Op, int MODE, typename A>
+__device__ __forceinline__ void consume(const OpCtx<Op> &ctx, A &acc, typename VecTraits<T>::vec_t va, typename VecTraits<T>::vec_t vb,
+                                        typename VecTraits<T>::vec_t *out_slot) {
+    typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     if constexpr (MODE == kFused) {
         const V r = apply_vec<Op, T>(ctx, va, vb);
@@ -121,14 +123,14 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
             else vb[u] = va[u];
         }
 #pragma unroll
-        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, A, V>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock);
+        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock);
     } else {
         for (int u = 0; u < kVecPerThread; ++u) {
             const size_t i = tile0 + (size_t)u * kBlock;
             if (i < n_vec) {
                 const V va = load_stream(av + i);
                 const V vb = MODE != kSum ? load_stream(bv + i) : va;
-                consume<T, Op, MODE, A, V>(ctx, acc, va, vb, ov + i);
+                consume<T, Op, MODE, A>(ctx, acc, va, vb, ov + i);
             }
         }
         // scalar tail (n % W elements): the last workgroup's first lane
@@ -142,24 +144,6 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
                 else acc += widen<T, A>(a[k]);
             }
         }
-    }
-    acc = block_reduce<A, kBlock>(acc);
-    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
-
-// Unaligned fallback: one element per lane per step, grid-stride.
-template <typename T, typename Op, int MODE>
-__global__ __launch_bounds__(kBlock) void reduce_elem_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
-                                                             size_t n, typename AccOf<T>::type *__restrict__ partials) {
-    typedef typename AccOf<T>::type A;
-    A acc = A(0);
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        if constexpr (MODE == kFused) {
-            const T r = Op::apply(a[i], b[i]);
-            out[i] = r;
-            acc += widen<T, A>(r);
-        } else if constexpr (MODE == kDot) add_prod<T, A>(acc, a[i], b[i]);
-        else acc += widen<T, A>(a[i]);
     }
     acc = block_reduce<A, kBlock>(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
@@ -255,19 +239,13 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     const size_t n_vec = n / W;
     const size_t tile = (size_t)kBlock * kVecPerThread;
     size_t blocks;
-    const bool vec = aligned16(a) && aligned16(b) && aligned16(out);
-    if (vec) blocks = n_vec / tile + 1;  // the last workgroup takes the partial tile and the n % W tail (maybe empty)
-    else blocks = n < (size_t)kBlock * 2048 ? (n + kBlock - 1) / kBlock : 2048;
-    if (blocks == 0) blocks = 1;
+    blocks = n_vec / tile + 1;  // the last workgroup takes the partial tile and the n % W tail (maybe empty)
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);
     const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
     double *scratch;
     if (int rc = reduce_scratch(blocks + folded, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
-    if (vec)
-        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials);
-    else
-        hipLaunchKernelGGL((reduce_elem_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n, partials);
+    hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials);
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks > (size_t)kFoldSpan) {
         hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)folded), dim3(kBlock), 0, s, partials, blocks, partials + blocks);

@@ -298,6 +298,49 @@ def test_transposed_and_permuted_views(smhip, oracle):
     assert np.array_equal(got, oracle.binary(orc.ADD, av, b4))
 
 
+def test_tile_kernel_vector_forms(smhip, oracle):
+    """Extents and pitches that are multiples of the vector width, so the tile kernel's 16-byte form runs:
+    one operand transposed (either side), both transposed (the Op is applied before the turn), partial
+    patches on both axes, 4- and 8-byte elements."""
+    for dtn, op in (("f32", "add"), ("f64", "sub"), ("i32", "mul"), ("i64", "add"), ("f64", "div")):
+        dt = DT[dtn]
+        for (r, c) in ((256, 192), (64, 128), (200, 72), (132, 516)):
+            a = gen.gen(dt, r * c, 41, "uniform").reshape(c, r)
+            b = gen.gen(dt, r * c, 42, "nonzero" if dtn[0] == "i" else "uniform").reshape(c, r)
+            d = gen.gen(dt, r * c, 43, "nonzero" if dtn[0] == "i" else "uniform").reshape(r, c)
+            da, db, dd = smhip.to_device(a), smhip.to_device(b), smhip.to_device(d)
+            for (x, xb, dx), (y, yb, dy) in (((a.T, a, da), (b.T, b, db)), ((a.T, a, da), (d, d, dd)), ((d, d, dd), (b.T, b, db))):
+                got = smhip.binary(sma.OPS[op], dx.view_like(x, xb), dy.view_like(y, yb)).numpy()
+                util.assert_same_bits(got, oracle.binary(orc.OPS[op], x, y), f"{dtn} {op} {x.shape} {x.strides} {y.strides}")
+
+
+def test_lds_kernel_patterns(smhip, oracle):
+    """A dense operand against a small one that is broadcast along the inner axis or has a tiny inner extent
+    (the LDS kernel): the reference tests' (N,224,224,3) op (1,224,1,3) family, either operand order, every
+    dtype, element counts that are not multiples of the vector width, a staged operand above 4 KiB (persistent
+    launch), six dimensions."""
+    cases = [
+        ((5, 224, 224, 3), (1, 224, 1, 3)),
+        ((7, 31, 33, 3), (1, 1, 1, 3)),
+        ((6, 100, 50, 4), (6, 1, 1, 4)),
+        ((3, 5, 7, 11, 13, 3), (3, 1, 7, 1, 13, 1)),
+        ((9, 40, 60, 5), (1, 40, 1, 5)),
+        ((4, 300, 70, 6), (1, 300, 1, 6)),      # 1800 elements = 7.2 KiB staged (f32)
+        ((33, 17, 5), (17, 1)),
+    ]
+    for dtn, op in (("f32", "add"), ("f64", "mul"), ("i32", "sub"), ("i64", "mul"), ("f32", "div")):
+        dt = DT[dtn]
+        for big, small in cases:
+            x = gen.gen(dt, int(np.prod(big)), 51, "uniform").reshape(big)
+            y = gen.gen(dt, int(np.prod(small)), 52, "nonzero" if dtn[0] == "i" else "uniform").reshape(small)
+            dx, dy = smhip.to_device(x), smhip.to_device(y)
+            util.assert_same_bits(smhip.binary(sma.OPS[op], dx, dy).numpy(), oracle.binary(orc.OPS[op], x, y), f"{dtn} {op} {big} {small}")
+            if op != "div" or dtn[0] != "i":
+                x2 = gen.gen(dt, int(np.prod(big)), 53, "nonzero" if dtn[0] == "i" else "uniform").reshape(big)
+                util.assert_same_bits(smhip.binary(sma.OPS[op], dy, smhip.to_device(x2)).numpy(), oracle.binary(orc.OPS[op], y, x2),
+                                      f"{dtn} {op} swapped {big} {small}")
+
+
 def test_fused_equals_two_passes(smhip, oracle):
     """smhip_fused_contiguous: (a op1 b) op2 c in one pass is bit-identical to the two operator calls."""
     for dtn in ("f32", "f64", "i32", "i64"):
@@ -626,7 +669,7 @@ def test_empty_and_tiny(smhip):
 
 
 def test_misaligned_views(smhip, oracle):
-    """Operands that start off a 16-byte boundary take the per-element kernels."""
+    """Operands that start off a 16-byte boundary: the same vector kernels, with element-aligned 16-byte accesses."""
     n = 5000
     a = gen.gen(np.float32, n + 8, 11, "mixed")
     b = gen.gen(np.float32, n + 8, 12, "mixed")
@@ -645,6 +688,44 @@ def test_misaligned_views(smhip, oracle):
     sub = m[1:, 1:]  # rows of 34 starting at odd offsets
     got = smhip.binary(sma.OP_SUB, dm.view_like(sub, m), dm.view_like(sub, m)).numpy()
     assert not got.any()
+
+
+def test_ragged_and_shifted_rows(smhip, oracle):
+    """Row kernel on 2-D / 3-D views whose row extent is not a multiple of the vector width, whose rows start at any
+    element offset and whose pitches are odd: every dtype, dense x dense, dense x row, dense x column, scalar fill,
+    fused and array-scalar forms on shifted bases."""
+    for dtn, op in (("f32", "add"), ("f64", "mul"), ("i32", "sub"), ("i64", "add")):
+        dt = DT[dtn]
+        big = gen.gen(dt, 71 * 203, 61, "uniform").reshape(71, 203)
+        oth = gen.gen(dt, 71 * 203, 62, "uniform").reshape(71, 203)
+        dbig, doth = smhip.to_device(big), smhip.to_device(oth)
+        for r0, r1, c0, c1 in ((0, 71, 0, 203), (1, 70, 1, 202), (3, 40, 5, 70), (0, 71, 2, 19), (2, 66, 7, 200), (0, 64, 3, 131)):
+            va, vb = big[r0:r1, c0:c1], oth[r0:r1, c0:c1]
+            got = smhip.binary(sma.OPS[op], dbig.view_like(va, big), doth.view_like(vb, oth)).numpy()
+            util.assert_same_bits(got, oracle.binary(orc.OPS[op], va, vb), f"{dtn} dense x dense [{r0}:{r1},{c0}:{c1}]")
+            row, col = oth[r0:r0 + 1, c0:c1], oth[r0:r1, c0:c0 + 1]
+            got = smhip.binary(sma.OPS[op], dbig.view_like(va, big), doth.view_like(row, oth)).numpy()
+            util.assert_same_bits(got, oracle.binary(orc.OPS[op], va, row), f"{dtn} dense x row [{r0}:{r1},{c0}:{c1}]")
+            got = smhip.binary(sma.OPS[op], doth.view_like(col, oth), dbig.view_like(va, big)).numpy()
+            util.assert_same_bits(got, oracle.binary(orc.OPS[op], col, va), f"{dtn} column x dense [{r0}:{r1},{c0}:{c1}]")
+        for va, vb in ((big[:, 0:202:2], oth[:, 1::2]), (big[::3, 1:202:3], oth[::3, 2::3]), (big[:, ::2], oth[:, :102]), (big[5, ::7][:24], oth[::3, 0])):
+            got = smhip.binary(sma.OPS[op], dbig.view_like(va, big), doth.view_like(vb, oth)).numpy()
+            util.assert_same_bits(got, oracle.binary(orc.OPS[op], va, vb), f"{dtn} strided inner {va.shape} {va.strides} {vb.strides}")
+        cube = gen.gen(dt, 9 * 11 * 37, 63, "uniform").reshape(9, 11, 37)
+        dcube = smhip.to_device(cube)
+        v = cube[1:8, 2:9, 3:36]
+        w = cube[2:3, 2:9, 1:34]
+        got = smhip.binary(sma.OPS[op], dcube.view_like(v, cube), dcube.view_like(w, cube)).numpy()
+        util.assert_same_bits(got, oracle.binary(orc.OPS[op], v, w), f"{dtn} 3-D shifted views")
+        # 1-D forms on bases shifted by 1..3 elements, lengths with every tail
+        flat = gen.gen(dt, 4100, 64, "uniform")
+        dflat = smhip.to_device(flat)
+        for off, n in ((1, 4096), (3, 4093), (2, 7), (1, 1), (3, 1023)):
+            x, y = flat[off:off + n], flat[4100 - off - n:4100 - off]
+            dx, dy = dflat.view_like(x, flat), dflat.view_like(y, flat)
+            util.assert_same_bits(smhip.binary(sma.OPS[op], dx, dy).numpy(), oracle.contiguous(orc.OPS[op], np.ascontiguousarray(x), np.ascontiguousarray(y)), f"{dtn} 1-D off {off} n {n}")
+            sc = dt(3)
+            util.assert_same_bits(smhip.array_scalar(sma.OPS[op], dx, sc).numpy(), oracle.array_scalar(orc.OPS[op], np.ascontiguousarray(x), sc), f"{dtn} scalar off {off} n {n}")
 
 
 def test_errors(smhip):
