@@ -25,12 +25,14 @@
 //                  axis is dropped) but broadcast along the INNER axis or with a tiny inner extent
 //                  -- the reference tests' own pattern, (N,224,224,3) op (1,224,1,3): the small
 //                  operand is staged whole into LDS once per workgroup, the dense one streams
-//                  as 16-byte vectors, and the per-element unravel (fast division) only feeds
-//                  an LDS read.
-//   gather kernel  whatever is left (tiny extents, irregular strides): W
-//                  consecutive outputs per lane so the store is still a
-//                  coalesced 16-byte vector; operand loads are per-element
-//                  gathers through fast-division unravel.
+//                  with four 16-byte vectors in flight per lane; one fast-division chain per vector, then
+//                  increment-and-carry, feeds the LDS reads.
+//   gather kernel  whatever is left (tiny extents, irregular strides): one fast-division chain per lane,
+//                  then increment-and-carry; W consecutive outputs per lane with a vector store when the
+//                  inner strides are 0/1, one output per lane when an operand is strided along the inner
+//                  axis (each load instruction then stays inside a few cache lines).
+// Every 16-byte access is only element-aligned (VecTraits, ops.hip.h): bases, pitches and row extents are
+// unconstrained, there are no per-element fallbacks for alignment.
 // Roofline: HBM-bound; algorithmic bytes = sizeof(T) * (|a| + |b| + |out|)
 // with each broadcast operand counted once (config 3: 134 234 112 B).
 #include <type_traits>

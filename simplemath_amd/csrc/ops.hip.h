@@ -45,8 +45,13 @@ SMHIP_VEC(int64_t, 2)
 // contiguous path is touched once, and keeping it out of L2's replacement
 // order is worth ~8 % on the 2R+1W stream (profiles/r01_sweep_stream_add.txt).
 // (Macros, not function templates: a template parameter would strip vec_t's reduced alignment.)
+#ifdef SMHIP_CACHED_STREAMS  // experiment switch (tools/chain_exp.py): plain cached accesses everywhere
+#define load_stream(ptr) (*(ptr))
+#define store_stream(ptr, ...) (*(ptr) = (__VA_ARGS__))
+#else
 #define load_stream(ptr) __builtin_nontemporal_load(ptr)
 #define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
+#endif
 
 // -------------------------------------------------------------- Op policies
 // f32/f64: one correctly rounded IEEE operation each (add.h:18-59 etc.);
