@@ -211,7 +211,7 @@ def main():
         i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
         step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A2.ptr), i64([cols, 1]),
                      C.c_void_p(r2.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr))
-        kernel = "row_kernel<float, MultiplyOp<float>, VEC, 1, 1, false, true, 256, 4>"
+        kernel = "row_kernel<float, MultiplyOp<float>, 1, 1, false, true, 256, 2>"
         workload = "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident"
     elif wl == "transpose_add":
         rows = cols = 8192

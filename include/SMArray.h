@@ -99,6 +99,12 @@ struct Storage {
         }
         return static_cast<T *>(dev);
     }
+    // device side current and about to be partly overwritten: host mirror goes stale
+    T *dev_rw() {
+        T *p = dev_ro();
+        host_valid = false;
+        return p;
+    }
     // device side about to be overwritten entirely
     T *dev_wo() {
         if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
@@ -187,12 +193,30 @@ public:
     SMArray &operator=(const SMArray &) = delete;
 
     // Element-wise copy into an existing array of the same shape (reference SMArray.h:89-97).
+    // The reference runs it as a host loop; here it is a strided device copy (smhip_copy_strided), so
+    // `a(SLICE(1, 3), SLICE_ALL) = b * c;` never leaves HBM.  A source that shares storage with the
+    // destination (`a = a.transpose()`) is made dense first.
     SMArray &operator=(const SMArray &&other) {
         if (_shape != other._shape) throw std::runtime_error("Shape mismatch in assignment");
-        std::vector<T> tmp(other.totalSize ? other.totalSize : 1);
-        other.copy_dense_to(tmp.data());
-        T *base = static_cast<T *>(data);
-        for_each_offset([&](std::size_t linear, std::size_t off) { base[off] = tmp[linear]; });
+        if constexpr (hip::dtype_of<T>::id >= 0) {
+            if (totalSize == 0) return *this;
+            std::unique_ptr<SMArray> holder;
+            const SMArray *src = &other;
+            if (other.data.storage() == data.storage()) {
+                holder.reset(new SMArray(other.contiguous()));
+                src = holder.get();
+            }
+            auto sh = hip::to_i64(_shape), ss = hip::to_i64(src->_strides), sd = hip::to_i64(_strides);
+            if (sh.empty()) { sh = {1}; ss = {1}; sd = {1}; }  // a 0-d array is one element
+            const T *from = src->device_data();
+            hip::check(smhip_copy_strided(hip::dtype_of<T>::id, from, ss.data(), data.storage()->dev_rw() + data.offset(), sd.data(),
+                                          sh.data(), static_cast<int>(sh.size())));
+        } else {
+            std::vector<T> tmp(other.totalSize ? other.totalSize : 1);
+            other.copy_dense_to(tmp.data());
+            T *base = static_cast<T *>(data);
+            for_each_offset([&](std::size_t linear, std::size_t off) { base[off] = tmp[linear]; });
+        }
         return *this;
     }
 

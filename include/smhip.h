@@ -117,6 +117,11 @@ int smhip_is_contiguous(int ndim, const int64_t *shape, const int64_t *strides);
 int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
                       const void *b, const int64_t *stride_b,
                       const int64_t *shape, int ndim, void *out);
+/* SMArray's element-copy assignment `dst_view = src` (SMArray.h:89-97, a host loop in the reference):
+ * dst[sum idx_k*dst_strides_k] = src[sum idx_k*src_strides_k] over `shape`.  A source stride may be 0 (broadcast);
+ * a destination stride may not (for extents > 1).  Source and destination must not overlap. */
+int smhip_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,
+                       const int64_t *shape, int ndim);
 /* handle_contiguous_arrays<T,Op> (calculate.h:101-134): out[i] = a[i] op b[i]. */
 int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n);
 /* array_scalar_op<T,Op> (calculate.h:137-169): out[i] = a[i] op value; `value_host`

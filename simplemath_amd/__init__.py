@@ -229,6 +229,16 @@ class Smhip:
         self.elementwise_raw(op, a.dtype, a.ptr, sa, b.ptr, sb, shape, out.ptr)
         return out
 
+    def assign(self, dst: DeviceArray, src: DeviceArray):
+        """dst[...] = src, element by element (src broadcast to dst's shape): SMArray::operator=(SMArray&&), SMArray.h:89-97."""
+        assert dst.dtype == src.dtype
+        res = self.broadcast(dst.shape, dst.strides, src.shape, src.strides)
+        if res is None or tuple(res[0]) != tuple(dst.shape):
+            raise RuntimeError("Shape mismatch in assignment")
+        shape, sd, ss, _ = res
+        self._ck(self.c.smhip_copy_strided(C.c_int(DTYPES[dst.dtype]), C.c_void_p(src.ptr), _i64(ss), C.c_void_p(dst.ptr), _i64(sd),
+                                           _i64(shape), C.c_int(len(shape))))
+
     def contiguous(self, op, a: DeviceArray, b: DeviceArray, out: DeviceArray | None = None):
         assert a.dtype == b.dtype and a.size == b.size
         if out is None:

@@ -700,6 +700,111 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
 }
 
 
+// ------------------------------------------------------------------ strided copy
+// dst[sum idx_k * sd_k] = src[sum idx_k * ss_k]: the scatter side of SMArray's element-copy assignment
+// (`view = array`, reference SMArray.h:89-97), which the reference runs as a host loop.  Rows are the merged
+// inner axis; when both inner strides are 1 a lane moves one (element-aligned) 16-byte vector, ragged
+// last slot element-wise; otherwise one element per lane.
+struct CopyParams {
+    int64_t ss[kMaxOuter], sd[kMaxOuter];  // outer strides, innermost-outer first
+    FastDiv shape[kMaxOuter];
+    int n_outer;
+    int64_t inner_ss, inner_sd;
+    uint32_t inner;
+    FastDiv slots_per_row;
+    uint32_t slots;  // rows * slots_per_row
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void strided_copy_kernel(const T *__restrict__ src, T *__restrict__ dst, CopyParams p) {
+    constexpr int W = VEC ? VecTraits<T>::width : 1;
+    typedef typename VecTraits<T>::vec_t V;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= p.slots) return;
+    uint32_t row, col;
+    p.slots_per_row.divmod(slot, row, col);
+    int64_t offS = 0, offD = 0;
+    uint32_t rem = row;
+    for (int k = 0; k < p.n_outer - 1; ++k) {
+        uint32_t q, idx;
+        p.shape[k].divmod(rem, q, idx);
+        rem = q;
+        offS += (int64_t)idx * p.ss[k];
+        offD += (int64_t)idx * p.sd[k];
+    }
+    if (p.n_outer > 0) {
+        offS += (int64_t)rem * p.ss[p.n_outer - 1];
+        offD += (int64_t)rem * p.sd[p.n_outer - 1];
+    }
+    const uint32_t e0 = col * W;
+    if constexpr (VEC) {
+        if (e0 + W <= p.inner) {
+            *reinterpret_cast<V *>(dst + offD + e0) = load_stream(reinterpret_cast<const V *>(src + offS + e0));
+        } else {
+            for (uint32_t e = e0; e < p.inner; ++e) dst[offD + e] = src[offS + e];
+        }
+    } else {
+        dst[offD + (int64_t)e0 * p.inner_sd] = src[offS + (int64_t)e0 * p.inner_ss];
+    }
+}
+
+template <typename T>
+int run_copy_strided(const void *src_, void *dst_, const Plan &pl, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const T *src = static_cast<const T *>(src_);
+    T *dst = static_cast<T *>(dst_);
+    const int nd = pl.ndim;
+    CopyParams p{};
+    p.n_outer = nd - 1;
+    p.inner = (uint32_t)pl.shape[nd - 1];
+    p.inner_ss = pl.sa[nd - 1];
+    p.inner_sd = pl.sb[nd - 1];
+    for (int k = 0; k < nd - 1; ++k) {
+        const int from = nd - 2 - k;
+        p.shape[k] = FastDiv((uint32_t)pl.shape[from]);
+        p.ss[k] = pl.sa[from];
+        p.sd[k] = pl.sb[from];
+    }
+    const bool vec = p.inner_ss == 1 && p.inner_sd == 1;
+    const size_t per_row = vec ? ((size_t)p.inner + W - 1) / W : p.inner;
+    const size_t slots = pl.n / (size_t)p.inner * per_row;
+    p.slots_per_row = FastDiv((uint32_t)per_row);
+    p.slots = (uint32_t)slots;
+    const unsigned grid = (unsigned)((slots + 255) / 256);
+    if (vec) hipLaunchKernelGGL((strided_copy_kernel<T, true>), dim3(grid), dim3(256), 0, s, src, dst, p);
+    else hipLaunchKernelGGL((strided_copy_kernel<T, false>), dim3(grid), dim3(256), 0, s, src, dst, p);
+    SMHIP_LAUNCH_CHECK("strided_copy_kernel");
+    return SMHIP_OK;
+}
+
+int copy_plan(int dtype, const void *src, void *dst, const Plan &pl, hipStream_t s) {
+    const size_t esz = dtype_size(dtype);
+    if (pl.ndim == 1 && pl.sa[0] == 1 && pl.sb[0] == 1) {
+        SMHIP_TRY(hipMemcpyAsync(dst, src, pl.n * esz, hipMemcpyDeviceToDevice, s));
+        return SMHIP_OK;
+    }
+    if (pl.n >= 0x7fffffffull) {  // same cut as launch_plan: pieces of < 2^31 elements along the outermost axis
+        const size_t slice = pl.n / (size_t)pl.shape[0];
+        const size_t per = slice >= 0x7fffffffull ? 1 : 0x7ffffffeull / slice;
+        int64_t shape[SMHIP_MAX_NDIM];
+        for (int d = 0; d < pl.ndim; ++d) shape[d] = pl.shape[d];
+        for (size_t i0 = 0; i0 < (size_t)pl.shape[0]; i0 += per) {
+            const size_t left = (size_t)pl.shape[0] - i0;
+            shape[0] = (int64_t)(left < per ? left : per);
+            const Plan sub = normalise(shape, pl.sa, pl.sb, pl.ndim);
+            if (int rc = copy_plan(dtype, static_cast<const char *>(src) + (int64_t)i0 * pl.sa[0] * (int64_t)esz,
+                                   static_cast<char *>(dst) + (int64_t)i0 * pl.sb[0] * (int64_t)esz, sub, s))
+                return rc;
+        }
+        return SMHIP_OK;
+    }
+    switch (dtype) {
+        case SMHIP_F32: case SMHIP_I32: return run_copy_strided<int32_t>(src, dst, pl, s);   // a copy only needs the width
+        case SMHIP_F64: case SMHIP_I64: return run_copy_strided<int64_t>(src, dst, pl, s);
+    }
+    return fail(SMHIP_ERR_INVALID, "copy_strided: bad dtype %d", dtype);
+}
+
 // Kernels below index one launch with 32 bits.  A problem of >= 2^31 elements (a 288 GB device holds 2^36
 // floats) is cut along its outermost dimension into pieces under that limit -- each still gigabytes, so
 // the extra launches cost nothing -- and a piece of one outer index recurses into the next dimension.
@@ -751,6 +856,13 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
 }
 
 }  // namespace
+
+int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,
+                        const int64_t *shape, int ndim, hipStream_t s) {
+    const Plan pl = normalise(shape, src_strides, dst_strides, ndim);  // merges axes that are jointly dense in src AND dst
+    if (pl.n == 0) return SMHIP_OK;
+    return copy_plan(dtype, src, dst, pl, s);
+}
 
 int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
                      const int64_t *shape, int ndim, void *out, hipStream_t s) {

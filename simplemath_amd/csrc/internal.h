@@ -50,6 +50,8 @@ int launch_array_devscalar(int op, int dtype, const void *a, const void *value_d
                            bool swapped, hipStream_t s);
 int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
                      const int64_t *shape, int ndim, void *out, hipStream_t s);
+int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,
+                        const int64_t *shape, int ndim, hipStream_t s);
 // run-time compiled user Ops (jit.hip)
 int jit_register(const char *expr, int *op_id);
 int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);

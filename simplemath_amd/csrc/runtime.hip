@@ -505,6 +505,23 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
 }
 
+int smhip_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,
+                       const int64_t *shape, int ndim) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "copy_strided: bad dtype %d", dtype);
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "copy_strided: ndim %d outside 1..%d", ndim, SMHIP_MAX_NDIM);
+    if (!src_strides || !dst_strides || !shape) return fail(SMHIP_ERR_INVALID, "copy_strided: null shape/stride");
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0 || src_strides[i] < 0 || dst_strides[i] < 0) return fail(SMHIP_ERR_INVALID, "copy_strided: negative extent or stride at dim %d", i);
+        if (shape[i] > 1 && dst_strides[i] == 0) return fail(SMHIP_ERR_INVALID, "copy_strided: destination stride 0 at dim %d (elements would overwrite each other)", i);
+        n *= shape[i];
+    }
+    if (n == 0) return SMHIP_OK;
+    if (!src || !dst) return fail(SMHIP_ERR_INVALID, "copy_strided: null buffer");
+    SMHIP_ACQUIRE(s);
+    return launch_copy_strided(dtype, src, src_strides, dst, dst_strides, shape, ndim, s);
+}
+
 int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n) {
     if ((!valid_op(op) && !user_op(op)) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
     if (n == 0) return SMHIP_OK;

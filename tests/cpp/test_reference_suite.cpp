@@ -369,6 +369,28 @@ TEST(Residency) {
     dst = m + m;
     CHECK_EQ(dst(1, 2), 120.0f); CHECK_EQ(dst(0, 0), 2.0f);
 }
+TEST(AssignIntoViews) {
+    // operator=(SMArray&&) is an element copy (SMArray.h:89-97); here a strided device copy, so it composes with views
+    sm::SMArray<float> m = {{1, 2, 3, 4}, {5, 6, 7, 8}, {9, 10, 11, 12}};
+    m(1, SLICE_ALL) = sm::ones<float>(4) * 50.0f;              // one row
+    CHECK_EQ(m(1, 0), 50.0f); CHECK_EQ(m(1, 3), 50.0f); CHECK_EQ(m(0, 3), 4.0f); CHECK_EQ(m(2, 0), 9.0f);
+    m(SLICE_ALL, SLICE(1, 3)) = sm::zeros<float>(3, 2);          // a column block (pitch 4, width 2)
+    CHECK_EQ(m(0, 0), 1.0f); CHECK_EQ(m(0, 1), 0.0f); CHECK_EQ(m(0, 2), 0.0f); CHECK_EQ(m(0, 3), 4.0f); CHECK_EQ(m(2, 2), 0.0f);
+    sm::SMArray<float> t = {{1, 2, 3}, {4, 5, 6}};
+    sm::SMArray<float> tt = {{0, 0}, {0, 0}, {0, 0}};
+    tt = t.transpose();                                          // strided source, dense destination
+    CHECK_EQ(tt(0, 1), 4.0f); CHECK_EQ(tt(2, 0), 3.0f); CHECK_EQ(tt(2, 1), 6.0f);
+    sm::SMArray<float> sq = {{1, 2}, {3, 4}};
+    sq = sq.transpose();                                         // source aliases the destination
+    CHECK_EQ(sq(0, 1), 3.0f); CHECK_EQ(sq(1, 0), 2.0f);
+    auto big = sm::zeros<float>(512, 300);
+    big(SLICE(100, 400), SLICE(7, 207)) = sm::ones<float>(300, 200) * 2.0f;   // stays in HBM end to end
+    CHECK_EQ(sm::sum(big), 2.0 * 300 * 200);
+    CHECK_EQ(big(100, 7), 2.0f); CHECK_EQ(big(99, 7), 0.0f); CHECK_EQ(big(399, 206), 2.0f); CHECK_EQ(big(399, 207), 0.0f);
+    bool threw = false;
+    try { m(0, SLICE_ALL) = sm::ones<float>(3); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+}
 TEST(Repeat) {
     sm::SMArray<int> a = {1, 2, 3};
     auto r = a.repeat(2);

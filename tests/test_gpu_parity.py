@@ -728,6 +728,42 @@ def test_ragged_and_shifted_rows(smhip, oracle):
             util.assert_same_bits(smhip.array_scalar(sma.OPS[op], dx, sc).numpy(), oracle.array_scalar(orc.OPS[op], np.ascontiguousarray(x), sc), f"{dtn} scalar off {off} n {n}")
 
 
+def test_strided_copy_assignment(smhip):
+    """smhip_copy_strided (SMArray's `view = array`): numpy's own assignment is the specification.  Dense, sliced,
+    transposed and broadcast sources into dense, sliced and transposed destinations; ragged rows; every element width."""
+    for dt in (np.float32, np.float64, np.int32, np.int64):
+        base = gen.gen(dt, 40 * 50 * 6, 71, "uniform").reshape(40, 50, 6)
+        src = gen.gen(dt, 40 * 50 * 6, 72, "uniform").reshape(40, 50, 6)
+        cases = [
+            (np.s_[:, :, :], np.s_[:, :, :], None),
+            (np.s_[3:30, 5:41, :], np.s_[0:27, 2:38, :], None),
+            (np.s_[:, :, 2], np.s_[:, :, 5], None),               # inner-strided both sides
+            (np.s_[1:38, 7, 1:6], np.s_[0:37, 3:8, 0], None),     # 2-D views of different pitch
+            (np.s_[5, :, :], np.s_[7, :, :], None),
+            (np.s_[2:35, 3:44, 1:4], None, (1, 41, 3)),           # broadcast source along the outer axis
+        ]
+        for dsel, ssel, bshape in cases:
+            want = base.copy()
+            if ssel is not None:
+                sv = src[ssel]
+            else:
+                sv = src[:bshape[0], :bshape[1], :bshape[2]]
+            want[dsel] = sv
+            dbase, dsrc = smhip.to_device(base), smhip.to_device(src)
+            smhip.assign(dbase.view_like(base[dsel], base), dsrc.view_like(sv, src))
+            assert np.array_equal(dbase.numpy(), want), f"{np.dtype(dt)} {dsel} <- {ssel}"
+        # transposed destination
+        sq = gen.gen(dt, 64 * 80, 73, "uniform").reshape(64, 80)
+        other = gen.gen(dt, 64 * 80, 74, "uniform").reshape(80, 64)
+        want = sq.copy(); want.T[...] = other
+        dsq = smhip.to_device(sq)
+        smhip.assign(dsq.view_like(sq.T, sq), smhip.to_device(other))
+        assert np.array_equal(dsq.numpy(), want)
+    with pytest.raises(sma.SmhipError):
+        z = smhip.to_device(np.zeros(8, np.float32))
+        smhip._ck(smhip.c.smhip_copy_strided(0, C.c_void_p(z.ptr), (C.c_int64 * 1)(1), C.c_void_p(z.ptr), (C.c_int64 * 1)(0), (C.c_int64 * 1)(8), 1))
+
+
 def test_errors(smhip):
     a = smhip.to_device(np.zeros((2, 3), dtype=np.float32))
     b = smhip.to_device(np.zeros((4, 3), dtype=np.float32))
