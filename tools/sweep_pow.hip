@@ -63,6 +63,38 @@ __global__ __launch_bounds__(BLOCK) void prefetch(const f4* __restrict__ a, floa
     }
 }
 
+// prefetch + wave priority raised while the next load is issued (memory instructions go out ahead of other waves' VALU)
+template <int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void prefetch_prio(const f4* __restrict__ a, float s, f4* __restrict__ o, size_t nvec) {
+    const double* tab = stage_table();
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nvec) return;
+    f4 cur[1] = {__builtin_nontemporal_load(a + i)};
+    for (;;) {
+        const size_t nx = i + stride;
+        f4 nxt[1];
+        const bool more = nx < nvec;
+        if (MODE & 1) __builtin_amdgcn_s_setprio(3);
+        if (more) nxt[0] = __builtin_nontemporal_load(a + nx);
+        if (MODE & 1) __builtin_amdgcn_s_setprio(0);
+        f4 r[1];
+        if (MODE & 2) {  // half the arithmetic: how sensitive is the time to VALU work?
+            float x[4], y[4], rr[4];
+            for (int k = 0; k < 4; ++k) { x[k] = cur[0][k]; y[k] = s; }
+            smpow::pow_n<2>(reinterpret_cast<const float(&)[2]>(x[0]), reinterpret_cast<const float(&)[2]>(y[0]), reinterpret_cast<float(&)[2]>(rr[0]), tab);
+            r[0][0] = rr[0]; r[0][1] = rr[1]; r[0][2] = x[2] * 2.5f; r[0][3] = x[3] * 2.5f;
+        } else {
+            pow_vecs<1>(tab, cur, s, r);
+        }
+        if (MODE & 4) __builtin_amdgcn_s_setprio(3);
+        __builtin_nontemporal_store(r[0], o + i);
+        if (MODE & 4) __builtin_amdgcn_s_setprio(0);
+        if (!more) break;
+        cur[0] = nxt[0]; i = nx;
+    }
+}
+
 // calibration: the same access shapes with the arithmetic removed (1R + 1W copy)
 template <int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void copy_oneshot(const f4* __restrict__ a, f4* __restrict__ o) {
@@ -171,6 +203,10 @@ int main() {
             printf("B2B x100 %-40s %.4f ms/launch %8.1f GB/s\n", name, ms / 100, 8.0 * n / (ms / 100) * 1e-6);
         };
         b2b("prefetch b512 x32 (nt ld+st)", [&] { prefetch<512><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch_prio(load) b512 x32", [&] { prefetch_prio<512, 1><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch_prio(load+store) b512 x32", [&] { prefetch_prio<512, 5><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch HALF arithmetic b512 x32", [&] { prefetch_prio<512, 2><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
+        b2b("prefetch b512 x32 again", [&] { prefetch<512><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
         b2b("prefetch2 b512 x32", [&] { prefetch2<512><<<256 * 32, 512>>>(av, 2.5f, ov, nvec); });
         b2b("prefetch2 b512 x8", [&] { prefetch2<512><<<256 * 8, 512>>>(av, 2.5f, ov, nvec); });
         b2b("prefetch2 b256 x16", [&] { prefetch2<256><<<256 * 16, 256>>>(av, 2.5f, ov, nvec); });
