@@ -615,7 +615,9 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
             const size_t lds = (size_t)lp.y_span * sizeof(T);
             const size_t want = ((size_t)lp.n_vec + 256 * U - 1) / (256 * U);
             const size_t cap = lds <= 4096 ? want : (size_t)compute_units() * 8;
-            const unsigned grid = (unsigned)(want < cap ? (want ? want : 1) : cap);
+            size_t blocks = want < cap ? want : cap;
+            if (blocks == 0) blocks = 1;  // fewer than W elements: the tail lanes of one workgroup do them
+            const unsigned grid = (unsigned)blocks;
             if (pick == 0) hipLaunchKernelGGL((dense_lds_kernel<T, Op, false, U>), dim3(grid), dim3(256), lds, s, a, b, out, lp);
             else hipLaunchKernelGGL((dense_lds_kernel<T, Op, true, U>), dim3(grid), dim3(256), lds, s, b, a, out, lp);
             SMHIP_LAUNCH_CHECK("dense_lds_kernel");
