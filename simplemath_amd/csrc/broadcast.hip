@@ -346,9 +346,8 @@ struct TileParams {
 
 // One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
 // VEC: every global access is a 16-byte vector (W elements) -- along p for operands turned through
-// LDS, along q for direct operands and the output.  LDS tiles are stored already transposed ([i][j],
-// pitch TQ + 1 elements: the scatter of phase 1 and the row reads of phase 2 are at most 2-way
-// bank conflicted).  There is ONE tile: with a single LDS-mode operand it holds that operand; when both
+// LDS, along q for direct operands and the output.  LDS tiles are stored already transposed ([i][j]) in
+// a bank-conflict-free layout (`at` below; measured: profiles/r01_pmc_lds_tile_kernel.txt).  There is ONE tile: with a single LDS-mode operand it holds that operand; when both
 // operands are contiguous along p (a.T op b.T) phase 1 loads both coalesced, applies the Op there and
 // stages the RESULT, so phase 2 is a pure transposed write-out.  MA / MB are compile-time in the
 // vector form; the element form (odd extents, pitches, bases) keeps them as runtime values.
@@ -358,7 +357,12 @@ __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, cons
     constexpr int W = VEC ? VecTraits<T>::width : 1;
     constexpr int TQ = tile_q<T>();
     constexpr int VP = kTileP / W, VQ = TQ / W;  // vector slots per patch row, along p / along q
-    constexpr int PITCH = TQ + 1;
+    // LDS layout of element (i, j): 4-byte types get a skewed layout (one pad word per 32 columns, two per 32 rows,
+    // odd pitch) that makes both the 4-byte scatter of phase 1 and the stride-4 reads of phase 2 hit 32 distinct
+    // banks per 32-lane group; 8-byte types keep the plain padded pitch.
+    constexpr bool SKEW = sizeof(T) == 4;
+    constexpr int PITCH = SKEW ? TQ + 5 : TQ + 1;
+    auto at = [](uint32_t i, uint32_t j) -> uint32_t { return SKEW ? i * PITCH + j + (j >> 5) + ((i >> 5) << 1) : i * PITCH + j; };
     typedef typename VecTraits<T>::vec_t V;
     __shared__ T tile[kTileP * PITCH];
     const int mode_a = VEC ? MA : p.mode_a, mode_b = VEC ? MB : p.mode_b;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, cons
                 along_p(b0, p.b_q, jl, ig, x);
             }
 #pragma unroll
-            for (int k = 0; k < W; ++k) tile[(ig * W + k) * PITCH + jl] = x[k];
+            for (int k = 0; k < W; ++k) tile[at(ig * W + k, jl)] = x[k];
         }
     }
     __syncthreads();
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, cons
         if (full || (i0 + il < p.np && j0 + jg * W < p.nq)) {
             T xt[W], xr[W];
 #pragma unroll
-            for (int k = 0; k < W; ++k) xt[k] = tile[il * PITCH + jg * W + k];
+            for (int k = 0; k < W; ++k) xt[k] = tile[at(il, jg * W + k)];
             if (both) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) xr[k] = xt[k];
