@@ -615,8 +615,8 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
             }
             // a small staged operand (<= 4 KiB) is re-staged by every workgroup of a one-shot launch, which lets
             // the hardware dispatcher balance the stream; a larger one is staged once per persistent workgroup
-            constexpr int U = 4;
             const size_t lds = (size_t)lp.y_span * sizeof(T);
+            constexpr int U = 4;  // vectors in flight per lane: 75-78 % of peak; 1: 55-65 %, 2: 73-80 %, 8: 71-74 % (tools/bcast_matrix.py)
             const size_t want = ((size_t)lp.n_vec + 256 * U - 1) / (256 * U);
             const size_t cap = lds <= 4096 ? want : (size_t)compute_units() * 8;
             size_t blocks = want < cap ? want : cap;
