@@ -33,8 +33,15 @@ struct ThreadState {
     unsigned char *ring[kMaxDevices] = {};
     size_t ring_head[kMaxDevices] = {};
     hipStream_t ring_stream[kMaxDevices] = {};
+    ~ThreadState();  // a thread that ends hands its scratch back to the pool and its ring to the next thread
 };
 thread_local ThreadState tls;
+
+// Pinned rings of threads that have ended, per device, with the stream their last copies were queued on
+// (the adopting thread drains it before reusing the memory).
+struct SpareRing { unsigned char *ptr; hipStream_t stream; };
+std::mutex g_ring_mutex;
+std::vector<SpareRing> g_spare_rings[kMaxDevices];
 
 // One library-owned stream per device, shared by all threads that did not
 // bring their own.
@@ -183,6 +190,20 @@ int reduce_scratch(size_t count, double **ptr) {
     }
     *ptr = tls.scratch[d];
     return SMHIP_OK;
+}
+
+ThreadState::~ThreadState() {
+    for (int d = 0; d < kMaxDevices; ++d) {
+        if (scratch[d]) {
+            smhip_free(scratch[d]);  // pool bookkeeping only, no HIP call
+            scratch[d] = nullptr;
+        }
+        if (ring[d]) {
+            std::lock_guard<std::mutex> lock(g_ring_mutex);
+            g_spare_rings[d].push_back({ring[d], ring_stream[d]});
+            ring[d] = nullptr;
+        }
+    }
 }
 
 }  // namespace smhip
@@ -392,7 +413,18 @@ int smhip_upload(void *dst, const void *src_host, size_t bytes) {
     constexpr size_t kRingBytes = 4u << 20, kSmall = 64u << 10;
     if (bytes <= kSmall) {
         const int d = tls.device;
-        if (!tls.ring[d]) SMHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&tls.ring[d]), kRingBytes, hipHostMallocDefault));
+        if (!tls.ring[d]) {
+            {
+                std::lock_guard<std::mutex> lock(g_ring_mutex);
+                if (!g_spare_rings[d].empty()) {  // adopt the ring of a thread that has ended
+                    tls.ring[d] = g_spare_rings[d].back().ptr;
+                    tls.ring_stream[d] = g_spare_rings[d].back().stream;
+                    tls.ring_head[d] = kRingBytes;  // forces the drain of that stream before the first reuse
+                    g_spare_rings[d].pop_back();
+                }
+            }
+            if (!tls.ring[d]) SMHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&tls.ring[d]), kRingBytes, hipHostMallocDefault));
+        }
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (tls.ring_head[d] + need > kRingBytes || tls.ring_stream[d] != s) {
             if (tls.ring_stream[d]) SMHIP_TRY(hipStreamSynchronize(tls.ring_stream[d]));

@@ -450,6 +450,18 @@ TEST(ThreadsShareTheLibrary) {
         });
     for (auto &th : pool) th.join();
     for (int t = 0; t < 6; ++t) CHECK(ok[t]);
+    // threads that end hand their reduction scratch back to the pool and their pinned upload ring to the next
+    // thread: 40 short-lived threads, each uploading a small host-built array and reducing it
+    int good = 0;
+    for (int round = 0; round < 40; ++round) {
+        std::thread th([&good, round] {
+            sm::SMArray<float> v = {1.0f, 2.0f, 3.0f, float(round)};
+            auto w = v + v;
+            if (sm::sum(w) == 2.0 * (6.0 + round)) ++good;
+        });
+        th.join();
+    }
+    CHECK_EQ(good, 40);
 }
 TEST(HostPointerLoops) {
     // calling the loop templates directly with host pointers, as the README's recipe does
