@@ -1,7 +1,7 @@
 """Randomised views against the oracle: sliced (with steps), permuted, broadcast operands of rank 1-5 through
 smhip_elementwise, and random strided assignments through smhip_copy_strided (numpy is the specification there).
 
-usage: python tools/fuzz_views.py [cases] [seed]      -- prints the first mismatch and exits 1, else "ok".
+usage: python tests/fuzz_views.py [cases] [seed]      -- prints the first mismatch and exits 1, else "ok".
 """
 import sys
 sys.path.insert(0, "/root/repo")

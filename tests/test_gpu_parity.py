@@ -779,16 +779,16 @@ def test_strided_copy_assignment(smhip):
 
 
 def test_fuzz_views_smoke(smhip):
-    """A short run of tools/fuzz_views.py (random sliced / stepped / permuted / broadcast views of rank 1-5 against the
-    oracle, random strided assignments against numpy) and of tools/fuzz_flat.py (1-D entry points, every tail and
+    """A short run of tests/fuzz_views.py (random sliced / stepped / permuted / broadcast views of rank 1-5 against the
+    oracle, random strided assignments against numpy) and of tests/fuzz_flat.py (1-D entry points, every tail and
     misalignment); 4 x 1500 and 2 x 800 cases of them ran clean when the kernels last changed."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_views.py"), "300", "17"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_views.py"), "300", "17"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_flat.py"), "120", "17"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_flat.py"), "120", "17"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
