@@ -48,7 +48,7 @@ int main() {
             auto result = sm::pow(arr, 2.5f);
             DoNotOptimize(result);
             ClobberMemory();
-        }, sync, 100);
+        }, sync);  // time-based iteration count (~0.5 s): a VALU-heavy kernel needs tens of ms before the clocks have ramped
         char extra[96];
         std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s (8 B/elem)", n / r.ns_per_iter, 8.0 * n / r.ns_per_iter);
         print(r, extra);
