@@ -1,0 +1,430 @@
+// bcast_kernels.hip.h -- the bodies of the broadcast kernels (row / gather / LDS / tile) and their parameter blocks.
+//
+// Device code only, no #includes: this text is compiled twice --
+//   * ahead of time by hipcc as part of broadcast.hip, which wraps each body in a __global__ template per built-in Op, and
+//   * at run time by hipRTC for user-defined Ops (jit.hip embeds this file as a string and wraps the one body variant a
+//     launch needs in an extern "C" kernel), so `x.apply<MyOp>(y)` runs the same kernels as `x + y`.
+// It expects, already declared where it is included: uint32_t / int64_t / size_t, SMHIP_MAX_NDIM, VecTraits<T>, FastDiv,
+// OpCtx<Op>, apply_n<Op, T, W>(), load_stream / store_stream  (ops.hip.h ahead of time; a short prelude in jit.hip at run time).
+// All kernels are launched with 256 threads per workgroup.
+
+constexpr int kMaxOuter = SMHIP_MAX_NDIM - 1;
+
+struct RowParams {
+    int64_t sa[kMaxOuter], sb[kMaxOuter];  // outer strides, elements, innermost-outer first
+    FastDiv shape[kMaxOuter];              // outer extents, innermost-outer first
+    int n_outer;
+    uint32_t rows;    // product of outer extents
+    uint32_t inner;   // inner extent in elements
+    uint32_t vpr;     // vector slots per row = ceil(inner / W)
+    uint32_t grid_x;  // workgroups along the row; the launch is 1-D (grid y is limited to 65 535)
+};
+
+// INNER_x: 1 = dense along the inner axis, 0 = broadcast along it.
+// CONST_x: operand has all outer strides zero -> identical for every row.
+// Every lane owns one 16-byte slot of W elements of a row; accesses are element-aligned vectors (any base,
+// any pitch).  The last slot of a row whose extent is not a multiple of W is handled element by element.
+template <typename T, typename Op, int INNER_A, int INNER_B, bool CONST_A, bool CONST_B, int TX, int ROWS>
+__device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                  RowParams p) {
+    constexpr int W = VecTraits<T>::width;
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int TY = 256 / TX;
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const uint32_t bx = blockIdx.x % p.grid_x, by = blockIdx.x / p.grid_x;
+    const uint32_t col = bx * TX + tx;  // vector slot within the row
+    if (col >= p.vpr) return;
+    const uint32_t col_elem = col * W;
+    const bool whole = col_elem + W <= p.inner;          // false only for a row's ragged last slot
+    const int count = whole ? W : (int)(p.inner - col_elem);
+
+    T va[ROWS][W], vb[ROWS][W];
+    // streamed: the operand changes from row to row (read once, non-temporal like the contiguous kernels);
+    // a row-constant operand is read through the caches
+    auto load = [&](const T *base, int64_t off, int inner_mode, bool streamed, T (&dst)[W]) {
+        if (inner_mode == 0) {
+            const T s = base[off];
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = s;
+        } else if (whole) {
+            const V *src = reinterpret_cast<const V *>(base + off + col_elem);
+            V v;
+            if (streamed) v = load_stream(src);
+            else v = *src;
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = k < count ? base[off + col_elem + k] : base[off + col_elem];
+        }
+    };
+
+    T ca[W], cb[W];
+    if constexpr (CONST_A) load(a, 0, INNER_A, false, ca);
+    if constexpr (CONST_B) load(b, 0, INNER_B, false, cb);
+
+    const uint32_t row0 = (by * ROWS) * TY + ty;
+    uint32_t rows_here = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t row = row0 + r * TY;
+        if (row >= p.rows) break;
+        ++rows_here;
+        int64_t offA = 0, offB = 0;
+        if constexpr (!CONST_A || !CONST_B) {
+            uint32_t rem = row;
+            for (int k = 0; k < p.n_outer - 1; ++k) {
+                uint32_t q, idx;
+                p.shape[k].divmod(rem, q, idx);
+                rem = q;
+                if constexpr (!CONST_A) offA += (int64_t)idx * p.sa[k];
+                if constexpr (!CONST_B) offB += (int64_t)idx * p.sb[k];
+            }
+            // the outermost axis needs no division: what is left IS its index
+            if constexpr (!CONST_A) offA += (int64_t)rem * p.sa[p.n_outer - 1];
+            if constexpr (!CONST_B) offB += (int64_t)rem * p.sb[p.n_outer - 1];
+        }
+        if constexpr (!CONST_A) load(a, offA, INNER_A, INNER_B == 1, va[r]);
+        if constexpr (!CONST_B) load(b, offB, INNER_B, INNER_A == 1, vb[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (r >= (int)rows_here) break;
+        const uint32_t row = row0 + r * TY;
+        T res[W];
+        apply_n<Op, T, W>(ctx, CONST_A ? ca : va[r], CONST_B ? cb : vb[r], res);
+        T *dst = out + (size_t)row * p.inner + col_elem;
+        if (whole) {
+            V v;
+#pragma unroll
+            for (int k = 0; k < W; ++k) v[k] = res[k];
+            store_stream(reinterpret_cast<V *>(dst), v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+                if (k < count) dst[k] = res[k];
+        }
+    }
+}
+
+struct GatherParams {
+    int64_t sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];  // innermost first
+    FastDiv shape[SMHIP_MAX_NDIM];                    // innermost first
+    int ndim;
+    uint32_t n;
+};
+
+// W consecutive outputs per lane: the store is one (element-aligned) 16-byte vector.  The N-D index of the lane's
+// first output comes from one fast-division chain (none for the outermost axis); the other W-1 follow by
+// increment-and-carry, which is full-rate integer work instead of W more chains of quarter-rate mul-hi / mul-lo.
+template <typename T, typename Op, int W>
+__device__ __forceinline__ void gather_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                     GatherParams p) {
+    constexpr int D = SMHIP_MAX_NDIM;
+    typedef typename VecTraits<T>::vec_t V;
+    const uint32_t first = (blockIdx.x * 256u + threadIdx.x) * W;
+    if (first >= p.n) return;
+    uint32_t idx[D], rem = first;
+    int64_t offA = 0, offB = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        idx[d] = 0;
+        if (d < p.ndim) {
+            if (d == p.ndim - 1) {
+                idx[d] = rem;
+            } else {
+                uint32_t q;
+                p.shape[d].divmod(rem, q, idx[d]);
+                rem = q;
+            }
+            offA += (int64_t)idx[d] * p.sa[d];
+            offB += (int64_t)idx[d] * p.sb[d];
+        }
+    }
+    T xa[W], xb[W], res[W];
+    const int count = first + W <= p.n ? W : (int)(p.n - first);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        if (k < count) {
+            xa[k] = a[offA];
+            xb[k] = b[offB];
+        } else {
+            xa[k] = xa[0];
+            xb[k] = xb[0];
+        }
+        bool carry = k + 1 < count;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < p.ndim && carry) {
+                offA += p.sa[d];
+                offB += p.sb[d];
+                if (++idx[d] == p.shape[d].d && d != p.ndim - 1) {
+                    idx[d] = 0;
+                    offA -= (int64_t)p.shape[d].d * p.sa[d];
+                    offB -= (int64_t)p.shape[d].d * p.sb[d];
+                } else {
+                    carry = false;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) res[k] = Op::apply(xa[k], xb[k]);
+    if constexpr (W == 1) {
+        out[first] = res[0];
+    } else if (count == W) {
+        V v;
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = res[k];
+        store_stream(reinterpret_cast<V *>(out + first), v);
+    } else {
+        for (int k = 0; k < count; ++k) out[first + k] = res[k];
+    }
+}
+
+// ------------------------------------------------------------------- LDS kernel
+struct LdsParams {
+    uint32_t sy[SMHIP_MAX_NDIM];      // the small operand's strides, innermost first (its span is <= 8192 elements)
+    uint32_t rewind[SMHIP_MAX_NDIM];  // extent * stride: what a wrap of that axis takes back off the offset
+    FastDiv shape[SMHIP_MAX_NDIM];    // innermost first
+    int ndim;
+    uint32_t n, n_vec;                // outputs, and whole vectors among them
+    uint32_t y_span;                  // elements of the small operand to stage
+};
+
+// x: the operand that is dense in output order (streams as vectors); y: the small one, gathered
+// from its LDS copy.  SWAPPED: x is the Op's right operand.  Each lane keeps U vectors of x in flight
+// (all loads issued before any arithmetic).  The N-D index of a vector's first element comes from one
+// fast-division chain (none for the outermost axis); its other W-1 elements follow by increment-and-carry,
+// which is full-rate integer work instead of W more chains of quarter-rate mul-hi / mul-lo.
+template <typename T, typename Op, bool SWAPPED, int U>
+__device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out,
+                                                        LdsParams p) {
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    constexpr int D = SMHIP_MAX_NDIM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *ylds = reinterpret_cast<T *>(lds_raw);
+    OpCtx<Op> ctx;
+    ctx.init();
+    for (uint32_t i = threadIdx.x; i < p.y_span; i += 256) ylds[i] = y[i];
+    __syncthreads();
+    auto unravel = [&](uint32_t linear, uint32_t (&idx)[D]) {
+        uint32_t off = 0, rem = linear;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            idx[d] = 0;
+            if (d < p.ndim) {
+                if (d == p.ndim - 1) {
+                    idx[d] = rem;
+                } else {
+                    uint32_t q;
+                    p.shape[d].divmod(rem, q, idx[d]);
+                    rem = q;
+                }
+                off += idx[d] * p.sy[d];
+            }
+        }
+        return off;
+    };
+    // the small operand's elements for W consecutive outputs starting at `linear` (all W must exist)
+    auto y_vec = [&](uint32_t linear, T (&dst)[W]) {
+        uint32_t idx[D];
+        uint32_t off = unravel(linear, idx);
+        dst[0] = ylds[off];
+#pragma unroll
+        for (int k = 1; k < W; ++k) {
+            bool carry = true;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (d < p.ndim && carry) {
+                    off += p.sy[d];
+                    if (++idx[d] == p.shape[d].d && d != p.ndim - 1) {
+                        idx[d] = 0;
+                        off -= p.rewind[d];
+                    } else {
+                        carry = false;
+                    }
+                }
+            }
+            dst[k] = ylds[off];
+        }
+    };
+    constexpr uint32_t kChunk = 256u * U;
+    for (uint32_t base = blockIdx.x * kChunk; base < p.n_vec; base += gridDim.x * kChunk) {
+        V xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t v = base + u * 256u + threadIdx.x;
+            if (v < p.n_vec) xv[u] = load_stream(reinterpret_cast<const V *>(x) + v);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t v = base + u * 256u + threadIdx.x;
+            if (v < p.n_vec) {
+                T xa[W], ya[W], r[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) xa[k] = xv[u][k];
+                y_vec(v * W, ya);
+                if (SWAPPED) apply_n<Op, T, W>(ctx, ya, xa, r);
+                else apply_n<Op, T, W>(ctx, xa, ya, r);
+                V rv;
+#pragma unroll
+                for (int k = 0; k < W; ++k) rv[k] = r[k];
+                store_stream(reinterpret_cast<V *>(out) + v, rv);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < p.n - p.n_vec * W) {
+        const uint32_t e = p.n_vec * W + threadIdx.x;
+        uint32_t idx[D];
+        const T ye = ylds[unravel(e, idx)];
+        out[e] = SWAPPED ? Op::apply(ye, x[e]) : Op::apply(x[e], ye);
+    }
+}
+
+// ------------------------------------------------------------------ tile kernel
+// Patch shape from tools/sweep_transpose.hip (profiles/r01_sweep_transpose.txt): 64 along p x 128 along q for
+// 4-byte elements -- 256-byte segments on the strided (transposed) side, 512-byte segments on the output side,
+// consecutive workgroups walking q -- matched the plain add's rate; 64 x 64 was 8 % behind, p-fastest ordering
+// 15-25 %.  8-byte elements take 64 x 64: the same 512-byte output segments and the same 33 KiB of LDS per tile,
+// so four workgroups still fit a CU (64 x 128 doubles left room for two: 57 % of peak instead of 80 %).
+constexpr int kTileP = 64;
+template <typename T> constexpr int tile_q() { return 512 / (int)sizeof(T); }
+
+struct TileParams {
+    // plane axes: p (operand-contiguous axis), q (output inner axis)
+    uint32_t np, nq;            // extents
+    int64_t a_p, a_q, b_p, b_q; // operand strides along p and q (elements)
+    int64_t o_p;                // output stride along p (its q stride is 1)
+    int mode_a, mode_b;         // 1: turned through LDS (operand contiguous along p); 0: read along q directly
+    // remaining axes, innermost first
+    int n_rest;
+    FastDiv rest[SMHIP_MAX_NDIM - 2];
+    int64_t a_r[SMHIP_MAX_NDIM - 2], b_r[SMHIP_MAX_NDIM - 2], o_r[SMHIP_MAX_NDIM - 2];
+    uint32_t tiles_p, tiles_q;
+};
+
+// One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
+// VEC: every global access is a 16-byte vector (W elements) -- along p for operands turned through
+// LDS, along q for direct operands and the output.  LDS tiles are stored already transposed ([i][j]) in
+// a bank-conflict-free layout (`at` below; measured: profiles/r01_pmc_lds_tile_kernel.txt).  There is ONE tile: with a single LDS-mode operand it holds that operand; when both
+// operands are contiguous along p (a.T op b.T) phase 1 loads both coalesced, applies the Op there and
+// stages the RESULT, so phase 2 is a pure transposed write-out.  MA / MB are compile-time in the
+// vector form; the element form (odd extents, pitches, bases) keeps them as runtime values.
+template <typename T, typename Op, bool VEC, int MA, int MB>
+__device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                   TileParams p) {
+    constexpr int W = VEC ? VecTraits<T>::width : 1;
+    constexpr int TQ = tile_q<T>();
+    constexpr int VP = kTileP / W, VQ = TQ / W;  // vector slots per patch row, along p / along q
+    // LDS layout of element (i, j): 4-byte types get a skewed layout (one pad word per 32 columns, two per 32 rows,
+    // odd pitch) that makes both the 4-byte scatter of phase 1 and the stride-4 reads of phase 2 hit 32 distinct
+    // banks per 32-lane group; 8-byte types keep the plain padded pitch.
+    constexpr bool SKEW = sizeof(T) == 4;
+    constexpr int PITCH = SKEW ? TQ + 5 : TQ + 1;
+    auto at = [](uint32_t i, uint32_t j) -> uint32_t { return SKEW ? i * PITCH + j + (j >> 5) + ((i >> 5) << 1) : i * PITCH + j; };
+    typedef typename VecTraits<T>::vec_t V;
+    __shared__ T tile[kTileP * PITCH];
+    const int mode_a = VEC ? MA : p.mode_a, mode_b = VEC ? MB : p.mode_b;
+    const bool both = mode_a == 1 && mode_b == 1;
+    OpCtx<Op> ctx;
+    ctx.init();
+    uint32_t bid = blockIdx.x;
+    const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;
+    const uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;
+    int64_t offA = 0, offB = 0, offO = 0;
+    for (int k = 0; k < p.n_rest; ++k) {
+        uint32_t qd, idx;
+        p.rest[k].divmod(bid, qd, idx);
+        bid = qd;
+        offA += (int64_t)idx * p.a_r[k];
+        offB += (int64_t)idx * p.b_r[k];
+        offO += (int64_t)idx * p.o_r[k];
+    }
+    const uint32_t i0 = tp * kTileP, j0 = tq * TQ;
+    const bool full = i0 + kTileP <= p.np && j0 + TQ <= p.nq;  // workgroup-uniform
+    // patch origins
+    const T *a0 = a + offA + (int64_t)i0 * p.a_p + (int64_t)j0 * p.a_q;
+    const T *b0 = b + offB + (int64_t)i0 * p.b_p + (int64_t)j0 * p.b_q;
+    T *o0 = out + offO + (int64_t)i0 * p.o_p + j0;
+
+    // phase 1: LDS-mode operands, coalesced along p (slot ig covers i = ig*W .. +W-1 of row jl)
+    auto along_p = [&](const T *src0, int64_t s_q, uint32_t jl, uint32_t ig, T (&dst)[W]) {
+        const T *g = src0 + ig * W + (int64_t)jl * s_q;
+        if constexpr (VEC) {
+            // two turned streams and no reuse: nt is worth 8 % there; with one it costs (tools/sweep_transpose.hip)
+            const V val = both ? load_stream(reinterpret_cast<const V *>(g)) : *reinterpret_cast<const V *>(g);
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = val[k];
+        } else {
+            dst[0] = *g;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < TQ * VP / 256; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
+        if (full || (i0 + ig * W < p.np && j0 + jl < p.nq)) {
+            T x[W];
+            if (both) {
+                T xa[W], xb[W];
+                along_p(a0, p.a_q, jl, ig, xa);
+                along_p(b0, p.b_q, jl, ig, xb);
+                apply_n<Op, T, W>(ctx, xa, xb, x);
+            } else if (mode_a == 1) {
+                along_p(a0, p.a_q, jl, ig, x);
+            } else {
+                along_p(b0, p.b_q, jl, ig, x);
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) tile[at(ig * W + k, jl)] = x[k];
+        }
+    }
+    __syncthreads();
+
+    // phase 2: everything coalesced along q (slot jg covers j = jg*W .. +W-1 of row il)
+    auto along_q = [&](const T *src0, int64_t s_p, int64_t s_q, uint32_t il, uint32_t jg, T (&dst)[W]) {
+        const T *g = src0 + (int64_t)il * s_p + (int64_t)(jg * W) * s_q;
+        if (VEC && s_q == 1) {
+            const V val = load_stream(reinterpret_cast<const V *>(g));
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = val[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = g[(int64_t)k * s_q];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < kTileP * VQ / 256; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
+        if (full || (i0 + il < p.np && j0 + jg * W < p.nq)) {
+            T xt[W], xr[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) xt[k] = tile[at(il, jg * W + k)];
+            if (both) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) xr[k] = xt[k];
+            } else if (mode_a == 1) {
+                T xb[W];
+                along_q(b0, p.b_p, p.b_q, il, jg, xb);
+                apply_n<Op, T, W>(ctx, xt, xb, xr);
+            } else {
+                T xa[W];
+                along_q(a0, p.a_p, p.a_q, il, jg, xa);
+                apply_n<Op, T, W>(ctx, xa, xt, xr);
+            }
+            T *dst = o0 + (int64_t)il * p.o_p + jg * W;
+            if constexpr (VEC) {
+                V val;
+#pragma unroll
+                for (int k = 0; k < W; ++k) val[k] = xr[k];
+                store_stream(reinterpret_cast<V *>(dst), val);
+            } else {
+                *dst = xr[0];
+            }
+        }
+    }
+}
+

@@ -37,439 +37,40 @@
 // with each broadcast operand counted once (config 3: 134 234 112 B).
 #include <type_traits>
 
-#include "internal.h"
-#include "ops.hip.h"
+#include "bcast_plan.h"
 
 namespace smhip {
 namespace {
 
 using namespace dev;
 
-constexpr int kMaxOuter = SMHIP_MAX_NDIM - 1;
+using namespace bk;
 
-struct RowParams {
-    int64_t sa[kMaxOuter], sb[kMaxOuter];  // outer strides, elements, innermost-outer first
-    FastDiv shape[kMaxOuter];              // outer extents, innermost-outer first
-    int n_outer;
-    uint32_t rows;    // product of outer extents
-    uint32_t inner;   // inner extent in elements
-    uint32_t vpr;     // vector slots per row = ceil(inner / W)
-    uint32_t grid_x;  // workgroups along the row; the launch is 1-D (grid y is limited to 65 535)
-};
-
-// INNER_x: 1 = dense along the inner axis, 0 = broadcast along it.
-// CONST_x: operand has all outer strides zero -> identical for every row.
-// Every lane owns one 16-byte slot of W elements of a row; accesses are element-aligned vectors (any base,
-// any pitch).  The last slot of a row whose extent is not a multiple of W is handled element by element.
+// The ahead-of-time kernels: one __global__ template per body.
 template <typename T, typename Op, int INNER_A, int INNER_B, bool CONST_A, bool CONST_B, int TX, int ROWS>
-__global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
-                                                  RowParams p) {
-    constexpr int W = VecTraits<T>::width;
-    typedef typename VecTraits<T>::vec_t V;
-    constexpr int TY = 256 / TX;
-    OpCtx<Op> ctx;
-    ctx.init();
-    const uint32_t tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const uint32_t bx = blockIdx.x % p.grid_x, by = blockIdx.x / p.grid_x;
-    const uint32_t col = bx * TX + tx;  // vector slot within the row
-    if (col >= p.vpr) return;
-    const uint32_t col_elem = col * W;
-    const bool whole = col_elem + W <= p.inner;          // false only for a row's ragged last slot
-    const int count = whole ? W : (int)(p.inner - col_elem);
-
-    T va[ROWS][W], vb[ROWS][W];
-    // streamed: the operand changes from row to row (read once, non-temporal like the contiguous kernels);
-    // a row-constant operand is read through the caches
-    auto load = [&](const T *base, int64_t off, int inner_mode, bool streamed, T (&dst)[W]) {
-        if (inner_mode == 0) {
-            const T s = base[off];
-#pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = s;
-        } else if (whole) {
-            const V *src = reinterpret_cast<const V *>(base + off + col_elem);
-            V v;
-            if (streamed) v = load_stream(src);
-            else v = *src;
-#pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = v[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = k < count ? base[off + col_elem + k] : base[off + col_elem];
-        }
-    };
-
-    T ca[W], cb[W];
-    if constexpr (CONST_A) load(a, 0, INNER_A, false, ca);
-    if constexpr (CONST_B) load(b, 0, INNER_B, false, cb);
-
-    const uint32_t row0 = (by * ROWS) * TY + ty;
-    uint32_t rows_here = 0;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const uint32_t row = row0 + r * TY;
-        if (row >= p.rows) break;
-        ++rows_here;
-        int64_t offA = 0, offB = 0;
-        if constexpr (!CONST_A || !CONST_B) {
-            uint32_t rem = row;
-            for (int k = 0; k < p.n_outer - 1; ++k) {
-                uint32_t q, idx;
-                p.shape[k].divmod(rem, q, idx);
-                rem = q;
-                if constexpr (!CONST_A) offA += (int64_t)idx * p.sa[k];
-                if constexpr (!CONST_B) offB += (int64_t)idx * p.sb[k];
-            }
-            // the outermost axis needs no division: what is left IS its index
-            if constexpr (!CONST_A) offA += (int64_t)rem * p.sa[p.n_outer - 1];
-            if constexpr (!CONST_B) offB += (int64_t)rem * p.sb[p.n_outer - 1];
-        }
-        if constexpr (!CONST_A) load(a, offA, INNER_A, INNER_B == 1, va[r]);
-        if constexpr (!CONST_B) load(b, offB, INNER_B, INNER_A == 1, vb[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        if (r >= (int)rows_here) break;
-        const uint32_t row = row0 + r * TY;
-        T res[W];
-        apply_n<Op, T, W>(ctx, CONST_A ? ca : va[r], CONST_B ? cb : vb[r], res);
-        T *dst = out + (size_t)row * p.inner + col_elem;
-        if (whole) {
-            V v;
-#pragma unroll
-            for (int k = 0; k < W; ++k) v[k] = res[k];
-            store_stream(reinterpret_cast<V *>(dst), v);
-        } else {
-#pragma unroll
-            for (int k = 0; k < W; ++k)
-                if (k < count) dst[k] = res[k];
-        }
-    }
+__global__ __launch_bounds__(256) void row_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, RowParams p) {
+    row_body<T, Op, INNER_A, INNER_B, CONST_A, CONST_B, TX, ROWS>(a, b, out, p);
 }
-
-struct GatherParams {
-    int64_t sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];  // innermost first
-    FastDiv shape[SMHIP_MAX_NDIM];                    // innermost first
-    int ndim;
-    uint32_t n;
-};
-
-// W consecutive outputs per lane: the store is one (element-aligned) 16-byte vector.  The N-D index of the lane's
-// first output comes from one fast-division chain (none for the outermost axis); the other W-1 follow by
-// increment-and-carry, which is full-rate integer work instead of W more chains of quarter-rate mul-hi / mul-lo.
 template <typename T, typename Op, int W>
-__global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
-                                                     GatherParams p) {
-    constexpr int D = SMHIP_MAX_NDIM;
-    typedef typename VecTraits<T>::vec_t V;
-    const uint32_t first = (blockIdx.x * 256u + threadIdx.x) * W;
-    if (first >= p.n) return;
-    uint32_t idx[D], rem = first;
-    int64_t offA = 0, offB = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        idx[d] = 0;
-        if (d < p.ndim) {
-            if (d == p.ndim - 1) {
-                idx[d] = rem;
-            } else {
-                uint32_t q;
-                p.shape[d].divmod(rem, q, idx[d]);
-                rem = q;
-            }
-            offA += (int64_t)idx[d] * p.sa[d];
-            offB += (int64_t)idx[d] * p.sb[d];
-        }
-    }
-    T xa[W], xb[W], res[W];
-    const int count = first + W <= p.n ? W : (int)(p.n - first);
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-        if (k < count) {
-            xa[k] = a[offA];
-            xb[k] = b[offB];
-        } else {
-            xa[k] = xa[0];
-            xb[k] = xb[0];
-        }
-        bool carry = k + 1 < count;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (d < p.ndim && carry) {
-                offA += p.sa[d];
-                offB += p.sb[d];
-                if (++idx[d] == p.shape[d].d && d != p.ndim - 1) {
-                    idx[d] = 0;
-                    offA -= (int64_t)p.shape[d].d * p.sa[d];
-                    offB -= (int64_t)p.shape[d].d * p.sb[d];
-                } else {
-                    carry = false;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < W; ++k) res[k] = Op::apply(xa[k], xb[k]);
-    if constexpr (W == 1) {
-        out[first] = res[0];
-    } else if (count == W) {
-        V v;
-#pragma unroll
-        for (int k = 0; k < W; ++k) v[k] = res[k];
-        store_stream(reinterpret_cast<V *>(out + first), v);
-    } else {
-        for (int k = 0; k < count; ++k) out[first + k] = res[k];
-    }
+__global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, GatherParams p) {
+    gather_body<T, Op, W>(a, b, out, p);
 }
-
-// ------------------------------------------------------------------- LDS kernel
-struct LdsParams {
-    uint32_t sy[SMHIP_MAX_NDIM];      // the small operand's strides, innermost first (its span is <= 8192 elements)
-    uint32_t rewind[SMHIP_MAX_NDIM];  // extent * stride: what a wrap of that axis takes back off the offset
-    FastDiv shape[SMHIP_MAX_NDIM];    // innermost first
-    int ndim;
-    uint32_t n, n_vec;                // outputs, and whole vectors among them
-    uint32_t y_span;                  // elements of the small operand to stage
-};
-
-// x: the operand that is dense in output order (streams as vectors); y: the small one, gathered
-// from its LDS copy.  SWAPPED: x is the Op's right operand.  Each lane keeps U vectors of x in flight
-// (all loads issued before any arithmetic).  The N-D index of a vector's first element comes from one
-// fast-division chain (none for the outermost axis); its other W-1 elements follow by increment-and-carry,
-// which is full-rate integer work instead of W more chains of quarter-rate mul-hi / mul-lo.
 template <typename T, typename Op, bool SWAPPED, int U>
-__global__ __launch_bounds__(256) void dense_lds_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out,
-                                                        LdsParams p) {
-    typedef typename VecTraits<T>::vec_t V;
-    constexpr int W = VecTraits<T>::width;
-    constexpr int D = SMHIP_MAX_NDIM;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T *ylds = reinterpret_cast<T *>(lds_raw);
-    OpCtx<Op> ctx;
-    ctx.init();
-    for (uint32_t i = threadIdx.x; i < p.y_span; i += 256) ylds[i] = y[i];
-    __syncthreads();
-    auto unravel = [&](uint32_t linear, uint32_t (&idx)[D]) {
-        uint32_t off = 0, rem = linear;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            idx[d] = 0;
-            if (d < p.ndim) {
-                if (d == p.ndim - 1) {
-                    idx[d] = rem;
-                } else {
-                    uint32_t q;
-                    p.shape[d].divmod(rem, q, idx[d]);
-                    rem = q;
-                }
-                off += idx[d] * p.sy[d];
-            }
-        }
-        return off;
-    };
-    // the small operand's elements for W consecutive outputs starting at `linear` (all W must exist)
-    auto y_vec = [&](uint32_t linear, T (&dst)[W]) {
-        uint32_t idx[D];
-        uint32_t off = unravel(linear, idx);
-        dst[0] = ylds[off];
-#pragma unroll
-        for (int k = 1; k < W; ++k) {
-            bool carry = true;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (d < p.ndim && carry) {
-                    off += p.sy[d];
-                    if (++idx[d] == p.shape[d].d && d != p.ndim - 1) {
-                        idx[d] = 0;
-                        off -= p.rewind[d];
-                    } else {
-                        carry = false;
-                    }
-                }
-            }
-            dst[k] = ylds[off];
-        }
-    };
-    constexpr uint32_t kChunk = 256u * U;
-    for (uint32_t base = blockIdx.x * kChunk; base < p.n_vec; base += gridDim.x * kChunk) {
-        V xv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t v = base + u * 256u + threadIdx.x;
-            if (v < p.n_vec) xv[u] = load_stream(reinterpret_cast<const V *>(x) + v);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t v = base + u * 256u + threadIdx.x;
-            if (v < p.n_vec) {
-                T xa[W], ya[W], r[W];
-#pragma unroll
-                for (int k = 0; k < W; ++k) xa[k] = xv[u][k];
-                y_vec(v * W, ya);
-                if (SWAPPED) apply_n<Op, T, W>(ctx, ya, xa, r);
-                else apply_n<Op, T, W>(ctx, xa, ya, r);
-                V rv;
-#pragma unroll
-                for (int k = 0; k < W; ++k) rv[k] = r[k];
-                store_stream(reinterpret_cast<V *>(out) + v, rv);
-            }
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < p.n - p.n_vec * W) {
-        const uint32_t e = p.n_vec * W + threadIdx.x;
-        uint32_t idx[D];
-        const T ye = ylds[unravel(e, idx)];
-        out[e] = SWAPPED ? Op::apply(ye, x[e]) : Op::apply(x[e], ye);
-    }
+__global__ __launch_bounds__(256) void dense_lds_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out, LdsParams p) {
+    dense_lds_body<T, Op, SWAPPED, U>(x, y, out, p);
 }
-
-// ------------------------------------------------------------------ tile kernel
-// Patch shape from tools/sweep_transpose.hip (profiles/r01_sweep_transpose.txt): 64 along p x 128 along q for
-// 4-byte elements -- 256-byte segments on the strided (transposed) side, 512-byte segments on the output side,
-// consecutive workgroups walking q -- matched the plain add's rate; 64 x 64 was 8 % behind, p-fastest ordering
-// 15-25 %.  8-byte elements take 64 x 64: the same 512-byte output segments and the same 33 KiB of LDS per tile,
-// so four workgroups still fit a CU (64 x 128 doubles left room for two: 57 % of peak instead of 80 %).
-constexpr int kTileP = 64;
-template <typename T> constexpr int tile_q() { return 512 / (int)sizeof(T); }
-
-struct TileParams {
-    // plane axes: p (operand-contiguous axis), q (output inner axis)
-    uint32_t np, nq;            // extents
-    int64_t a_p, a_q, b_p, b_q; // operand strides along p and q (elements)
-    int64_t o_p;                // output stride along p (its q stride is 1)
-    int mode_a, mode_b;         // 1: turned through LDS (operand contiguous along p); 0: read along q directly
-    // remaining axes, innermost first
-    int n_rest;
-    FastDiv rest[SMHIP_MAX_NDIM - 2];
-    int64_t a_r[SMHIP_MAX_NDIM - 2], b_r[SMHIP_MAX_NDIM - 2], o_r[SMHIP_MAX_NDIM - 2];
-    uint32_t tiles_p, tiles_q;
-};
-
-// One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
-// VEC: every global access is a 16-byte vector (W elements) -- along p for operands turned through
-// LDS, along q for direct operands and the output.  LDS tiles are stored already transposed ([i][j]) in
-// a bank-conflict-free layout (`at` below; measured: profiles/r01_pmc_lds_tile_kernel.txt).  There is ONE tile: with a single LDS-mode operand it holds that operand; when both
-// operands are contiguous along p (a.T op b.T) phase 1 loads both coalesced, applies the Op there and
-// stages the RESULT, so phase 2 is a pure transposed write-out.  MA / MB are compile-time in the
-// vector form; the element form (odd extents, pitches, bases) keeps them as runtime values.
 template <typename T, typename Op, bool VEC, int MA, int MB>
-__global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
-                                                   TileParams p) {
-    constexpr int W = VEC ? VecTraits<T>::width : 1;
-    constexpr int TQ = tile_q<T>();
-    constexpr int VP = kTileP / W, VQ = TQ / W;  // vector slots per patch row, along p / along q
-    // LDS layout of element (i, j): 4-byte types get a skewed layout (one pad word per 32 columns, two per 32 rows,
-    // odd pitch) that makes both the 4-byte scatter of phase 1 and the stride-4 reads of phase 2 hit 32 distinct
-    // banks per 32-lane group; 8-byte types keep the plain padded pitch.
-    constexpr bool SKEW = sizeof(T) == 4;
-    constexpr int PITCH = SKEW ? TQ + 5 : TQ + 1;
-    auto at = [](uint32_t i, uint32_t j) -> uint32_t { return SKEW ? i * PITCH + j + (j >> 5) + ((i >> 5) << 1) : i * PITCH + j; };
-    typedef typename VecTraits<T>::vec_t V;
-    __shared__ T tile[kTileP * PITCH];
-    const int mode_a = VEC ? MA : p.mode_a, mode_b = VEC ? MB : p.mode_b;
-    const bool both = mode_a == 1 && mode_b == 1;
-    OpCtx<Op> ctx;
-    ctx.init();
-    uint32_t bid = blockIdx.x;
-    const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;
-    const uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;
-    int64_t offA = 0, offB = 0, offO = 0;
-    for (int k = 0; k < p.n_rest; ++k) {
-        uint32_t qd, idx;
-        p.rest[k].divmod(bid, qd, idx);
-        bid = qd;
-        offA += (int64_t)idx * p.a_r[k];
-        offB += (int64_t)idx * p.b_r[k];
-        offO += (int64_t)idx * p.o_r[k];
-    }
-    const uint32_t i0 = tp * kTileP, j0 = tq * TQ;
-    const bool full = i0 + kTileP <= p.np && j0 + TQ <= p.nq;  // workgroup-uniform
-    // patch origins
-    const T *a0 = a + offA + (int64_t)i0 * p.a_p + (int64_t)j0 * p.a_q;
-    const T *b0 = b + offB + (int64_t)i0 * p.b_p + (int64_t)j0 * p.b_q;
-    T *o0 = out + offO + (int64_t)i0 * p.o_p + j0;
-
-    // phase 1: LDS-mode operands, coalesced along p (slot ig covers i = ig*W .. +W-1 of row jl)
-    auto along_p = [&](const T *src0, int64_t s_q, uint32_t jl, uint32_t ig, T (&dst)[W]) {
-        const T *g = src0 + ig * W + (int64_t)jl * s_q;
-        if constexpr (VEC) {
-            // two turned streams and no reuse: nt is worth 8 % there; with one it costs (tools/sweep_transpose.hip)
-            const V val = both ? load_stream(reinterpret_cast<const V *>(g)) : *reinterpret_cast<const V *>(g);
-#pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = val[k];
-        } else {
-            dst[0] = *g;
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < TQ * VP / 256; ++s) {
-        const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
-        if (full || (i0 + ig * W < p.np && j0 + jl < p.nq)) {
-            T x[W];
-            if (both) {
-                T xa[W], xb[W];
-                along_p(a0, p.a_q, jl, ig, xa);
-                along_p(b0, p.b_q, jl, ig, xb);
-                apply_n<Op, T, W>(ctx, xa, xb, x);
-            } else if (mode_a == 1) {
-                along_p(a0, p.a_q, jl, ig, x);
-            } else {
-                along_p(b0, p.b_q, jl, ig, x);
-            }
-#pragma unroll
-            for (int k = 0; k < W; ++k) tile[at(ig * W + k, jl)] = x[k];
-        }
-    }
-    __syncthreads();
-
-    // phase 2: everything coalesced along q (slot jg covers j = jg*W .. +W-1 of row il)
-    auto along_q = [&](const T *src0, int64_t s_p, int64_t s_q, uint32_t il, uint32_t jg, T (&dst)[W]) {
-        const T *g = src0 + (int64_t)il * s_p + (int64_t)(jg * W) * s_q;
-        if (VEC && s_q == 1) {
-            const V val = load_stream(reinterpret_cast<const V *>(g));
-#pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = val[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = g[(int64_t)k * s_q];
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < kTileP * VQ / 256; ++s) {
-        const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
-        if (full || (i0 + il < p.np && j0 + jg * W < p.nq)) {
-            T xt[W], xr[W];
-#pragma unroll
-            for (int k = 0; k < W; ++k) xt[k] = tile[at(il, jg * W + k)];
-            if (both) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) xr[k] = xt[k];
-            } else if (mode_a == 1) {
-                T xb[W];
-                along_q(b0, p.b_p, p.b_q, il, jg, xb);
-                apply_n<Op, T, W>(ctx, xt, xb, xr);
-            } else {
-                T xa[W];
-                along_q(a0, p.a_p, p.a_q, il, jg, xa);
-                apply_n<Op, T, W>(ctx, xa, xt, xr);
-            }
-            T *dst = o0 + (int64_t)il * p.o_p + jg * W;
-            if constexpr (VEC) {
-                V val;
-#pragma unroll
-                for (int k = 0; k < W; ++k) val[k] = xr[k];
-                store_stream(reinterpret_cast<V *>(dst), val);
-            } else {
-                *dst = xr[0];
-            }
-        }
-    }
+__global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, TileParams p) {
+    tile_body<T, Op, VEC, MA, MB>(a, b, out, p);
 }
 
-struct Plan {
-    int ndim;
-    int64_t shape[SMHIP_MAX_NDIM], sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];
-    size_t n;
-};
+// ---------------------------------------------------------------------------- choosing a kernel
+// plan_launch() turns a normalised problem into a Launch: which body, which compile-time variant of it, the grid and the
+// parameter block.  It depends on the element type only through its size, so the built-in Ops (launch_aot below: a switch
+// over template instantiations) and user-defined Ops (jit.hip: the same variant compiled by hipRTC on first use) share it.
+}  // namespace
+
+namespace bk {
 
 // Drop size-1 dims; merge neighbours (i, i+1) when both operands satisfy
 // stride[i] == shape[i+1] * stride[i+1] (jointly dense, or jointly broadcast).
@@ -499,71 +100,19 @@ Plan normalise(const int64_t *shape, const int64_t *sa, const int64_t *sb, int n
     return p;
 }
 
-template <typename T, typename Op, int IA, int IB, bool CA, bool CB>
-int launch_row_tx(const T *a, const T *b, T *out, const RowParams &p_in, hipStream_t s) {
-    RowParams p = p_in;
-    bool too_big = false;
-    auto go2 = [&](auto tx_tag, auto rows_tag) {
-        constexpr int TX = decltype(tx_tag)::value;
-        constexpr int ROWS = decltype(rows_tag)::value;
-        constexpr int TY = 256 / TX;
-        const size_t gx = (p.vpr + TX - 1) / TX;
-        const size_t gy = ((size_t)p.rows + TY * ROWS - 1) / (TY * ROWS);
-        if (gx * gy > 0x7fffffffull) { too_big = true; return; }
-        p.grid_x = (uint32_t)gx;
-        hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, TX, ROWS>), dim3((unsigned)(gx * gy)), dim3(256), 0, s, a, b, out, p);
-    };
-    // Rows per lane (tools/bcast_matrix.py, profiles/r01_bcast_matrix.txt): two when one side is a row-constant or a
-    // per-row scalar -- two independent 16-byte loads in flight per lane, 83 % of peak on config 3 against 80 % with
-    // one or four; one when both operands stream (three full streams behave like the contiguous kernel: 80 % vs
-    // 74-77 %) and for pow, whose arithmetic already overlaps the next lane's loads.
-    constexpr bool kThreeStreams = IA == 1 && IB == 1 && !CA && !CB;
-    constexpr int kRows = (kThreeStreams || std::is_same<Op, PowOp<T>>::value) ? 1 : 2;
-    auto go = [&](auto tx_tag) { go2(tx_tag, std::integral_constant<int, kRows>{}); };
-    if (p.vpr > 128) go(std::integral_constant<int, 256>{});
-    else if (p.vpr > 64) go(std::integral_constant<int, 128>{});
-    else if (p.vpr > 32) go(std::integral_constant<int, 64>{});
-    else if (p.vpr > 16) go(std::integral_constant<int, 32>{});
-    else go(std::integral_constant<int, 16>{});
-    if (too_big) return fail(SMHIP_ERR_UNSUPPORTED, "row kernel: more than 2^31 workgroups");
-    SMHIP_LAUNCH_CHECK("row_kernel");
-    return SMHIP_OK;
-}
-
-template <typename T, typename Op>
-int launch_row(const T *a, const T *b, T *out, const RowParams &p, int ia, int ib, bool ca, bool cb, hipStream_t s) {
-    // inner (1,1): neither, one or the other operand constant over rows; (1,0)/(0,1): the
-    // broadcast side may additionally be row-constant only together with being a scalar,
-    // which normalise() has already folded away -- so CONST applies to dense sides only.
-#define ROW(IA, IB, CA, CB) return launch_row_tx<T, Op, IA, IB, CA, CB>(a, b, out, p, s)
-    if (ia == 1 && ib == 1) {
-        if (cb && !ca) ROW(1, 1, false, true);
-        if (ca && !cb) ROW(1, 1, true, false);
-        ROW(1, 1, false, false);
-    }
-    if (ia == 1 && ib == 0) {
-        if (ca) ROW(1, 0, true, false);
-        ROW(1, 0, false, false);
-    }
-    if (cb) ROW(0, 1, false, true);
-    ROW(0, 1, false, false);
-#undef ROW
-}
-
-template <typename T, typename Op>
-int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hipStream_t s) {
-    constexpr int W = VecTraits<T>::width;
-    const T *a = static_cast<const T *>(a_), *b = static_cast<const T *>(b_);
-    T *out = static_cast<T *>(out_);
+int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
+    const int W = 16 / esz;
     const int nd = pl.ndim;
     const int64_t ia = pl.sa[nd - 1], ib = pl.sb[nd - 1];
     const int64_t inner = pl.shape[nd - 1];
     const size_t rows = pl.n / (size_t)inner;
+    *L = Launch{};
 
-    const bool row_ok = (ia == 0 || ia == 1) && (ib == 0 || ib == 1) && (ia | ib) != 0 && inner >= 16 &&
+    const bool row_ok = nd >= 2 && (ia == 0 || ia == 1) && (ib == 0 || ib == 1) && (ia | ib) != 0 && inner >= 16 &&
                         rows < 0x7fffffffull && inner < 0x7fffffffll;
     if (row_ok) {
-        RowParams p{};
+        RowParams &p = L->p.row;
+        p = RowParams{};
         p.n_outer = nd - 1;
         p.rows = (uint32_t)rows;
         p.inner = (uint32_t)inner;
@@ -577,7 +126,33 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
             cb &= pl.sb[src] == 0;
         }
         p.vpr = (uint32_t)((inner + W - 1) / W);
-        return launch_row<T, Op>(a, b, out, p, (int)ia, (int)ib, ca, cb, s);
+        L->kind = Launch::kRow;
+        L->ia = (int)ia;
+        L->ib = (int)ib;
+        // inner (1,1): neither, one or the other operand constant over rows; (1,0)/(0,1): the broadcast side may be
+        // row-constant only together with being a scalar, which normalise() has folded away -- CONST is for dense sides
+        if (ia == 1 && ib == 1) {
+            if (cb && !ca) L->cb = true;
+            else if (ca && !cb) L->ca = true;
+        } else if (ia == 1) {
+            L->ca = ca;
+        } else {
+            L->cb = cb;
+        }
+        L->tx = p.vpr > 128 ? 256 : p.vpr > 64 ? 128 : p.vpr > 32 ? 64 : p.vpr > 16 ? 32 : 16;
+        // Rows per lane (tools/bcast_matrix.py, profiles/r01_bcast_matrix.txt): two when one side is a row-constant or a
+        // per-row scalar -- two independent 16-byte loads in flight per lane, 83 % of peak on config 3 against 80 % with
+        // one or four; one when both operands stream (three full streams behave like the contiguous kernel: 80 % vs
+        // 74-77 %) and for pow, whose arithmetic already overlaps the next lane's loads.
+        const bool three_streams = ia == 1 && ib == 1 && !L->ca && !L->cb;
+        L->rows = (three_streams || heavy) ? 1 : 2;
+        const int ty = 256 / L->tx;
+        const size_t gx = (p.vpr + L->tx - 1) / L->tx;
+        const size_t gy = ((size_t)p.rows + ty * L->rows - 1) / (ty * L->rows);
+        if (gx * gy > 0x7fffffffull) return fail(SMHIP_ERR_UNSUPPORTED, "row kernel: more than 2^31 workgroups");
+        p.grid_x = (uint32_t)gx;
+        L->grid = (unsigned)(gx * gy);
+        return SMHIP_OK;
     }
 
     // One operand dense in output order, the other small: stage the small one in LDS.
@@ -599,10 +174,11 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         const bool a_dense = dense_in_output_order(pl.sa), b_dense = dense_in_output_order(pl.sb);
         const int64_t span_a = span_of(pl.sa), span_b = span_of(pl.sb);
         int pick = -1;  // 0: a streams, b staged;  1: b streams, a staged
-        if (a_dense && !b_dense && span_b * (int64_t)sizeof(T) <= kLdsBytes) pick = 0;
-        else if (b_dense && !a_dense && span_a * (int64_t)sizeof(T) <= kLdsBytes) pick = 1;
+        if (a_dense && !b_dense && span_b * esz <= kLdsBytes) pick = 0;
+        else if (b_dense && !a_dense && span_a * esz <= kLdsBytes) pick = 1;
         if (pick >= 0) {
-            LdsParams lp{};
+            LdsParams &lp = L->p.lds;
+            lp = LdsParams{};
             lp.ndim = nd;
             lp.n = (uint32_t)pl.n;
             lp.n_vec = (uint32_t)(pl.n / W);
@@ -615,16 +191,16 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
             }
             // a small staged operand (<= 4 KiB) is re-staged by every workgroup of a one-shot launch, which lets
             // the hardware dispatcher balance the stream; a larger one is staged once per persistent workgroup
-            const size_t lds = (size_t)lp.y_span * sizeof(T);
-            constexpr int U = 4;  // vectors in flight per lane: 75-78 % of peak; 1: 55-65 %, 2: 73-80 %, 8: 71-74 % (tools/bcast_matrix.py)
+            const size_t lds = (size_t)lp.y_span * esz;
+            constexpr int U = kLdsVectorsInFlight;
             const size_t want = ((size_t)lp.n_vec + 256 * U - 1) / (256 * U);
             const size_t cap = lds <= 4096 ? want : (size_t)compute_units() * 8;
             size_t blocks = want < cap ? want : cap;
             if (blocks == 0) blocks = 1;  // fewer than W elements: the tail lanes of one workgroup do them
-            const unsigned grid = (unsigned)blocks;
-            if (pick == 0) hipLaunchKernelGGL((dense_lds_kernel<T, Op, false, U>), dim3(grid), dim3(256), lds, s, a, b, out, lp);
-            else hipLaunchKernelGGL((dense_lds_kernel<T, Op, true, U>), dim3(grid), dim3(256), lds, s, b, a, out, lp);
-            SMHIP_LAUNCH_CHECK("dense_lds_kernel");
+            L->kind = Launch::kLds;
+            L->swapped = pick == 1;
+            L->grid = (unsigned)blocks;
+            L->lds_bytes = lds;
             return SMHIP_OK;
         }
     }
@@ -641,7 +217,9 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
         int pa = a_strided ? contiguous_axis(pl.sa) : -1, pb = b_strided ? contiguous_axis(pl.sb) : -1;
         const int paxis = pa >= 0 ? pa : pb;
         if (paxis >= 0) {
-            TileParams t{};
+            TileParams &t = L->p.tile;
+            t = TileParams{};
+            const int tq = 512 / esz;  // tile_q<T>()
             t.np = (uint32_t)pl.shape[paxis];
             t.nq = (uint32_t)inner;
             t.a_p = pl.sa[paxis]; t.a_q = ia;
@@ -664,17 +242,15 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
                 slices *= (size_t)pl.shape[d];
             }
             t.tiles_p = (t.np + kTileP - 1) / kTileP;
-            t.tiles_q = (t.nq + tile_q<T>() - 1) / tile_q<T>();
+            t.tiles_q = (t.nq + tq - 1) / tq;
             const size_t blocks = slices * t.tiles_p * t.tiles_q;
             if (blocks < 0x7fffffffull && pl.shape[paxis] < 0x7fffffffll && inner < 0x7fffffffll) {
                 // the 16-byte form needs whole vectors along both plane axes; bases and pitches may be anything
-                const bool vec = t.np % W == 0 && t.nq % W == 0;
-                const dim3 grid((unsigned)blocks), block(256);
-                if (!vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0>), grid, block, 0, s, a, b, out, t);
-                else if (t.mode_a == 1 && t.mode_b == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1>), grid, block, 0, s, a, b, out, t);
-                else if (t.mode_a == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0>), grid, block, 0, s, a, b, out, t);
-                else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, 0, s, a, b, out, t);
-                SMHIP_LAUNCH_CHECK("tile_kernel");
+                L->kind = Launch::kTile;
+                L->vec = t.np % W == 0 && t.nq % W == 0;
+                L->ma = L->vec ? t.mode_a : 0;
+                L->mb = L->vec ? t.mode_b : 0;
+                L->grid = (unsigned)blocks;
                 return SMHIP_OK;
             }
         }
@@ -682,7 +258,8 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
 
     if (pl.n >= 0x7fffffffull)
         return fail(SMHIP_ERR_UNSUPPORTED, "gather path limited to < 2^31 elements (got %zu)", pl.n);
-    GatherParams g{};
+    GatherParams &g = L->p.gather;
+    g = GatherParams{};
     g.ndim = nd;
     g.n = (uint32_t)pl.n;
     for (int d = 0; d < nd; ++d) {
@@ -694,17 +271,87 @@ int run_broadcast(const void *a_, const void *b_, void *out_, const Plan &pl, hi
     // An operand strided along the inner axis (a[:, ::2], a channel of an interleaved image): consecutive LANES on
     // consecutive outputs keep each load instruction inside a few cache lines -- 119 us against 160 us with W outputs
     // per lane for A[:, ::2] + B[:, ::2] at 8192 x 4096.  Inner strides 0 / 1 (tiny inner extents) keep the vector store.
-    if (ia > 1 || ib > 1) {
-        const unsigned grid = (unsigned)((pl.n + 255) / 256);
-        hipLaunchKernelGGL((gather_kernel<T, Op, 1>), dim3(grid), dim3(256), 0, s, a, b, out, g);
-    } else {
-        const unsigned grid = (unsigned)(((pl.n + W - 1) / W + 255) / 256);
-        hipLaunchKernelGGL((gather_kernel<T, Op, W>), dim3(grid), dim3(256), 0, s, a, b, out, g);
-    }
-    SMHIP_LAUNCH_CHECK("gather_kernel");
+    L->kind = Launch::kGather;
+    L->w = (ia > 1 || ib > 1) ? 1 : W;
+    L->grid = (unsigned)(((pl.n + L->w - 1) / L->w + 255) / 256);
     return SMHIP_OK;
 }
 
+}  // namespace bk
+
+namespace {
+
+// Built-in Ops: the Launch's variant picks a template instantiation.
+template <typename T, typename Op>
+int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const T *a = static_cast<const T *>(a_), *b = static_cast<const T *>(b_);
+    T *out = static_cast<T *>(out_);
+    const dim3 grid(L.grid), block(256);
+    switch (L.kind) {
+        case Launch::kRow: {
+            constexpr int kRows = std::is_same<Op, PowOp<T>>::value ? 1 : 2;  // what plan_launch gives non-three-stream forms
+            bool launched = false;
+            auto go_tx = [&](auto ia_t, auto ib_t, auto ca_t, auto cb_t, auto rows_t) {
+                constexpr int IA = decltype(ia_t)::value, IB = decltype(ib_t)::value, ROWS = decltype(rows_t)::value;
+                constexpr bool CA = decltype(ca_t)::value, CB = decltype(cb_t)::value;
+                if (ROWS != L.rows) return;  // the grid was sized for L.rows: refuse rather than cover the wrong rows
+                launched = true;
+                switch (L.tx) {
+                    case 256: hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, 256, ROWS>), grid, block, 0, s, a, b, out, L.p.row); break;
+                    case 128: hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, 128, ROWS>), grid, block, 0, s, a, b, out, L.p.row); break;
+                    case 64: hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, 64, ROWS>), grid, block, 0, s, a, b, out, L.p.row); break;
+                    case 32: hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, 32, ROWS>), grid, block, 0, s, a, b, out, L.p.row); break;
+                    default: hipLaunchKernelGGL((row_kernel<T, Op, IA, IB, CA, CB, 16, ROWS>), grid, block, 0, s, a, b, out, L.p.row); break;
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using RN = std::integral_constant<int, kRows>;
+            using F = std::false_type;
+            using Tr = std::true_type;
+            if (L.ia == 1 && L.ib == 1) {
+                if (L.cb) go_tx(I1{}, I1{}, F{}, Tr{}, RN{});
+                else if (L.ca) go_tx(I1{}, I1{}, Tr{}, F{}, RN{});
+                else go_tx(I1{}, I1{}, F{}, F{}, I1{});  // three streams: one row per lane
+            } else if (L.ia == 1) {
+                if (L.ca) go_tx(I1{}, I0{}, Tr{}, F{}, RN{});
+                else go_tx(I1{}, I0{}, F{}, F{}, RN{});
+            } else {
+                if (L.cb) go_tx(I0{}, I1{}, F{}, Tr{}, RN{});
+                else go_tx(I0{}, I1{}, F{}, F{}, RN{});
+            }
+            if (!launched) return fail(SMHIP_ERR_INVALID, "row kernel: rows-per-lane mismatch between plan and launch");
+            SMHIP_LAUNCH_CHECK("row_kernel");
+            return SMHIP_OK;
+        }
+        case Launch::kLds:
+            if (!L.swapped) hipLaunchKernelGGL((dense_lds_kernel<T, Op, false, kLdsVectorsInFlight>), grid, block, L.lds_bytes, s, a, b, out, L.p.lds);
+            else hipLaunchKernelGGL((dense_lds_kernel<T, Op, true, kLdsVectorsInFlight>), grid, block, L.lds_bytes, s, b, a, out, L.p.lds);
+            SMHIP_LAUNCH_CHECK("dense_lds_kernel");
+            return SMHIP_OK;
+        case Launch::kTile:
+            if (!L.vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0>), grid, block, 0, s, a, b, out, L.p.tile);
+            else if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1>), grid, block, 0, s, a, b, out, L.p.tile);
+            else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0>), grid, block, 0, s, a, b, out, L.p.tile);
+            else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, 0, s, a, b, out, L.p.tile);
+            SMHIP_LAUNCH_CHECK("tile_kernel");
+            return SMHIP_OK;
+        case Launch::kGather:
+            if (L.w == 1) hipLaunchKernelGGL((gather_kernel<T, Op, 1>), grid, block, 0, s, a, b, out, L.p.gather);
+            else hipLaunchKernelGGL((gather_kernel<T, Op, W>), grid, block, 0, s, a, b, out, L.p.gather);
+            SMHIP_LAUNCH_CHECK("gather_kernel");
+            return SMHIP_OK;
+    }
+    return fail(SMHIP_ERR_INVALID, "broadcast: no kernel chosen");
+}
+
+template <typename T, typename Op>
+int run_broadcast(const void *a, const void *b, void *out, const Plan &pl, hipStream_t s) {
+    Launch L;
+    if (int rc = plan_launch(pl, (int)sizeof(T), std::is_same<Op, PowOp<T>>::value, &L)) return rc;
+    return launch_aot<T, Op>(L, a, b, out, s);
+}
 
 // ------------------------------------------------------------------ strided copy
 // dst[sum idx_k * sd_k] = src[sum idx_k * ss_k]: the scatter side of SMArray's element-copy assignment
