@@ -45,4 +45,8 @@ struct Launch {
 int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L);
 
 }  // namespace bk
+
+// jit.hip: one broadcast launch of a user-defined Op (the variant is compiled by hipRTC on first use)
+int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void *b, void *out, hipStream_t s);
+
 }  // namespace smhip

@@ -464,11 +464,12 @@ int copy_plan(int dtype, const void *src, void *dst, const Plan &pl, hipStream_t
 constexpr size_t kMaxLaunchElems = 0x7fffffffull;
 
 int launch_plan(int op, int dtype, const void *a, const void *b, void *out, const Plan &pl, hipStream_t s) {
+    const bool user = op >= SMHIP_OP_USER_BASE;  // a registered expression: the same kernels, compiled by hipRTC (jit.hip)
     if (pl.ndim == 1) {
         // calculate.h:10-11's fast path, decided on the normalised problem
-        if (pl.sa[0] == 1 && pl.sb[0] == 1) return launch_contiguous(op, dtype, a, b, out, pl.n, s);
-        if (pl.sa[0] == 1 && pl.sb[0] == 0) return launch_array_devscalar(op, dtype, a, b, pl.n, out, false, s);
-        if (pl.sa[0] == 0 && pl.sb[0] == 1) return launch_array_devscalar(op, dtype, b, a, pl.n, out, true, s);
+        if (pl.sa[0] == 1 && pl.sb[0] == 1) return user ? jit_contiguous(op, dtype, a, b, out, pl.n, s) : launch_contiguous(op, dtype, a, b, out, pl.n, s);
+        if (!user && pl.sa[0] == 1 && pl.sb[0] == 0) return launch_array_devscalar(op, dtype, a, b, pl.n, out, false, s);
+        if (!user && pl.sa[0] == 0 && pl.sb[0] == 1) return launch_array_devscalar(op, dtype, b, a, pl.n, out, true, s);
     }
     if (pl.n >= kMaxLaunchElems) {
         const size_t esz = dtype_size(dtype);
@@ -487,6 +488,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
             if (int rc = launch_plan(op, dtype, pa, pb, po, sub, s)) return rc;
         }
         return SMHIP_OK;
+    }
+    if (user) {
+        Launch L;
+        if (int rc = plan_launch(pl, (int)dtype_size(dtype), false, &L)) return rc;
+        return jit_launch(op, dtype, L, a, b, out, s);
     }
 #define SMHIP_DISPATCH_OP(T)                                                                   \
     switch (op) {                                                                              \

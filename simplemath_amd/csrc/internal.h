@@ -56,8 +56,6 @@ int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, 
 int jit_register(const char *expr, int *op_id);
 int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);
 int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s);
-int jit_elementwise(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb, const int64_t *shape,
-                    int ndim, void *out, hipStream_t s);
 inline bool user_op(int op) { return op >= SMHIP_OP_USER_BASE; }
 int launch_fused(int op1, int op2, int dtype, const void *a, const void *b, const void *c, const void *c_scalar_host, void *out,
                  size_t n, hipStream_t s);

@@ -6,13 +6,16 @@
 // and a g++-compiled `apply` cannot run there either -- so the device-side
 // plugin contract is one string: the Op's arithmetic as a HIP expression in
 // `a` and `b` (e.g. "(a + b) * 2").  smhip_register_op() hands back an op id;
-// the first use per element type compiles three kernels around the expression
-// for gfx950 (hiprtc -> code object -> hipModule) and caches them:
+// kernels are compiled around the expression for gfx950 on first use (hiprtc -> code object -> hipModule) and cached:
 //     contig   out[i] = a[i] op b[i]          16-byte vectors, one per lane, nt
 //     scalar   out[i] = a[i] op s  /  s op a[i]
-//     gather   the general broadcast form (fast-division unravel, vector stores)
+//     broadcast forms: the SAME row / LDS / tile / gather bodies the built-in Ops use (bcast_kernels.hip.h, embedded
+//              as text by the build), in exactly the variant broadcast.hip's plan_launch() picks for the problem; each
+//              variant is compiled when a launch first needs it.  `x.apply<MyOp>(y)` therefore runs at the rate of `x * y`
+//              on every shape (it was 2.4-3.8x slower through a generic gather: tools/jit_rates.py).
 // The built-in Ops never come through here (they are AOT kernels).
 #include <hip/hiprtc.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <map>
@@ -20,8 +23,8 @@
 #include <string>
 #include <vector>
 
-#include "internal.h"
-#include "ops.hip.h"
+#include "bcast_plan.h"
+#include "jit_sources.inc"
 
 namespace smhip {
 namespace {
@@ -29,7 +32,8 @@ namespace {
 struct UserOp {
     std::string expr;
     hipModule_t module[4] = {};  // per dtype
-    hipFunction_t contig[4] = {}, scalar[4] = {}, gather[4] = {};
+    hipFunction_t contig[4] = {}, scalar[4] = {};
+    std::map<std::string, hipFunction_t> bcast[4];  // broadcast-body variants, by instantiation text
 };
 std::mutex g_jit_mutex;
 std::vector<UserOp *> g_ops;  // id = SMHIP_OP_USER_BASE + index; never freed (ids stay valid)
@@ -67,64 +71,84 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_scalar(const T* __r
     if (i < n) out[i] = swapped ? UserOp::apply(s, a[i]) : UserOp::apply(a[i], s);
 }
 
-struct GatherParams {
-    long long sa[6], sb[6];      // innermost first
-    unsigned d[6], mul[6], shr[6];
-    int ndim;
-    unsigned n;
+)SRC";
+
+// What bcast_kernels.hip.h expects to find declared (ops.hip.h provides it ahead of time): fixed-width types, the
+// element-aligned 16-byte vector types, the streaming access macros, FastDiv (same layout as dev::FastDiv: the host fills
+// it in), and the Op plumbing -- a user Op has no per-workgroup state and is applied element by element.
+const char *kBcastPrelude = R"SRC(
+typedef __UINT32_TYPE__ uint32_t;
+typedef __INT32_TYPE__ int32_t;
+typedef __INT64_TYPE__ int64_t;
+typedef __UINT64_TYPE__ uint64_t;
+typedef __SIZE_TYPE__ size_t;
+#define SMHIP_MAX_NDIM 6
+template <typename T> struct VecTraits;
+#define SMHIP_VEC(T, N) template <> struct VecTraits<T> { typedef T full_t __attribute__((ext_vector_type(N))); \
+    typedef full_t vec_t __attribute__((aligned(sizeof(T)))); static constexpr int width = N; };
+SMHIP_VEC(float, 4) SMHIP_VEC(int32_t, 4) SMHIP_VEC(double, 2) SMHIP_VEC(int64_t, 2)
+#define load_stream(ptr) __builtin_nontemporal_load(ptr)
+#define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
+struct FastDiv {
+    uint32_t d, mul, shr;
+    __device__ FastDiv() : d(1), mul(0), shr(0) {}
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : (__umulhi(n, mul) >> shr); }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const { q = div(n); r = n - q * d; }
 };
-extern "C" __global__ __launch_bounds__(256) void smhip_user_gather(const T* __restrict__ a, const T* __restrict__ b,
-                                                                     T* __restrict__ out, GatherParams p) {
-    const unsigned linear = blockIdx.x * 256u + threadIdx.x;
-    if (linear >= p.n) return;
-    unsigned rem = linear;
-    long long offA = 0, offB = 0;
-    for (int k = 0; k < p.ndim; ++k) {
-        const unsigned q = p.d[k] == 1 ? rem : (__umulhi(rem, p.mul[k]) >> p.shr[k]);
-        const unsigned idx = rem - q * p.d[k];
-        rem = q;
-        offA += (long long)idx * p.sa[k];
-        offB += (long long)idx * p.sb[k];
-    }
-    out[linear] = UserOp::apply(a[offA], b[offB]);
+template <typename Op> struct OpCtx { __device__ __forceinline__ void init() {} };
+template <typename Op, typename T, int W>
+__device__ __forceinline__ void apply_n(const OpCtx<Op> &, const T (&a)[W], const T (&b)[W], T (&r)[W]) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);
 }
 )SRC";
 
-struct GatherParamsHost {
-    long long sa[6], sb[6];
-    unsigned d[6], mul[6], shr[6];
-    int ndim;
-    unsigned n;
-};
+const char *kBcastWrapper = R"SRC(
+typedef TYPE T;
+struct UserOp { static __device__ __forceinline__ T apply(T a, T b) { return (T)(EXPR); } };
+extern "C" __global__ __launch_bounds__(256) void smhip_user_bcast(const T* __restrict__ a, const T* __restrict__ b,
+                                                                    T* __restrict__ out, PARAMS p) {
+    BODY(a, b, out, p);
+}
+)SRC";
 
-int compile(UserOp &op, int dtype) {
-    if (op.module[dtype]) return SMHIP_OK;
+const char *kStdTypeName[4] = {"float", "double", "int32_t", "int64_t"};
+
+int hiprtc_build(const std::string &source, const std::vector<std::string> &defines, const char *what, const std::string &expr,
+                 hipModule_t *mod) {
     hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, kSource, "smhip_user_op.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    if (hiprtcCreateProgram(&prog, source.c_str(), "smhip_user_op.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(SMHIP_ERR_HIP, "hiprtcCreateProgram failed");
-    const std::string dtype_def = std::string("-DTYPE=") + kTypeName[dtype];
-    const std::string width_def = std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4");
-    const std::string expr_def = "-DEXPR=" + op.expr;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dtype_def.c_str(), width_def.c_str(), expr_def.c_str()};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 6, opts);
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+    for (const auto &d : defines) opts.push_back(d.c_str());
+    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
         std::string log(n, '\0');
         if (n) hiprtcGetProgramLog(prog, &log[0]);
         hiprtcDestroyProgram(&prog);
-        return fail(SMHIP_ERR_INVALID, "user op \"%s\" does not compile for %s: %.300s", op.expr.c_str(), kTypeName[dtype], log.c_str());
+        return fail(SMHIP_ERR_INVALID, "user op \"%s\" does not compile for %s: %.400s", expr.c_str(), what, log.c_str());
     }
     size_t size = 0;
     hiprtcGetCodeSize(prog, &size);
     std::vector<char> code(size);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    SMHIP_TRY(hipModuleLoadData(mod, code.data()));
+    return SMHIP_OK;
+}
+
+int compile(UserOp &op, int dtype) {
+    if (op.module[dtype]) return SMHIP_OK;
     hipModule_t mod;
-    SMHIP_TRY(hipModuleLoadData(&mod, code.data()));
+    if (int rc = hiprtc_build(kSource, {std::string("-DTYPE=") + kTypeName[dtype],
+                                        std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"),
+                                        "-DEXPR=" + op.expr},
+                              kTypeName[dtype], op.expr, &mod))
+        return rc;
     SMHIP_TRY(hipModuleGetFunction(&op.contig[dtype], mod, "smhip_user_contig"));
     SMHIP_TRY(hipModuleGetFunction(&op.scalar[dtype], mod, "smhip_user_scalar"));
-    SMHIP_TRY(hipModuleGetFunction(&op.gather[dtype], mod, "smhip_user_gather"));
     op.module[dtype] = mod;
     return SMHIP_OK;
 }
@@ -181,48 +205,54 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
     return SMHIP_OK;
 }
 
-int jit_elementwise(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb, const int64_t *shape,
-                    int ndim, void *out, hipStream_t s) {
-    size_t n = 1;
-    bool dense = true;
-    int64_t expect = 1;
-    for (int i = ndim - 1; i >= 0; --i) {
-        n *= (size_t)shape[i];
-        if (shape[i] != 1 && (sa[i] != expect || sb[i] != expect)) dense = false;
-        expect *= shape[i];
+// One broadcast launch of a user Op: the variant plan_launch() chose, compiled on first use.
+int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void *b, void *out, hipStream_t s) {
+    using bk::Launch;
+    char body[160];
+    const char *params = "";
+    const void *x = a, *y = b;
+    switch (L.kind) {
+        case Launch::kRow:
+            snprintf(body, sizeof body, "row_body<T,UserOp,%d,%d,%s,%s,%d,%d>", L.ia, L.ib, L.ca ? "true" : "false", L.cb ? "true" : "false", L.tx, L.rows);
+            params = "RowParams";
+            break;
+        case Launch::kLds:
+            snprintf(body, sizeof body, "dense_lds_body<T,UserOp,%s,%d>", L.swapped ? "true" : "false", bk::kLdsVectorsInFlight);
+            params = "LdsParams";
+            if (L.swapped) { x = b; y = a; }  // the streamed operand comes first
+            break;
+        case Launch::kTile:
+            snprintf(body, sizeof body, "tile_body<T,UserOp,%s,%d,%d>", L.vec ? "true" : "false", L.ma, L.mb);
+            params = "TileParams";
+            break;
+        case Launch::kGather:
+            snprintf(body, sizeof body, "gather_body<T,UserOp,%d>", L.w);
+            params = "GatherParams";
+            break;
     }
-    if (n == 0) return SMHIP_OK;
-    if (dense) return jit_contiguous(op, dtype, a, b, out, n, s);
-    if (n >= 0x7fffffffull) {  // cut along the first dimension with an extent: pieces of < 2^31 elements
-        int d = 0;
-        while (shape[d] == 1) ++d;
-        const size_t esz = dtype_size(dtype), slice = n / (size_t)shape[d];
-        const size_t per = slice >= 0x7fffffffull ? 1 : 0x7ffffffeull / slice;
-        int64_t sub[SMHIP_MAX_NDIM];
-        for (int i = 0; i < ndim; ++i) sub[i] = shape[i];
-        for (size_t i0 = 0; i0 < (size_t)shape[d]; i0 += per) {
-            const size_t left = (size_t)shape[d] - i0;
-            sub[d] = (int64_t)(left < per ? left : per);
-            if (int rc = jit_elementwise(op, dtype, static_cast<const char *>(a) + (int64_t)i0 * sa[d] * (int64_t)esz, sa,
-                                         static_cast<const char *>(b) + (int64_t)i0 * sb[d] * (int64_t)esz, sb, sub, ndim,
-                                         static_cast<char *>(out) + i0 * slice * esz, s))
+    hipFunction_t fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        const int idx = op - SMHIP_OP_USER_BASE;
+        if (idx < 0 || idx >= (int)g_ops.size()) return fail(SMHIP_ERR_INVALID, "op %d was never registered", op);
+        UserOp &u = *g_ops[idx];
+        auto it = u.bcast[dtype].find(body);
+        if (it == u.bcast[dtype].end()) {
+            const std::string source = std::string(kBcastPrelude) + kBcastKernelsSrc + kBcastWrapper;
+            hipModule_t mod;
+            if (int rc = hiprtc_build(source, {std::string("-DTYPE=") + kStdTypeName[dtype], "-DEXPR=" + u.expr, std::string("-DPARAMS=") + params,
+                                               std::string("-DBODY=") + body},
+                                      kStdTypeName[dtype], u.expr, &mod))
                 return rc;
+            SMHIP_TRY(hipModuleGetFunction(&fn, mod, "smhip_user_bcast"));
+            u.bcast[dtype][body] = fn;  // the module stays loaded for the life of the process
+        } else {
+            fn = it->second;
         }
-        return SMHIP_OK;
     }
-    UserOp *u;
-    if (int rc = lookup(op, dtype, &u)) return rc;
-    GatherParamsHost p{};
-    p.ndim = ndim;
-    p.n = (unsigned)n;
-    for (int k = 0; k < ndim; ++k) {
-        const int src = ndim - 1 - k;
-        const dev::FastDiv fd((uint32_t)shape[src]);
-        p.d[k] = fd.d; p.mul[k] = fd.mul; p.shr[k] = fd.shr;
-        p.sa[k] = sa[src]; p.sb[k] = sb[src];
-    }
-    void *args[] = {&a, &b, &out, &p};
-    SMHIP_TRY(hipModuleLaunchKernel(u->gather[dtype], (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    void *pblock = const_cast<void *>(static_cast<const void *>(&L.p));
+    void *args[] = {&x, &y, &out, pblock};
+    SMHIP_TRY(hipModuleLaunchKernel(fn, L.grid, 1, 1, 256, 1, 1, (unsigned)L.lds_bytes, s, args, nullptr));
     return SMHIP_OK;
 }
 

@@ -533,7 +533,6 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
     SMHIP_ACQUIRE(s);
-    if (user_op(op)) return jit_elementwise(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
 }
 
