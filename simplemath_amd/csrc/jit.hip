@@ -66,9 +66,16 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_contig(const T* __r
 }
 
 extern "C" __global__ __launch_bounds__(256) void smhip_user_scalar(const T* __restrict__ a, T s, T* __restrict__ out,
-                                                                     unsigned long long n, int swapped) {
+                                                                     unsigned long long n_vec, unsigned long long n, int swapped) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = swapped ? UserOp::apply(s, a[i]) : UserOp::apply(a[i], s);
+    if (i < n_vec) {
+        const V va = __builtin_nontemporal_load((const V*)a + i);
+        V r;
+        for (int k = 0; k < WIDTH; ++k) r[k] = swapped ? UserOp::apply(s, va[k]) : UserOp::apply(va[k], s);
+        __builtin_nontemporal_store(r, (V*)out + i);
+    } else if (i == n_vec) {
+        for (unsigned long long k = n_vec * WIDTH; k < n; ++k) out[k] = swapped ? UserOp::apply(s, a[k]) : UserOp::apply(a[k], s);
+    }
 }
 
 )SRC";
@@ -194,13 +201,14 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
 int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s) {
     UserOp *u;
     if (int rc = lookup(op, dtype, &u)) return rc;
-    unsigned long long nn = n;
+    const unsigned long long w = (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 2 : 4;
+    unsigned long long n_vec = n / w, nn = n;
     int swapped = 0;
-    const size_t grid = (n + 255) / 256;
+    const size_t grid = (n_vec + 1 + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
     unsigned char scalar[8];
     memcpy(scalar, value_host, dtype_size(dtype));
-    void *args[] = {&a, scalar, &out, &nn, &swapped};
+    void *args[] = {&a, scalar, &out, &n_vec, &nn, &swapped};
     SMHIP_TRY(hipModuleLaunchKernel(u->scalar[dtype], (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }
