@@ -195,6 +195,28 @@ def test_f64_pow(smhip, oracle):
     assert orc.ulp_diff_f64(got, oracle.contiguous(orc.POW, a, b)).max() <= 1
 
 
+def test_pow_exact_exponents(smhip, oracle):
+    """sm::pow(a, s) for s in {2, 1, -1, 0.5}: one correctly rounded IEEE operation each (x*x, x, 1/x, sqrt x with pow's
+    answers at -0 and -inf), so the result must equal the correctly rounded power bit for bit -- specials, denormals,
+    overflow and all -- and agree with libm's pow (the reference's PowOp<T>::apply) to <= 1 ULP."""
+    for dt, ulp in ((np.float32, orc.ulp_diff_f32), (np.float64, orc.ulp_diff_f64)):
+        a = np.concatenate([gen.gen(dt, 5000, 101, "mixed"), gen.gen(dt, 3001, 102, "positive"),
+                            np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 4.0, 1e-40, -1e-40, 3e38, -3e38], dtype=dt)])
+        da = smhip.to_device(a)
+        with np.errstate(all="ignore"):
+            sq = np.sqrt(a)
+            sq[a == 0] = 0.0          # pow(-0, 0.5) = +0
+            sq[np.isneginf(a)] = np.inf  # pow(-inf, 0.5) = +inf
+            want = {2.0: a * a, 1.0: a.copy(), -1.0: (dt(1) / a), 0.5: sq}
+        for y, w in want.items():
+            got = smhip.array_scalar(sma.OP_POW, da, dt(y)).numpy()
+            util.assert_same_bits(got, w, f"{np.dtype(dt)} ^ {y}")
+            lib = oracle.array_scalar(orc.POW, a, dt(y))
+            ok = ~(np.isnan(got) | np.isnan(lib))
+            assert np.array_equal(np.isnan(got), np.isnan(lib)), (np.dtype(dt), y)
+            assert ulp(got[ok], lib[ok]).max() <= 1, (np.dtype(dt), y)
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64", "i32", "i64"])
 def test_array_scalar_vs_oracle(smhip, oracle, dt):
     for op in ("add", "sub", "mul", "div"):
