@@ -29,3 +29,13 @@ def test_benchmark_harness_runs():
     print(r.stdout)
     assert r.returncode == 0, r.stderr
     assert "BM_SMArrayPow_Large/1000" in r.stdout
+
+
+def test_readme_example():
+    r = subprocess.run([_exe("readme_example")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    row, total, first = r.stdout.strip().rsplit(" ", 2)
+    assert row == "[2, 4, 6, 8]"
+    c = 6.0 ** 2.5 / 2.0                      # a = 3, b = a.T + a = 6, c = b^2.5 / 2; rows 0-1 of a are then set to c
+    assert abs(float(first) - (c + 6.0) * c) < 1e-2 * c
+    assert abs(float(total) - ((4096 - 2) * 4096 * 9.0 * c + 2 * 4096 * (c + 6.0) * c)) < 1e-5 * float(total)
