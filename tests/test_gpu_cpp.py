@@ -39,3 +39,15 @@ def test_readme_example():
     c = 6.0 ** 2.5 / 2.0                      # a = 3, b = a.T + a = 6, c = b^2.5 / 2; rows 0-1 of a are then set to c
     assert abs(float(first) - (c + 6.0) * c) < 1e-2 * c
     assert abs(float(total) - ((4096 - 2) * 4096 * 9.0 * c + 2 * 4096 * (c + 6.0) * c)) < 1e-5 * float(total)
+
+
+def test_pow_exhaustive_over_all_positive_floats():
+    """BASELINE config 4's exponent over EVERY positive finite float (2 139 095 039 values, denormals and the overflow /
+    underflow ranges included) against x*x*sqrt(x) in fp64: nothing beyond 1 ULP (bar: 4), >= 95 % correctly rounded."""
+    import re
+    for y, floor in (("2.5", 96.5), ("1.5", 94.5)):
+        r = subprocess.run([_exe("pow_exhaustive"), y], capture_output=True, text=True, timeout=600)
+        print(r.stdout)
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.search(r"0 ULP \d+ \(([\d.]+) %\)  1 ULP \d+ \([\d.]+ %\)  2 ULP (\d+)  >2 ULP (\d+)", r.stdout)
+        assert m and int(m.group(2)) == 0 and int(m.group(3)) == 0 and float(m.group(1)) >= floor, r.stdout
