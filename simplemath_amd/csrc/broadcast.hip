@@ -346,13 +346,6 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
     return fail(SMHIP_ERR_INVALID, "broadcast: no kernel chosen");
 }
 
-template <typename T, typename Op>
-int run_broadcast(const void *a, const void *b, void *out, const Plan &pl, hipStream_t s) {
-    Launch L;
-    if (int rc = plan_launch(pl, (int)sizeof(T), std::is_same<Op, PowOp<T>>::value, &L)) return rc;
-    return launch_aot<T, Op>(L, a, b, out, s);
-}
-
 // ------------------------------------------------------------------ strided copy
 // dst[sum idx_k * sd_k] = src[sum idx_k * ss_k]: the scatter side of SMArray's element-copy assignment
 // (`view = array`, reference SMArray.h:89-97), which the reference runs as a host loop.  Rows are the merged
@@ -489,19 +482,18 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         }
         return SMHIP_OK;
     }
-    if (user) {
-        Launch L;
-        if (int rc = plan_launch(pl, (int)dtype_size(dtype), false, &L)) return rc;
-        return jit_launch(op, dtype, L, a, b, out, s);
-    }
+    const bool heavy = op == SMHIP_OP_POW;  // launch_aot instantiates PowOp<T> with one row per lane for every T
+    Launch L;
+    if (int rc = plan_launch(pl, (int)dtype_size(dtype), heavy, &L)) return rc;
+    if (user) return jit_launch(op, dtype, L, a, b, out, s);
 #define SMHIP_DISPATCH_OP(T)                                                                   \
     switch (op) {                                                                              \
-        case SMHIP_OP_ADD: return run_broadcast<T, AddOp<T>>(a, b, out, pl, s);                \
-        case SMHIP_OP_SUB: return run_broadcast<T, SubtractOp<T>>(a, b, out, pl, s);           \
-        case SMHIP_OP_MUL: return run_broadcast<T, MultiplyOp<T>>(a, b, out, pl, s);           \
-        case SMHIP_OP_DIV: return run_broadcast<T, DivideOp<T>>(a, b, out, pl, s);             \
-        case SMHIP_OP_POW: return run_broadcast<T, PowOp<T>>(a, b, out, pl, s);                \
-        case SMHIP_OP_LEFT: return run_broadcast<T, LeftOp<T>>(a, b, out, pl, s);                \
+        case SMHIP_OP_ADD: return launch_aot<T, AddOp<T>>(L, a, b, out, s);                \
+        case SMHIP_OP_SUB: return launch_aot<T, SubtractOp<T>>(L, a, b, out, s);           \
+        case SMHIP_OP_MUL: return launch_aot<T, MultiplyOp<T>>(L, a, b, out, s);           \
+        case SMHIP_OP_DIV: return launch_aot<T, DivideOp<T>>(L, a, b, out, s);             \
+        case SMHIP_OP_POW: return launch_aot<T, PowOp<T>>(L, a, b, out, s);                \
+        case SMHIP_OP_LEFT: return launch_aot<T, LeftOp<T>>(L, a, b, out, s);                \
     }                                                                                          \
     break;
     switch (dtype) {
