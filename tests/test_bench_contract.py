@@ -41,3 +41,30 @@ def test_multi_gpu_needs_torchrun():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+import json
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_rehearsal_on_one_gpu():
+    """The multi-rank path of bench.py as the driver launches it (torch.distributed.run, one process per rank), with
+    both ranks sharing this box's one GPU and gloo standing in for RCCL (RCCL refuses two ranks on one device): the
+    JSON contract, the whole-job aggregate, and the config-5 object with its all-reduced sum."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--log2n", "24", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["elements_per_gpu"] == 1 << 24 and "x2" in d["config"]["sharding"]
+    assert abs(d["value"] - 2 * (1 << 24) / (d["ms_per_step"] * 1e-3) * 1e-9) < 1e-6 * d["value"]   # units of ALL ranks / max time
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    c5 = d["c5"]
+    # sum over both shards of (a + b), a and b uniform[-1,1): 2 * 2^24 terms of mean 0, variance 2/3 -- a 6-sigma band
+    n = 2 * (1 << 24)
+    assert abs(c5["global_sum"]) < 6 * (n * 2.0 / 3.0) ** 0.5 and c5["value"] > 0
