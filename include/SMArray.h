@@ -528,8 +528,11 @@ private:
             if (s.sliceType == Slice::INDEX) continue;
             const std::size_t stop = s.open_ended() ? _shape[axis] : s.end;
             assert(stop <= _shape[axis] && stop >= s.start && "slice end out of bounds");
-            v._shape.push_back(stop - s.start);
-            v._strides.push_back(_strides[axis]);
+            // SliceStep only names SINGLE_STEP, but the reference's view code honours any positive value stored in
+            // `step` (SMArray.h:416-424: extent = ceil(range / step), stride * step); so does this one
+            const std::size_t step = static_cast<int>(s.step) > 1 ? static_cast<std::size_t>(s.step) : 1;
+            v._shape.push_back((stop - s.start + step - 1) / step);
+            v._strides.push_back(_strides[axis] * step);
         }
         v.data = detail::HostPtr<T>(data.storage(), off);
         v.ndim = v._shape.size();

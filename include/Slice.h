@@ -4,7 +4,8 @@
 //   arr(0, SLICE_ALL)        row 0 of a 2-D array, as a view
 //   arr(SLICE(2, 5), 1)      rows 2..4 of column 1
 //
-// `end == size_t(-1)` means "to the end of the axis".  Only unit steps exist.
+// `end == size_t(-1)` means "to the end of the axis".  `step` is an enum with the single name SINGLE_STEP (= 0, a unit
+// step), as in the reference; a larger value stored in it is honoured as a stride multiplier, as the reference's view code does.
 #pragma once
 
 #include <cstddef>
