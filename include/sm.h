@@ -1,4 +1,5 @@
-// sm.h -- umbrella header: `#include <sm.h>` and link with -lsmhip.
+// sm.h -- the one header user code includes (drop-in for the reference's include/sm.h): sm::SMArray<T>, the free
+// functions, and through them the C ABI of libsmhip.so (include/smhip.h).  Link with -lsmhip.
 #pragma once
-#include "SMArray.h"
-#include "UserFunctions.h"
+
+#include "UserFunctions.h"  // brings SMArray.h, the Op policies and the loop entry points with it
