@@ -25,8 +25,21 @@ namespace {
 using namespace dev;
 
 constexpr int kBlock = 256;
-constexpr int kVecPerThread = 1;  // one 16-byte vector per lane and operand, like the streaming kernels:
-                                  // profiles/r01_sweep_fused_sum.txt -- 81.6 % of peak vs 79 % (4) / 72 % (8)
+// 16-byte vectors per lane and operand (tools/reduce_rates.py, profiles/r01_reduce_rates.txt).  Read-only streams want
+// more loads in flight than the 2R+1W streams do: a plain sum runs at 86 % of peak with two vectors per lane (65-69 %
+// with one, 82-84 % with four or eight), a dot at 84 % with two per operand (79 % with one).  The fused op+sum writes as
+// well and keeps ONE per operand like the streaming kernels (79.5 %; 75 % with two; profiles/r01_sweep_fused_sum.txt).
+#ifndef SMHIP_SUM_VECTORS
+#define SMHIP_SUM_VECTORS 2
+#endif
+#ifndef SMHIP_DOT_VECTORS
+#define SMHIP_DOT_VECTORS 2
+#endif
+#ifndef SMHIP_FUSED_VECTORS
+#define SMHIP_FUSED_VECTORS 1
+#endif
+constexpr int kSumVectors = SMHIP_SUM_VECTORS, kDotVectors = SMHIP_DOT_VECTORS;
+constexpr int vec_per_thread(int mode) { return mode == 0 /* kSum */ ? kSumVectors : mode == 1 /* kDot */ ? kDotVectors : SMHIP_FUSED_VECTORS; }
 constexpr int kFinalBlock = 1024;
 
 template <typename T> struct AccOf { typedef double type; };
@@ -107,6 +120,7 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
     typedef typename AccOf<T>::type A;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
+    constexpr int kVecPerThread = vec_per_thread(MODE);
     constexpr size_t kTile = (size_t)kBlock * kVecPerThread;
     const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
     V *ov = reinterpret_cast<V *>(out);
@@ -237,7 +251,7 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     const T *a = static_cast<const T *>(a_), *b = static_cast<const T *>(b_);
     T *out = static_cast<T *>(out_);
     const size_t n_vec = n / W;
-    const size_t tile = (size_t)kBlock * kVecPerThread;
+    const size_t tile = (size_t)kBlock * vec_per_thread(MODE);
     size_t blocks;
     blocks = n_vec / tile + 1;  // the last workgroup takes the partial tile and the n % W tail (maybe empty)
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);

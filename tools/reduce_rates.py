@@ -1,0 +1,26 @@
+"""Whole-array reductions at N = 2^28 (2^27 for 8-byte types): sum, dot, fused add+sum, async forms (no host read-back)."""
+import sys, ctypes as C
+sys.path.insert(0, "/root/repo")
+import numpy as np
+import simplemath_amd as sma
+lib = sma.load(sys.argv[1]) if len(sys.argv) > 1 else sma.load()
+def timeit(fn, steps=50):
+    for _ in range(5): fn()
+    e0, e1 = lib.event(), lib.event()
+    lib.synchronize(); lib.record(e0)
+    for _ in range(steps): fn()
+    lib.record(e1); lib.synchronize()
+    return lib.elapsed_ms(e0, e1) / steps * 1000
+print("%-34s %10s %9s %7s" % ("reduction", "us", "GB/s", "% peak"))
+for dt in (np.float32, np.float64, np.int32, np.int64):
+    n = (1 << 30) // np.dtype(dt).itemsize
+    a = lib.empty((n,), dt); b = lib.empty((n,), dt); c = lib.empty((n,), dt)
+    lib.c.smhip_fill(C.c_int(sma.DTYPES[np.dtype(dt)]), C.c_void_p(a.ptr), np.array([1], dtype=dt).ctypes.data_as(C.c_void_p), C.c_size_t(n))
+    lib.c.smhip_fill(C.c_int(sma.DTYPES[np.dtype(dt)]), C.c_void_p(b.ptr), np.array([2], dtype=dt).ctypes.data_as(C.c_void_p), C.c_size_t(n))
+    sp = lib.alloc(8)
+    esz = np.dtype(dt).itemsize
+    for name, fn, byts in (("sum", lambda: lib.sum_async(a, sp), esz * n), ("dot", lambda: lib.dot_async(a, b, sp), 2 * esz * n),
+                           ("fused add+sum", lambda: lib.contiguous_sum_async(sma.OP_ADD, a, b, c, sp), 3 * esz * n)):
+        t = timeit(fn)
+        print("%-34s %10.1f %9.0f %6.1f%%" % ("%s %s n=2^%d" % (np.dtype(dt).name, name, n.bit_length() - 1), t, byts / t * 1e-3, byts / t * 1e-3 / 80), flush=True)
+    lib.free(sp); del a, b, c
