@@ -425,10 +425,6 @@ int run_copy_strided(const void *src_, void *dst_, const Plan &pl, hipStream_t s
 
 int copy_plan(int dtype, const void *src, void *dst, const Plan &pl, hipStream_t s) {
     const size_t esz = dtype_size(dtype);
-    if (pl.ndim == 1 && pl.sa[0] == 1 && pl.sb[0] == 1) {
-        SMHIP_TRY(hipMemcpyAsync(dst, src, pl.n * esz, hipMemcpyDeviceToDevice, s));
-        return SMHIP_OK;
-    }
     if (pl.n >= 0x7fffffffull) {  // same cut as launch_plan: pieces of < 2^31 elements along the outermost axis
         const size_t slice = pl.n / (size_t)pl.shape[0];
         const size_t per = slice >= 0x7fffffffull ? 1 : 0x7ffffffeull / slice;
@@ -512,6 +508,26 @@ int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, 
                         const int64_t *shape, int ndim, hipStream_t s) {
     const Plan pl = normalise(shape, src_strides, dst_strides, ndim);  // merges axes that are jointly dense in src AND dst
     if (pl.n == 0) return SMHIP_OK;
+    // A destination that is dense in SOME axis order (a whole array, or a transposed / permuted view of one): walk the
+    // axes in the destination's order and the copy is "dense out = strided view", i.e. SMHIP_OP_LEFT through the
+    // broadcast kernels -- contiguous stream, row kernel, or the LDS tile kernel when the source is the turned side
+    // (tools/misc_rates.py: 80 % of peak where one element per lane reached 17-21 %; plain dense copies run through
+    // the array kernel at 81 % where hipMemcpyAsync device-to-device gave 67 %).
+    int order[SMHIP_MAX_NDIM];
+    for (int d = 0; d < pl.ndim; ++d) order[d] = d;
+    for (int i = 1; i < pl.ndim; ++i)  // insertion sort, destination stride descending
+        for (int j = i; j > 0 && pl.sb[order[j]] > pl.sb[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    bool dst_dense = true;
+    int64_t expect = 1;
+    for (int k = pl.ndim - 1; k >= 0; --k) {
+        if (pl.sb[order[k]] != expect) { dst_dense = false; break; }
+        expect *= pl.shape[order[k]];
+    }
+    if (dst_dense) {
+        int64_t pshape[SMHIP_MAX_NDIM], psrc[SMHIP_MAX_NDIM], zeros[SMHIP_MAX_NDIM];
+        for (int k = 0; k < pl.ndim; ++k) { pshape[k] = pl.shape[order[k]]; psrc[k] = pl.sa[order[k]]; zeros[k] = 0; }
+        return launch_plan(SMHIP_OP_LEFT, dtype, src, src, dst, normalise(pshape, psrc, zeros, pl.ndim), s);
+    }
     return copy_plan(dtype, src, dst, pl, s);
 }
 
