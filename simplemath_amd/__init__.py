@@ -158,6 +158,10 @@ class Smhip:
         host = np.ascontiguousarray(host)
         self._ck(self.c.smhip_upload(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes)))
 
+    def copy(self, dst_ptr, src_ptr, nbytes):
+        """Device-to-device copy on the library's stream."""
+        self._ck(self.c.smhip_copy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes)))
+
     def download(self, host: np.ndarray, ptr):
         assert host.flags.c_contiguous
         self._ck(self.c.smhip_download(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(host.nbytes)))

@@ -846,6 +846,18 @@ def test_fuzz_views_smoke(smhip):
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
+def test_device_copy(smhip):
+    """smhip_copy: word-sized copies run through the streaming kernel, anything else through the runtime's memcpy."""
+    src = gen.gen(np.int32, 100003, 111, "wide")
+    d = smhip.to_device(src)
+    for nbytes, so, do in ((4 * 100003, 0, 0), (4 * 4099, 4 * 3, 4 * 1), (4, 8, 0), (1001, 0, 0), (4000, 2, 6)):
+        out = smhip.to_device(np.zeros(100003, np.int32))
+        smhip.copy(out.ptr + do, d.ptr + so, nbytes)
+        want = np.zeros(100003, np.int32).view(np.uint8)
+        want[do:do + nbytes] = src.view(np.uint8)[so:so + nbytes]
+        assert np.array_equal(out.numpy().view(np.uint8), want), (nbytes, so, do)
+
+
 def test_errors(smhip):
     a = smhip.to_device(np.zeros((2, 3), dtype=np.float32))
     b = smhip.to_device(np.zeros((4, 3), dtype=np.float32))
