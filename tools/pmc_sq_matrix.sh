@@ -6,7 +6,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d $out/pmc_sq_matrix -- \
-  python3 $GRAFT_REPO_ROOT/tools/bcast_matrix.py > $out/pmc_sq_matrix.log 2>&1
+  python3 $GRAFT_REPO_ROOT/${SM_SCRIPT:-tools/bcast_matrix.py} > $out/pmc_sq_matrix.log 2>&1
 echo "rc=$?"
 cd $GRAFT_REPO_ROOT
 f=$(find $out/pmc_sq_matrix -name "*counter_collection.csv" | head -1)
