@@ -18,6 +18,10 @@ def t(a, y=2.5, steps=300):
     return lib.elapsed_ms(e0, e1) / steps * 1000
 rnd = lib.uniform_f32(n, 5, 0.01, 100.0)
 narrow = lib.uniform_f32(n, 5, 1.70, 1.71)
-const = lib.empty((n,), np.float32); lib.fill(const, np.float32(1.7)) if hasattr(lib, "fill") else None
+const = lib.empty((n,), np.float32)
+lib.c.smhip_fill(C.c_int(0), C.c_void_p(const.ptr), np.array([1.7], dtype=np.float32).ctypes.data_as(C.c_void_p), C.c_size_t(n))
 print("random (0.01, 100): %.1f us" % t(rnd))
 print("narrow (1.70, 1.71): %.1f us" % t(narrow))
+print("constant 1.7: %.1f us" % t(const))
+wide = lib.uniform_f32(n, 9, 1e-30, 1e30)
+print("uniform (1e-30, 1e30) [still mostly one binade]: %.1f us" % t(wide))
