@@ -146,7 +146,10 @@ __global__ __launch_bounds__(kHeavyBlock) void heavy_vec_kernel(const T *__restr
 }
 
 template <typename Op> struct IsHeavy : std::false_type {};
-template <typename T> struct IsHeavy<PowOp<T>> : std::true_type {};
+// float / double pow only: integer pow is a short square-and-multiply loop, and the plain launch beats the pipelined one on
+// it for every exponent distribution tried (tools/ipow_exp.py: 80 % vs 64 % of peak for exponents < 32, 42 % vs 40 % for
+// 20-bit exponents)
+template <typename T> struct IsHeavy<PowOp<T>> : std::integral_constant<bool, std::is_floating_point<T>::value> {};
 
 inline unsigned heavy_grid(size_t n_vec) {
     const size_t want = (n_vec + kHeavyBlock - 1) / kHeavyBlock;
@@ -220,7 +223,8 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
             return SMHIP_OK;
         }
     }
-    if constexpr (IsHeavy<Op>::value) {
+    constexpr bool kHeavy = IsHeavy<Op>::value;
+    if constexpr (kHeavy) {
         hipLaunchKernelGGL((heavy_vec_kernel<T, Op, SWAPPED ? 2 : 1>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa,
                            static_cast<const T *>(nullptr), value, po, n_vec, tail);
     } else {
