@@ -290,7 +290,7 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
     const dim3 grid(L.grid), block(256);
     switch (L.kind) {
         case Launch::kRow: {
-            constexpr int kRows = std::is_same<Op, PowOp<T>>::value ? 1 : 2;  // what plan_launch gives non-three-stream forms
+            constexpr int kRows = (std::is_same<Op, PowOp<T>>::value && std::is_floating_point<T>::value) ? 1 : 2;  // what plan_launch gives non-three-stream forms
             bool launched = false;
             auto go_tx = [&](auto ia_t, auto ib_t, auto ca_t, auto cb_t, auto rows_t) {
                 constexpr int IA = decltype(ia_t)::value, IB = decltype(ib_t)::value, ROWS = decltype(rows_t)::value;
@@ -478,7 +478,7 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         }
         return SMHIP_OK;
     }
-    const bool heavy = op == SMHIP_OP_POW;  // launch_aot instantiates PowOp<T> with one row per lane for every T
+    const bool heavy = op == SMHIP_OP_POW && (dtype == SMHIP_F32 || dtype == SMHIP_F64);  // as launch_aot's kRows: float / double pow only
     Launch L;
     if (int rc = plan_launch(pl, (int)dtype_size(dtype), heavy, &L)) return rc;
     if (user) return jit_launch(op, dtype, L, a, b, out, s);
