@@ -214,14 +214,23 @@ inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<
 // the real and imaginary sums, grid-stride, then the same wave / LDS / partials tree.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a, const dbl2 *__restrict__ b, size_t n,
-                                                      double *__restrict__ partials) {
+                                                      double *__restrict__ partials, size_t blocks) {
+    // one-shot like reduce_kernel: a workgroup owns kBlock * 2 consecutive elements, two per lane and operand in flight;
+    // its partial sums go to partials[block] (real) and partials[blocks + block] (imaginary)
     double re = 0.0, im = 0.0;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        const dbl2 x = load_stream(a + i), y = load_stream(b + i);
+    auto acc = [&](dbl2 x, dbl2 y) {
         re = __builtin_fma(x[0], y[0], re);
         re = __builtin_fma(-x[1], y[1], re);
         im = __builtin_fma(x[0], y[1], im);
         im = __builtin_fma(x[1], y[0], im);
+    };
+    const size_t i0 = (size_t)blockIdx.x * (kBlock * 2) + threadIdx.x, i1 = i0 + kBlock;
+    if (i1 < n) {
+        const dbl2 x0 = load_stream(a + i0), y0 = load_stream(b + i0), x1 = load_stream(a + i1), y1 = load_stream(b + i1);
+        acc(x0, y0);
+        acc(x1, y1);
+    } else if (i0 < n) {
+        acc(load_stream(a + i0), load_stream(b + i0));
     }
     __shared__ double lds[2][kBlock / 64];
     re = wave_reduce(re);
@@ -232,13 +241,14 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
     if (threadIdx.x == 0) {
         double r = 0.0, m = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) { r += lds[0][w]; m += lds[1][w]; }
-        partials[2 * blockIdx.x] = r;
-        partials[2 * blockIdx.x + 1] = m;
+        partials[blockIdx.x] = r;
+        partials[blocks + blockIdx.x] = m;
     }
 }
-__global__ __launch_bounds__(64) void cdot_finalize_kernel(const double *__restrict__ partials, size_t blocks, double *__restrict__ out2) {
+__global__ __launch_bounds__(64) void cdot_finalize_kernel(const double *__restrict__ re_parts, const double *__restrict__ im_parts,
+                                                           size_t count, double *__restrict__ out2) {
     double re = 0.0, im = 0.0;
-    for (size_t i = threadIdx.x; i < blocks; i += 64) { re += partials[2 * i]; im += partials[2 * i + 1]; }
+    for (size_t i = threadIdx.x; i < count; i += 64) { re += re_parts[i]; im += im_parts[i]; }
     re = wave_reduce(re);
     im = wave_reduce(im);
     if (threadIdx.x == 0) { out2[0] = re; out2[1] = im; }
@@ -295,14 +305,23 @@ int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out8_d
 }
 
 int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s) {
-    size_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks == 0) blocks = 1;
+    const size_t blocks = n / (kBlock * 2) + 1;
+    if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "complex dot too large (%zu workgroups)", blocks);
+    const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
     double *scratch;
-    if (int rc = reduce_scratch(2 * blocks, &scratch)) return rc;
-    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch);
+    if (int rc = reduce_scratch(2 * blocks + 2 * folded, &scratch)) return rc;
+    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, blocks);
     SMHIP_LAUNCH_CHECK("cdot");
-    hipLaunchKernelGGL(cdot_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, out2_dev);
+    const double *re = scratch, *im = scratch + blocks;
+    size_t count = blocks;
+    if (blocks > (size_t)kFoldSpan) {  // fixed-order fold of the two partial arrays, as in run_reduce
+        double *fre = scratch + 2 * blocks, *fim = fre + folded;
+        hipLaunchKernelGGL(fold_kernel<double>, dim3((unsigned)folded), dim3(kBlock), 0, s, re, blocks, fre);
+        hipLaunchKernelGGL(fold_kernel<double>, dim3((unsigned)folded), dim3(kBlock), 0, s, im, blocks, fim);
+        SMHIP_LAUNCH_CHECK("cdot fold");
+        re = fre; im = fim; count = folded;
+    }
+    hipLaunchKernelGGL(cdot_finalize_kernel, dim3(1), dim3(64), 0, s, re, im, count, out2_dev);
     SMHIP_LAUNCH_CHECK("cdot finalize");
     return SMHIP_OK;
 }

@@ -2,7 +2,7 @@ import sys, ctypes as C
 sys.path.insert(0, "/root/repo")
 import numpy as np
 import simplemath_amd as sma
-lib = sma.load()
+lib = sma.load(sys.argv[1]) if len(sys.argv) > 1 else sma.load()
 n = 1 << 26
 a = lib.empty((n,), np.float64); out = lib.empty((n,), np.float64)
 h = np.random.default_rng(1).uniform(0.01, 100.0, 1 << 20)
