@@ -59,8 +59,10 @@ typedef enum smhip_op {
  * Op's device form is its arithmetic as a HIP expression in `a` and `b` of the element type, e.g.
  * "(a + b) * 2".  smhip_register_op returns an id >= SMHIP_OP_USER_BASE that smhip_elementwise,
  * smhip_contiguous and smhip_array_scalar accept as `op`; kernels are compiled for gfx950 with hipRTC on
- * first use per element type and cached for the life of the process.  A string that does not compile
- * fails that first use with SMHIP_ERR_INVALID and the compiler's message. */
+ * first use per element type and kernel variant, kept loaded for the life of the process, and their code objects are
+ * cached on disk ($SMHIP_JIT_CACHE, default $XDG_CACHE_HOME/smhip or ~/.cache/smhip; "off" disables) so later
+ * processes skip the compile.  A string that does not compile fails that first use with SMHIP_ERR_INVALID and the
+ * compiler's message. */
 #define SMHIP_OP_USER_BASE 100
 int smhip_register_op(const char *hip_expression, int *op_id);
 

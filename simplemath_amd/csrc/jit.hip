@@ -16,7 +16,10 @@
 // The built-in Ops never come through here (they are AOT kernels).
 #include <hip/hiprtc.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <map>
 #include <mutex>
@@ -121,8 +124,59 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_bcast(const T* __re
 
 const char *kStdTypeName[4] = {"float", "double", "int32_t", "int64_t"};
 
+// Code objects are cached on disk, keyed by a hash of (library version, source text, options): a program that registers the
+// same Ops on every run pays the ~0.3 s of hipRTC per kernel variant once per machine, not once per process.
+// SMHIP_JIT_CACHE=<dir> moves the cache (default $XDG_CACHE_HOME/smhip or ~/.cache/smhip); SMHIP_JIT_CACHE=off disables it.
+std::string cache_dir() {
+    const char *env = getenv("SMHIP_JIT_CACHE");
+    if (env && (!strcmp(env, "off") || !strcmp(env, "0") || !*env)) return "";
+    std::string dir;
+    if (env) dir = env;
+    else if (const char *x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/smhip";
+    else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/smhip";
+    else return "";
+    std::string partial;
+    for (size_t i = 0; i <= dir.size(); ++i) {  // mkdir -p
+        if (i == dir.size() || dir[i] == '/') {
+            if (!partial.empty()) mkdir(partial.c_str(), 0755);
+        }
+        if (i < dir.size()) partial += dir[i];
+    }
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || access(dir.c_str(), W_OK) != 0) return "";
+    return dir;
+}
+
+uint64_t fnv1a(uint64_t h, const std::string &s) {
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ULL; }
+    return h ^ 0xff;  // separator between fields
+}
+
 int hiprtc_build(const std::string &source, const std::vector<std::string> &defines, const char *what, const std::string &expr,
                  hipModule_t *mod) {
+    static const std::string dir = cache_dir();
+    std::string path;
+    if (!dir.empty()) {
+        int rtc_major = 0, rtc_minor = 0;
+        hiprtcVersion(&rtc_major, &rtc_minor);
+        char tag[96];
+        snprintf(tag, sizeof tag, "%s hiprtc %d.%d -O3 -ffp-contract=off -std=c++17", smhip_version(), rtc_major, rtc_minor);
+        uint64_t h = fnv1a(0xcbf29ce484222325ULL, tag);
+        h = fnv1a(h, source);
+        for (const auto &d : defines) h = fnv1a(h, d);
+        char name[64];
+        snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+        path = dir + name;
+        if (FILE *f = fopen(path.c_str(), "rb")) {
+            std::vector<char> code;
+            char buf[65536];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + got);
+            fclose(f);
+            if (!code.empty() && hipModuleLoadData(mod, code.data()) == hipSuccess) return SMHIP_OK;
+            // unreadable or stale entry: fall through and rebuild it
+        }
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, source.c_str(), "smhip_user_op.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(SMHIP_ERR_HIP, "hiprtcCreateProgram failed");
@@ -143,6 +197,16 @@ int hiprtc_build(const std::string &source, const std::vector<std::string> &defi
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     SMHIP_TRY(hipModuleLoadData(mod, code.data()));
+    if (!path.empty()) {  // publish atomically: write a private file, then rename it into place
+        char tmp[32];
+        snprintf(tmp, sizeof tmp, ".%ld.tmp", (long)getpid());
+        const std::string tpath = path + tmp;
+        if (FILE *f = fopen(tpath.c_str(), "wb")) {
+            const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+            fclose(f);
+            if (!ok || rename(tpath.c_str(), path.c_str()) != 0) remove(tpath.c_str());
+        }
+    }
     return SMHIP_OK;
 }
 

@@ -473,6 +473,38 @@ def test_user_op_runs_the_broadcast_kernels(smhip, oracle):
             util.assert_same_bits(got, oracle.binary(orc.MUL, av, bv), f"{dtn} vs oracle {av.shape} x {bv.shape}")
 
 
+def test_jit_disk_cache(tmp_path):
+    """hipRTC code objects are cached on disk (SMHIP_JIT_CACHE): a second process finds them, computes the same values and
+    compiles nothing; SMHIP_JIT_CACHE=off leaves no files."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, time; sys.path.insert(0, %r); import numpy as np, simplemath_amd as sma; lib = sma.load();"
+            "op = lib.register_op('(a + b) * 3'); a = lib.to_device(np.arange(4096, dtype=np.float32).reshape(64, 64));"
+            "r = lib.to_device(np.ones((1, 64), dtype=np.float32)); t = time.perf_counter();"
+            "out = lib.binary(op, a, r).numpy(); c = lib.contiguous(op, a, a).numpy(); dt = time.perf_counter() - t;"
+            "print(float(out.sum()), float(c.sum()), dt)" % root)
+    def run(cache):
+        env = dict(os.environ, SMHIP_JIT_CACHE=cache)
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        a, b, dt = r.stdout.split()
+        return float(a), float(b), float(dt)
+    cache = str(tmp_path / "jit")
+    first = run(cache)
+    files = sorted(os.listdir(cache))
+    assert len(files) >= 2 and all(f.endswith(".hsaco") for f in files), files
+    second = run(cache)
+    assert sorted(os.listdir(cache)) == files            # nothing new was compiled
+    assert first[:2] == second[:2] == (float((np.arange(4096) + 1).sum() * 3), float(np.arange(4096).sum() * 6))
+    assert second[2] < first[2]                          # and the cached run did not pay for hipRTC
+    off = str(tmp_path / "off")
+    os.mkdir(off)
+    env_run = run("off")
+    assert env_run[:2] == first[:2] and os.listdir(off) == []
+
+
 def test_left_op_gathers_views(smhip):
     """SMHIP_OP_LEFT (out = a): the dense copy of strided / broadcast views that contiguous() and repeat()
     are built from; bit-exact including NaN payloads (nothing is computed)."""
