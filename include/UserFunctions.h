@@ -69,6 +69,34 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, T c) {
     return a.template apply<Op1>(b).template apply_scalar<Op2>(c);
 }
 
+// A whole expression in ONE pass over HBM: sm::expr("(a0 + a1) * a2 - 3 * a3", a, b, c, d).  The operands appear as
+// a0 .. a7 in a HIP expression of the element type; all must have the same shape (views are made dense first).  Each
+// operation rounds as the separate operators do, so the values equal the operator chain's; the traffic is
+// (k + 1) * sizeof(T) bytes per element instead of 3 * sizeof(T) per operator.  Compiled by hipRTC on first use, cached.
+template <typename T, typename... Rest>
+SMArray<T> expr(const char *expression, const SMArray<T> &first, const Rest &...rest) {
+    static_assert(hip::dtype_of<T>::id >= 0, "sm::expr: element type has no kernels");
+    static_assert(sizeof...(Rest) <= 7, "sm::expr: at most 8 operands");
+    static_assert((std::is_same_v<Rest, SMArray<T>> && ...), "sm::expr: operands must be SMArray<T> of one element type");
+    const SMArray<T> *arrays[] = {&first, &rest...};
+    constexpr int n = 1 + static_cast<int>(sizeof...(Rest));
+    std::vector<SMArray<T>> dense;  // dense copies of strided operands, kept alive until the launch is queued
+    dense.reserve(n);
+    const void *ptrs[8] = {};
+    for (int k = 0; k < n; ++k) {
+        if (arrays[k]->shape() != first.shape()) throw std::runtime_error("sm::expr: operands must have the same shape");
+        if (arrays[k]->is_dense()) {
+            ptrs[k] = arrays[k]->device_data();
+        } else {
+            dense.push_back(arrays[k]->contiguous());
+            ptrs[k] = dense.back().device_data();
+        }
+    }
+    SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(first.shape()));
+    hip::check(smhip_fused_expr(expression, hip::dtype_of<T>::id, ptrs, n, out.device_data_mut(), first.totalSize));
+    return out;
+}
+
 // Sum of all elements in fp64 (BASELINE config 5's reduction; no reference counterpart).
 template <typename T>
 double sum(const SMArray<T> &arr) {

@@ -83,6 +83,37 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_scalar(const T* __r
 
 )SRC";
 
+// N-ary fused expressions (smhip_fused_expr): out[i] = EXPR(a0[i], ..., a7[i]) over dense operands in ONE pass --
+// (k + 1) * sizeof(T) bytes per element instead of 3 * sizeof(T) per operator of the chain it replaces.
+const char *kExprSource = R"SRC(
+typedef TYPE T;
+typedef T V0 __attribute__((ext_vector_type(WIDTH)));
+typedef V0 V __attribute__((aligned(sizeof(T))));
+struct Operands { const T* p[8]; };
+__device__ __forceinline__ T smhip_eval(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7) { return (T)(EXPR); }
+extern "C" __global__ __launch_bounds__(256) void smhip_user_expr(Operands in, T* __restrict__ out, unsigned long long n_vec,
+                                                                   unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_vec) {
+        V v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < NOPS) v[k] = __builtin_nontemporal_load((const V*)in.p[k] + i);
+            else v[k] = v[0];
+        V r;
+#pragma unroll
+        for (int e = 0; e < WIDTH; ++e) r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e]);
+        __builtin_nontemporal_store(r, (V*)out + i);
+    } else if (i == n_vec) {
+        for (unsigned long long j = n_vec * WIDTH; j < n; ++j) {
+            T x[8];
+            for (int k = 0; k < 8; ++k) x[k] = in.p[k < NOPS ? k : 0][j];
+            out[j] = smhip_eval(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+        }
+    }
+}
+)SRC";
+
 // What bcast_kernels.hip.h expects to find declared (ops.hip.h provides it ahead of time): fixed-width types, the
 // element-aligned 16-byte vector types, the streaming access macros, FastDiv (same layout as dev::FastDiv: the host fills
 // it in), and the Op plumbing -- a user Op has no per-workgroup state and is applied element by element.
@@ -325,6 +356,45 @@ int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void
     void *pblock = const_cast<void *>(static_cast<const void *>(&L.p));
     void *args[] = {&x, &y, &out, pblock};
     SMHIP_TRY(hipModuleLaunchKernel(fn, L.grid, 1, 1, 256, 1, 1, (unsigned)L.lds_bytes, s, args, nullptr));
+    return SMHIP_OK;
+}
+
+namespace {
+struct ExprKernel { hipFunction_t fn = nullptr; };
+std::map<std::string, ExprKernel> g_exprs;  // key: dtype | operand count | expression
+}  // namespace
+
+int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, void *out, size_t n, hipStream_t s) {
+    hipFunction_t fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        char head[32];
+        snprintf(head, sizeof head, "%d|%d|", dtype, n_operands);
+        const std::string key = std::string(head) + expr;
+        auto it = g_exprs.find(key);
+        if (it == g_exprs.end()) {
+            char nops[24];
+            snprintf(nops, sizeof nops, "-DNOPS=%d", n_operands);
+            hipModule_t mod;
+            if (int rc = hiprtc_build(kExprSource, {std::string("-DTYPE=") + kTypeName[dtype],
+                                                    std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"), nops,
+                                                    std::string("-DEXPR=") + expr},
+                                      kTypeName[dtype], expr, &mod))
+                return rc;
+            SMHIP_TRY(hipModuleGetFunction(&fn, mod, "smhip_user_expr"));
+            g_exprs[key].fn = fn;
+        } else {
+            fn = it->second.fn;
+        }
+    }
+    struct { const void *p[8]; } in;
+    for (int k = 0; k < 8; ++k) in.p[k] = operands[k < n_operands ? k : 0];
+    const unsigned long long w = (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 2 : 4;
+    unsigned long long n_vec = n / w, nn = n;
+    const size_t grid = (n_vec + 1 + 255) / 256;
+    if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused expression: array too large for one launch");
+    void *args[] = {&in, &out, &n_vec, &nn};
+    SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }
 

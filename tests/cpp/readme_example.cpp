@@ -12,6 +12,8 @@ int main() {
     a(SLICE(0, 2), SLICE_ALL) = c(SLICE(2, 4), SLICE_ALL);
     auto d = a.apply<Hypot2<float>>(c);
     auto e = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, c);
+    auto f = sm::expr("(a0 + a1) * a2 - 3 * a3", a, b, c, d);
+    (void)f;
     double total = sm::sum(e);
     float first = e(0, 0);
     std::cout << row * 2.0f << " " << total << " " << first << "\n";

@@ -448,6 +448,20 @@ TEST(FusionHook) {
     auto rb = sm::fused<AddOp<float>, MultiplyOp<float>>(m, row, m);  // broadcast: evaluated as two calls, same values
     CHECK_EQ(rb(1, 1), (4.0f + 20.0f) * 4.0f);
 }
+TEST(FusedExpression) {
+    auto a = sm::ones<float>(300, 200) * 2.0f, b = sm::ones<float>(300, 200) * 3.0f, c = sm::ones<float>(300, 200) * 4.0f;
+    sm::SMArray<float> d = sm::ones<float>(200, 300) * 0.5f;
+    auto r = sm::expr("(a0 + a1) * a2 - 3 * a3", a, b, c, d.transpose());   // one pass; the transposed view is made dense
+    auto chain = (a + b) * c - d.transpose() * 3.0f;
+    CHECK_EQ(r(0, 0), 18.5f); CHECK_EQ(r(299, 199), 18.5f);
+    CHECK_EQ(sm::sum(r), sm::sum(chain));
+    sm::SMArray<int> i = {1, 2, 3}, j = {10, 20, 30};
+    auto k = sm::expr("a0 * a1 + (a0 > 1 ? 100 : 0)", i, j);
+    CHECK_EQ(k(0), 10); CHECK_EQ(k(1), 140); CHECK_EQ(k(2), 190);
+    bool threw = false;
+    try { auto bad = sm::expr("a0 + a1", a, d); (void)bad; } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+}
 TEST(ThreadsShareTheLibrary) {
     // the C ABI is callable from any host thread (per-thread device/stream selection, locked allocator)
     std::vector<std::thread> pool;

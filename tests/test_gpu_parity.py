@@ -505,6 +505,28 @@ def test_jit_disk_cache(tmp_path):
     assert env_run[:2] == first[:2] and os.listdir(off) == []
 
 
+def test_fused_expression_equals_the_operator_chain(smhip, oracle):
+    """smhip_fused_expr: a whole expression in one pass must give the operator chain's values bit for bit (every
+    operation rounds separately: no contraction), for every element type, every tail length, up to eight operands."""
+    for dtn in ("f32", "f64", "i32", "i64"):
+        dt = DT[dtn]
+        for n in (1, 3, 4099, 100001):
+            xs = [gen.gen(dt, n, 120 + k, "nonzero" if dtn[0] == "i" else "uniform") for k in range(8)]
+            ds = [smhip.to_device(x) for x in xs]
+            got = smhip.fused_expr("(a0 + a1) * a2 - a3", *ds[:4]).numpy()
+            want = oracle.contiguous(orc.SUB, oracle.contiguous(orc.MUL, oracle.contiguous(orc.ADD, xs[0], xs[1]), xs[2]), xs[3])
+            util.assert_same_bits(got, want, f"{dtn} n={n} four operands")
+            got = smhip.fused_expr("a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7", *ds).numpy()
+            want = xs[0]
+            for k in range(1, 8):
+                want = oracle.contiguous(orc.ADD, want, xs[k])
+            util.assert_same_bits(got, want, f"{dtn} n={n} eight operands")
+            got = smhip.fused_expr("a0 * a0", ds[0]).numpy()
+            util.assert_same_bits(got, oracle.contiguous(orc.MUL, xs[0], xs[0]), f"{dtn} n={n} one operand")
+    with pytest.raises(sma.SmhipError):
+        smhip.fused_expr("a0 +* a1", ds[0], ds[1])
+
+
 def test_left_op_gathers_views(smhip):
     """SMHIP_OP_LEFT (out = a): the dense copy of strided / broadcast views that contiguous() and repeat()
     are built from; bit-exact including NaN payloads (nothing is computed)."""
