@@ -7,6 +7,7 @@
 // touches `data` or operator()(i...).
 #pragma once
 
+#include <initializer_list>
 #include <ostream>
 #include <vector>
 
@@ -73,11 +74,14 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, T c) {
 // a0 .. a7 in a HIP expression of the element type; all must have the same shape (views are made dense first).  Each
 // operation rounds as the separate operators do, so the values equal the operator chain's; the traffic is
 // (k + 1) * sizeof(T) bytes per element instead of 3 * sizeof(T) per operator.  Compiled by hipRTC on first use, cached.
+// Run-time scalars appear as s0 .. s3 and are passed at launch (changing them does not recompile):
+//     sm::expr("a0 * s0 + a1", {alpha}, x, y)        // axpy in one pass
 template <typename T, typename... Rest>
-SMArray<T> expr(const char *expression, const SMArray<T> &first, const Rest &...rest) {
+SMArray<T> expr(const char *expression, std::initializer_list<T> scalars, const SMArray<T> &first, const Rest &...rest) {
     static_assert(hip::dtype_of<T>::id >= 0, "sm::expr: element type has no kernels");
     static_assert(sizeof...(Rest) <= 7, "sm::expr: at most 8 operands");
     static_assert((std::is_same_v<Rest, SMArray<T>> && ...), "sm::expr: operands must be SMArray<T> of one element type");
+    if (scalars.size() > 4) throw std::runtime_error("sm::expr: at most 4 scalars");
     const SMArray<T> *arrays[] = {&first, &rest...};
     constexpr int n = 1 + static_cast<int>(sizeof...(Rest));
     std::vector<SMArray<T>> dense;  // dense copies of strided operands, kept alive until the launch is queued
@@ -93,8 +97,13 @@ SMArray<T> expr(const char *expression, const SMArray<T> &first, const Rest &...
         }
     }
     SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(first.shape()));
-    hip::check(smhip_fused_expr(expression, hip::dtype_of<T>::id, ptrs, n, out.device_data_mut(), first.totalSize));
+    hip::check(smhip_fused_expr(expression, hip::dtype_of<T>::id, ptrs, n, scalars.size() ? scalars.begin() : nullptr,
+                                static_cast<int>(scalars.size()), out.device_data_mut(), first.totalSize));
     return out;
+}
+template <typename T, typename... Rest>
+SMArray<T> expr(const char *expression, const SMArray<T> &first, const Rest &...rest) {
+    return expr<T>(expression, std::initializer_list<T>{}, first, rest...);
 }
 
 // Sum of all elements in fp64 (BASELINE config 5's reduction; no reference counterpart).

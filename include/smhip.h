@@ -120,11 +120,13 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
                       const void *b, const int64_t *stride_b,
                       const int64_t *shape, int ndim, void *out);
 /* A whole expression in one pass: out[i] = EXPR(a0[i], ..., a{k-1}[i]) over k <= 8 dense operands of n elements each,
- * EXPR a HIP expression in a0..a7 of the element type, e.g. "(a0 + a1) * a2 - 3 * a3".  (k + 1) * sizeof(T) bytes per
+ * EXPR a HIP expression in a0..a7 and the scalars s0..s3 (n_scalars <= 4 values of the element type in host memory, passed
+ * at launch: changing them does not recompile), e.g. "(a0 + a1) * a2 - s0 * a3".  (k + 1) * sizeof(T) bytes per
  * element instead of 3 * sizeof(T) per operator of the chain it replaces (the reference evaluates such a chain as one
  * operator call and one temporary per step, SMArray.h:217-305).  Compiled by hipRTC on first use, cached like
  * smhip_register_op's kernels; each operation rounds as the separate operators do (no contraction). */
-int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, void *out, size_t n);
+int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, const void *scalars_host,
+                     int n_scalars, void *out, size_t n);
 /* SMArray's element-copy assignment `dst_view = src` (SMArray.h:89-97, a host loop in the reference):
  * dst[sum idx_k*dst_strides_k] = src[sum idx_k*src_strides_k] over `shape`.  A source stride may be 0 (broadcast);
  * a destination stride may not (for extents > 1).  Source and destination must not overlap. */

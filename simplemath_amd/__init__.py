@@ -272,14 +272,16 @@ class Smhip:
                                                C.c_void_p(b.ptr), cp, sp, C.c_void_p(out.ptr), C.c_size_t(a.size)))
         return out
 
-    def fused_expr(self, expression: str, *arrays: DeviceArray, out: DeviceArray | None = None):
-        """out = EXPR(a0, a1, ...) in one pass over dense, equal-sized operands (smhip_fused_expr)."""
+    def fused_expr(self, expression: str, *arrays: DeviceArray, scalars=(), out: DeviceArray | None = None):
+        """out = EXPR(a0, a1, ..., s0, ...) in one pass over dense, equal-sized operands (smhip_fused_expr)."""
         a0 = arrays[0]
         assert all(a.dtype == a0.dtype and a.size == a0.size and a.is_dense() for a in arrays)
         if out is None:
             out = self.empty(a0.shape, a0.dtype)
         ptrs = (C.c_void_p * len(arrays))(*[a.ptr for a in arrays])
-        self._ck(self.c.smhip_fused_expr(expression.encode(), C.c_int(DTYPES[a0.dtype]), ptrs, C.c_int(len(arrays)), C.c_void_p(out.ptr),
+        sc = np.array(list(scalars), dtype=a0.dtype)
+        self._ck(self.c.smhip_fused_expr(expression.encode(), C.c_int(DTYPES[a0.dtype]), ptrs, C.c_int(len(arrays)),
+                                         sc.ctypes.data_as(C.c_void_p) if len(sc) else None, C.c_int(len(sc)), C.c_void_p(out.ptr),
                                          C.c_size_t(a0.size)))
         return out
 

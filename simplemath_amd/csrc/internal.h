@@ -54,7 +54,8 @@ int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, 
                         const int64_t *shape, int ndim, hipStream_t s);
 // run-time compiled user Ops (jit.hip)
 int jit_register(const char *expr, int *op_id);
-int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, void *out, size_t n, hipStream_t s);
+int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, const void *scalars_host, int n_scalars,
+                   void *out, size_t n, hipStream_t s);
 int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);
 int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s);
 inline bool user_op(int op) { return op >= SMHIP_OP_USER_BASE; }

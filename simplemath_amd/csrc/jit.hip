@@ -83,15 +83,16 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_scalar(const T* __r
 
 )SRC";
 
-// N-ary fused expressions (smhip_fused_expr): out[i] = EXPR(a0[i], ..., a7[i]) over dense operands in ONE pass --
+// N-ary fused expressions (smhip_fused_expr): out[i] = EXPR(a0[i], ..., a7[i], s0..s3) over dense operands in ONE pass --
 // (k + 1) * sizeof(T) bytes per element instead of 3 * sizeof(T) per operator of the chain it replaces.
 const char *kExprSource = R"SRC(
 typedef TYPE T;
 typedef T V0 __attribute__((ext_vector_type(WIDTH)));
 typedef V0 V __attribute__((aligned(sizeof(T))));
 struct Operands { const T* p[8]; };
-__device__ __forceinline__ T smhip_eval(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7) { return (T)(EXPR); }
-extern "C" __global__ __launch_bounds__(256) void smhip_user_expr(Operands in, T* __restrict__ out, unsigned long long n_vec,
+struct Scalars { T v[4]; };
+__device__ __forceinline__ T smhip_eval(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7, T s0, T s1, T s2, T s3) { return (T)(EXPR); }
+extern "C" __global__ __launch_bounds__(256) void smhip_user_expr(Operands in, Scalars sc, T* __restrict__ out, unsigned long long n_vec,
                                                                    unsigned long long n) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n_vec) {
@@ -102,13 +103,13 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_expr(Operands in, T
             else v[k] = v[0];
         V r;
 #pragma unroll
-        for (int e = 0; e < WIDTH; ++e) r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e]);
+        for (int e = 0; e < WIDTH; ++e) r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);
         __builtin_nontemporal_store(r, (V*)out + i);
     } else if (i == n_vec) {
         for (unsigned long long j = n_vec * WIDTH; j < n; ++j) {
             T x[8];
             for (int k = 0; k < 8; ++k) x[k] = in.p[k < NOPS ? k : 0][j];
-            out[j] = smhip_eval(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+            out[j] = smhip_eval(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);
         }
     }
 }
@@ -364,7 +365,8 @@ struct ExprKernel { hipFunction_t fn = nullptr; };
 std::map<std::string, ExprKernel> g_exprs;  // key: dtype | operand count | expression
 }  // namespace
 
-int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, void *out, size_t n, hipStream_t s) {
+int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, const void *scalars_host, int n_scalars,
+                   void *out, size_t n, hipStream_t s) {
     hipFunction_t fn = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -393,7 +395,9 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     unsigned long long n_vec = n / w, nn = n;
     const size_t grid = (n_vec + 1 + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused expression: array too large for one launch");
-    void *args[] = {&in, &out, &n_vec, &nn};
+    unsigned char sc[32] = {};  // Scalars { T v[4]; }: runtime values, so changing them does not recompile
+    if (n_scalars > 0) memcpy(sc, scalars_host, (size_t)n_scalars * dtype_size(dtype));
+    void *args[] = {&in, sc, &out, &n_vec, &nn};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }

@@ -541,16 +541,18 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
 }
 
-int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, void *out, size_t n) {
+int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, const void *scalars_host,
+                     int n_scalars, void *out, size_t n) {
     if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fused_expr: bad dtype %d", dtype);
     if (!hip_expression || !*hip_expression) return fail(SMHIP_ERR_INVALID, "fused_expr: empty expression");
     if (n_operands < 1 || n_operands > 8) return fail(SMHIP_ERR_INVALID, "fused_expr: %d operands (1..8)", n_operands);
+    if (n_scalars < 0 || n_scalars > 4 || (n_scalars > 0 && !scalars_host)) return fail(SMHIP_ERR_INVALID, "fused_expr: %d scalars (0..4)", n_scalars);
     if (n == 0) return SMHIP_OK;
     if (!operands || !out) return fail(SMHIP_ERR_INVALID, "fused_expr: null buffer");
     for (int k = 0; k < n_operands; ++k)
         if (!operands[k]) return fail(SMHIP_ERR_INVALID, "fused_expr: operand %d is null", k);
     SMHIP_ACQUIRE(s);
-    return jit_fused_expr(hip_expression, dtype, operands, n_operands, out, n, s);
+    return jit_fused_expr(hip_expression, dtype, operands, n_operands, scalars_host, n_scalars, out, n, s);
 }
 
 int smhip_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,

@@ -455,6 +455,10 @@ TEST(FusedExpression) {
     auto chain = (a + b) * c - d.transpose() * 3.0f;
     CHECK_EQ(r(0, 0), 18.5f); CHECK_EQ(r(299, 199), 18.5f);
     CHECK_EQ(sm::sum(r), sm::sum(chain));
+    for (float alpha : {2.0f, -0.5f}) {  // run-time scalars: one compile, two launches
+        auto axpy = sm::expr("a0 * s0 + a1", {alpha}, a, b);
+        CHECK_EQ(axpy(7, 7), 2.0f * alpha + 3.0f);
+    }
     sm::SMArray<int> i = {1, 2, 3}, j = {10, 20, 30};
     auto k = sm::expr("a0 * a1 + (a0 > 1 ? 100 : 0)", i, j);
     CHECK_EQ(k(0), 10); CHECK_EQ(k(1), 140); CHECK_EQ(k(2), 190);

@@ -523,6 +523,10 @@ def test_fused_expression_equals_the_operator_chain(smhip, oracle):
             util.assert_same_bits(got, want, f"{dtn} n={n} eight operands")
             got = smhip.fused_expr("a0 * a0", ds[0]).numpy()
             util.assert_same_bits(got, oracle.contiguous(orc.MUL, xs[0], xs[0]), f"{dtn} n={n} one operand")
+            for alpha in (3, -2):  # run-time scalars: passed at launch
+                got = smhip.fused_expr("a0 * s0 + a1 - s1", ds[0], ds[1], scalars=(alpha, 1)).numpy()
+                want = oracle.array_scalar(orc.SUB, oracle.contiguous(orc.ADD, oracle.array_scalar(orc.MUL, xs[0], dt(alpha)), xs[1]), dt(1))
+                util.assert_same_bits(got, want, f"{dtn} n={n} scalars {alpha}")
     with pytest.raises(sma.SmhipError):
         smhip.fused_expr("a0 +* a1", ds[0], ds[1])
 

@@ -36,7 +36,7 @@ show("repeat(4, axis=0) of (2048,8192) ((2048,4,8192) s (8192,0,1))", timeit(lef
 d = lib.uniform_f32(n, 4, 0.5, 2.0)
 t1 = lib.empty((n,), np.float32); t2 = lib.empty((n,), np.float32)
 ptrs = (C.c_void_p * 4)(a.ptr, b.ptr, c.ptr, d.ptr)
-te = timeit(lambda: lib.c.smhip_fused_expr(b"(a0 + a1) * a2 - a3", f32, ptrs, C.c_int(4), C.c_void_p(out.ptr), C.c_size_t(n)))
+te = timeit(lambda: lib.c.smhip_fused_expr(b"(a0 + a1) * a2 - a3", f32, ptrs, C.c_int(4), None, C.c_int(0), C.c_void_p(out.ptr), C.c_size_t(n)))
 show("expr (a0 + a1) * a2 - a3, one pass, 2^26", te, 20 * n)
 def chain():
     lib.c.smhip_contiguous(C.c_int(0), f32, C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_void_p(t1.ptr), C.c_size_t(n))
