@@ -106,6 +106,40 @@ SMArray<T> expr(const char *expression, const SMArray<T> &first, const Rest &...
     return expr<T>(expression, std::initializer_list<T>{}, first, rest...);
 }
 
+// The sum of an expression's results in the same single pass, nothing stored: sm::expr_sum("(a0 - a1) * (a0 - a1)", x, y)
+// is a squared distance at 8 bytes per element and no temporary (fp64 accumulation, deterministic).
+template <typename T, typename... Rest>
+double expr_sum(const char *expression, std::initializer_list<T> scalars, const SMArray<T> &first, const Rest &...rest) {
+    static_assert(hip::dtype_of<T>::id >= 0, "sm::expr_sum: element type has no kernels");
+    static_assert(sizeof...(Rest) <= 7, "sm::expr_sum: at most 8 operands");
+    static_assert((std::is_same_v<Rest, SMArray<T>> && ...), "sm::expr_sum: operands must be SMArray<T> of one element type");
+    if (scalars.size() > 4) throw std::runtime_error("sm::expr_sum: at most 4 scalars");
+    const SMArray<T> *arrays[] = {&first, &rest...};
+    constexpr int n = 1 + static_cast<int>(sizeof...(Rest));
+    std::vector<SMArray<T>> dense;
+    dense.reserve(n);
+    const void *ptrs[8] = {};
+    for (int k = 0; k < n; ++k) {
+        if (arrays[k]->shape() != first.shape()) throw std::runtime_error("sm::expr_sum: operands must have the same shape");
+        if (arrays[k]->is_dense()) {
+            ptrs[k] = arrays[k]->device_data();
+        } else {
+            dense.push_back(arrays[k]->contiguous());
+            ptrs[k] = dense.back().device_data();
+        }
+    }
+    hip::DeviceBuffer result(sizeof(double));
+    hip::check(smhip_fused_expr_sum_async(expression, hip::dtype_of<T>::id, ptrs, n, scalars.size() ? scalars.begin() : nullptr,
+                                          static_cast<int>(scalars.size()), nullptr, first.totalSize, result.template as<double>()));
+    double total = 0;
+    hip::check(smhip_download(&total, result.get(), sizeof total));
+    return total;
+}
+template <typename T, typename... Rest>
+double expr_sum(const char *expression, const SMArray<T> &first, const Rest &...rest) {
+    return expr_sum<T>(expression, std::initializer_list<T>{}, first, rest...);
+}
+
 // Sum of all elements in fp64 (BASELINE config 5's reduction; no reference counterpart).
 template <typename T>
 double sum(const SMArray<T> &arr) {

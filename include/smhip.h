@@ -127,6 +127,12 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
  * smhip_register_op's kernels; each operation rounds as the separate operators do (no contraction). */
 int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, const void *scalars_host,
                      int n_scalars, void *out, size_t n);
+/* The same expression with the sum of its results, in the same single pass: *sum_dev (device memory, fp64; integer types:
+ * the exact 64-bit total as a double, like smhip_sum) = sum_i EXPR(...).  out_or_null: also store the elementwise result, or
+ * reduce only -- e.g. "(a0 - a1) * (a0 - a1)" with out_or_null = NULL is a squared distance at 8 bytes per element and no
+ * temporary.  Generalises smhip_contiguous_sum_async (BASELINE config 5's fused add + sum).  Asynchronous. */
+int smhip_fused_expr_sum_async(const char *hip_expression, int dtype, const void *const *operands, int n_operands,
+                               const void *scalars_host, int n_scalars, void *out_or_null, size_t n, double *sum_dev);
 /* SMArray's element-copy assignment `dst_view = src` (SMArray.h:89-97, a host loop in the reference):
  * dst[sum idx_k*dst_strides_k] = src[sum idx_k*src_strides_k] over `shape`.  A source stride may be 0 (broadcast);
  * a destination stride may not (for extents > 1).  Source and destination must not overlap. */

@@ -285,6 +285,23 @@ class Smhip:
                                          C.c_size_t(a0.size)))
         return out
 
+    def fused_expr_sum(self, expression: str, *arrays: DeviceArray, scalars=(), store=False):
+        """sum_i EXPR(a0[i], ...) in one pass; store=True also returns the elementwise result.  Blocks for the value."""
+        a0 = arrays[0]
+        assert all(a.dtype == a0.dtype and a.size == a0.size and a.is_dense() for a in arrays)
+        out = self.empty(a0.shape, a0.dtype) if store else None
+        ptrs = (C.c_void_p * len(arrays))(*[a.ptr for a in arrays])
+        sc = np.array(list(scalars), dtype=a0.dtype)
+        sp = self.alloc(8)
+        try:
+            self._ck(self.c.smhip_fused_expr_sum_async(expression.encode(), C.c_int(DTYPES[a0.dtype]), ptrs, C.c_int(len(arrays)),
+                                                       sc.ctypes.data_as(C.c_void_p) if len(sc) else None, C.c_int(len(sc)),
+                                                       C.c_void_p(out.ptr) if store else None, C.c_size_t(a0.size), C.c_void_p(sp)))
+            total = self.read_f64(sp)
+        finally:
+            self.free(sp)
+        return (total, out) if store else total
+
     def dot(self, a: DeviceArray, b: DeviceArray):
         out = np.zeros(1, dtype=a.dtype)
         self._ck(self.c.smhip_dot(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),

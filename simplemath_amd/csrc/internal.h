@@ -22,6 +22,8 @@ int compute_units();
 // Per-device scratch for reductions: `count` doubles, stable until the next
 // call with a larger count on the same device.
 int reduce_scratch(size_t count, double **ptr);
+int reduce_finish(int dtype, void *partials, size_t blocks, double *out8, hipStream_t s);
+constexpr int kReduceFoldSpan = 1024;  // = reduce.hip's kFoldSpan: partial buffers need blocks + blocks / span + 1 slots
 
 #define SMHIP_TRY(expr)                                                                        \
     do {                                                                                       \
@@ -55,7 +57,7 @@ int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, 
 // run-time compiled user Ops (jit.hip)
 int jit_register(const char *expr, int *op_id);
 int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, const void *scalars_host, int n_scalars,
-                   void *out, size_t n, hipStream_t s);
+                   void *out, size_t n, double *sum_dev, hipStream_t s);
 int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);
 int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s);
 inline bool user_op(int op) { return op >= SMHIP_OP_USER_BASE; }

@@ -113,6 +113,45 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_expr(Operands in, S
         }
     }
 }
+
+// The same with a sum of the results (SUM_OUT: the elementwise result is stored as well; otherwise reduce only): one
+// accumulator per workgroup -- fp64 for float types, wrapping 64-bit for integer types, like the built-in reductions.
+typedef ACC A;
+__device__ __forceinline__ A smhip_widen(T x) { return WIDEN; }
+extern "C" __global__ __launch_bounds__(256) void smhip_user_expr_sum(Operands in, Scalars sc, T* __restrict__ out, int store,
+                                                                       unsigned long long n_vec, unsigned long long n,
+                                                                       A* __restrict__ partials) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    A acc = 0;
+    if (i < n_vec) {
+        V v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < NOPS) v[k] = __builtin_nontemporal_load((const V*)in.p[k] + i);
+            else v[k] = v[0];
+        V r;
+#pragma unroll
+        for (int e = 0; e < WIDTH; ++e) {
+            r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);
+            acc += smhip_widen(r[e]);
+        }
+        if (store) __builtin_nontemporal_store(r, (V*)out + i);
+    } else if (i == n_vec) {
+        for (unsigned long long j = n_vec * WIDTH; j < n; ++j) {
+            T x[8];
+            for (int k = 0; k < 8; ++k) x[k] = in.p[k < NOPS ? k : 0][j];
+            const T r = smhip_eval(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);
+            if (store) out[j] = r;
+            acc += smhip_widen(r);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ A lds[4];
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
 )SRC";
 
 // What bcast_kernels.hip.h expects to find declared (ops.hip.h provides it ahead of time): fixed-width types, the
@@ -361,12 +400,12 @@ int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void
 }
 
 namespace {
-struct ExprKernel { hipFunction_t fn = nullptr; };
+struct ExprKernel { hipFunction_t fn = nullptr, fn_sum = nullptr; };
 std::map<std::string, ExprKernel> g_exprs;  // key: dtype | operand count | expression
 }  // namespace
 
 int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, const void *scalars_host, int n_scalars,
-                   void *out, size_t n, hipStream_t s) {
+                   void *out, size_t n, double *sum_dev, hipStream_t s) {
     hipFunction_t fn = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -378,16 +417,19 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
             char nops[24];
             snprintf(nops, sizeof nops, "-DNOPS=%d", n_operands);
             hipModule_t mod;
+            const bool integer = dtype == SMHIP_I32 || dtype == SMHIP_I64;
             if (int rc = hiprtc_build(kExprSource, {std::string("-DTYPE=") + kTypeName[dtype],
                                                     std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"), nops,
-                                                    std::string("-DEXPR=") + expr},
+                                                    std::string("-DEXPR=") + expr, integer ? "-DACC=unsigned long long" : "-DACC=double",
+                                                    integer ? "-DWIDEN=(A)(long long)x" : "-DWIDEN=(A)x"},
                                       kTypeName[dtype], expr, &mod))
                 return rc;
-            SMHIP_TRY(hipModuleGetFunction(&fn, mod, "smhip_user_expr"));
-            g_exprs[key].fn = fn;
-        } else {
-            fn = it->second.fn;
+            ExprKernel k;
+            SMHIP_TRY(hipModuleGetFunction(&k.fn, mod, "smhip_user_expr"));
+            SMHIP_TRY(hipModuleGetFunction(&k.fn_sum, mod, "smhip_user_expr_sum"));
+            it = g_exprs.emplace(key, k).first;
         }
+        fn = sum_dev ? it->second.fn_sum : it->second.fn;
     }
     struct { const void *p[8]; } in;
     for (int k = 0; k < 8; ++k) in.p[k] = operands[k < n_operands ? k : 0];
@@ -397,9 +439,18 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused expression: array too large for one launch");
     unsigned char sc[32] = {};  // Scalars { T v[4]; }: runtime values, so changing them does not recompile
     if (n_scalars > 0) memcpy(sc, scalars_host, (size_t)n_scalars * dtype_size(dtype));
-    void *args[] = {&in, sc, &out, &n_vec, &nn};
+    if (!sum_dev) {
+        void *args[] = {&in, sc, &out, &n_vec, &nn};
+        SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        return SMHIP_OK;
+    }
+    // expression + sum: per-workgroup partials, then the built-in reductions' fixed-order fold and final pass
+    double *scratch;
+    if (int rc = reduce_scratch(grid + grid / kReduceFoldSpan + 2, &scratch)) return rc;
+    int store = out != nullptr;
+    void *args[] = {&in, sc, &out, &store, &n_vec, &nn, &scratch};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
-    return SMHIP_OK;
+    return reduce_finish(dtype, scratch, grid, sum_dev, s);
 }
 
 }  // namespace smhip

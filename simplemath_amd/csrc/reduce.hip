@@ -347,4 +347,32 @@ int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void 
     return fail(SMHIP_ERR_INVALID, "contiguous_sum: bad op %d / dtype %d", op, dtype);
 }
 
+// For reductions whose first pass is compiled at run time (jit.hip: fused expression + sum): `partials` holds one
+// accumulator per workgroup of that pass (double for float types, uint64 for integer types, as AccOf<T>), with room
+// for blocks / kFoldSpan + 1 more behind them; this runs the fixed-order fold and the final pass into *out8 (fp64).
+int reduce_finish(int dtype, void *partials_, size_t blocks, double *out8, hipStream_t s) {
+    const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
+    auto go = [&](auto tag) {
+        typedef decltype(tag) T;
+        typedef typename AccOf<T>::type A;
+        A *partials = static_cast<A *>(partials_);
+        size_t count = blocks;
+        if (blocks > (size_t)kFoldSpan) {
+            hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)folded), dim3(kBlock), 0, s, partials, blocks, partials + blocks);
+            partials += blocks;
+            count = folded;
+        }
+        hipLaunchKernelGGL((finalize_kernel<T, true>), dim3(1), dim3(kFinalBlock), 0, s, partials, count, out8, static_cast<T *>(nullptr));
+    };
+    switch (dtype) {
+        case SMHIP_F32: go(float{}); break;
+        case SMHIP_F64: go(double{}); break;
+        case SMHIP_I32: go(int32_t{}); break;
+        case SMHIP_I64: go(int64_t{}); break;
+        default: return fail(SMHIP_ERR_INVALID, "reduce_finish: bad dtype %d", dtype);
+    }
+    SMHIP_LAUNCH_CHECK("reduce finish");
+    return SMHIP_OK;
+}
+
 }  // namespace smhip

@@ -552,7 +552,25 @@ int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *o
     for (int k = 0; k < n_operands; ++k)
         if (!operands[k]) return fail(SMHIP_ERR_INVALID, "fused_expr: operand %d is null", k);
     SMHIP_ACQUIRE(s);
-    return jit_fused_expr(hip_expression, dtype, operands, n_operands, scalars_host, n_scalars, out, n, s);
+    return jit_fused_expr(hip_expression, dtype, operands, n_operands, scalars_host, n_scalars, out, n, nullptr, s);
+}
+
+int smhip_fused_expr_sum_async(const char *hip_expression, int dtype, const void *const *operands, int n_operands,
+                               const void *scalars_host, int n_scalars, void *out_or_null, size_t n, double *sum_dev) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: bad dtype %d", dtype);
+    if (!hip_expression || !*hip_expression) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: empty expression");
+    if (n_operands < 1 || n_operands > 8) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: %d operands (1..8)", n_operands);
+    if (n_scalars < 0 || n_scalars > 4 || (n_scalars > 0 && !scalars_host)) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: %d scalars (0..4)", n_scalars);
+    if (!sum_dev) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: null result");
+    if (n > 0 && !operands) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: null buffer");
+    for (int k = 0; n > 0 && k < n_operands; ++k)
+        if (!operands[k]) return fail(SMHIP_ERR_INVALID, "fused_expr_sum: operand %d is null", k);
+    SMHIP_ACQUIRE(s);
+    if (n == 0) {
+        SMHIP_TRY(hipMemsetAsync(sum_dev, 0, sizeof(double), s));
+        return SMHIP_OK;
+    }
+    return jit_fused_expr(hip_expression, dtype, operands, n_operands, scalars_host, n_scalars, out_or_null, n, sum_dev, s);
 }
 
 int smhip_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,

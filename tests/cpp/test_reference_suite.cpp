@@ -462,6 +462,8 @@ TEST(FusedExpression) {
     sm::SMArray<int> i = {1, 2, 3}, j = {10, 20, 30};
     auto k = sm::expr("a0 * a1 + (a0 > 1 ? 100 : 0)", i, j);
     CHECK_EQ(k(0), 10); CHECK_EQ(k(1), 140); CHECK_EQ(k(2), 190);
+    CHECK_EQ(sm::expr_sum("(a0 - a1) * (a0 - a1)", a, b), 300.0 * 200.0);          // squared distance, one pass, nothing stored
+    CHECK_EQ(sm::expr_sum("a0 * s0", {10}, i), 60.0);
     bool threw = false;
     try { auto bad = sm::expr("a0 + a1", a, d); (void)bad; } catch (const std::runtime_error &) { threw = true; }
     CHECK(threw);

@@ -527,6 +527,16 @@ def test_fused_expression_equals_the_operator_chain(smhip, oracle):
                 got = smhip.fused_expr("a0 * s0 + a1 - s1", ds[0], ds[1], scalars=(alpha, 1)).numpy()
                 want = oracle.array_scalar(orc.SUB, oracle.contiguous(orc.ADD, oracle.array_scalar(orc.MUL, xs[0], dt(alpha)), xs[1]), dt(1))
                 util.assert_same_bits(got, want, f"{dtn} n={n} scalars {alpha}")
+            # the sum of an expression in the same pass: equals the sum of the stored results (same adds), and of the oracle's chain
+            total, stored = smhip.fused_expr_sum("(a0 - a1) * a2", ds[0], ds[1], ds[2], store=True)
+            chain = oracle.contiguous(orc.MUL, oracle.contiguous(orc.SUB, xs[0], xs[1]), xs[2])
+            util.assert_same_bits(stored.numpy(), chain, f"{dtn} n={n} expr+sum stored")
+            only = smhip.fused_expr_sum("(a0 - a1) * a2", ds[0], ds[1], ds[2])
+            assert total == only
+            if dtn[0] == "i":
+                assert total == smhip.sum(stored)   # integer totals are exact: any order gives the same value
+            else:
+                assert abs(total - oracle.sum(chain)) <= n * 2.0 ** -50 * (float(np.abs(chain.astype(np.float64)).sum()) + 1.0)
     with pytest.raises(sma.SmhipError):
         smhip.fused_expr("a0 +* a1", ds[0], ds[1])
 

@@ -44,3 +44,7 @@ def chain():
     lib.c.smhip_contiguous(C.c_int(1), f32, C.c_void_p(t2.ptr), C.c_void_p(d.ptr), C.c_void_p(out.ptr), C.c_size_t(n))
 tc = timeit(chain)
 print("%-58s %9.1f us   (the one-pass form is %.2fx faster)" % ("the same as three operator calls", tc, tc / te))
+sp = lib.alloc(8)
+ptr2 = (C.c_void_p * 2)(a.ptr, b.ptr)
+ts = timeit(lambda: lib.c.smhip_fused_expr_sum_async(b"(a0 - a1) * (a0 - a1)", f32, ptr2, C.c_int(2), None, C.c_int(0), None, C.c_size_t(n), C.c_void_p(sp)))
+show("expr_sum (a0 - a1)^2, reduce only, 2^26", ts, 8 * n)
