@@ -556,6 +556,21 @@ def test_left_op_gathers_views(smhip):
             assert np.array_equal(got.view(u), np.ascontiguousarray(view).view(u)), (dtn, view.shape)
 
 
+def test_flat_repeat_kernel(smhip):
+    """repeat(r) of a dense array -- the (N, r) view with strides (1, 0) -- has a kernel of its own for r < 16: every
+    repeat count, element width and tail length against numpy.repeat, bit for bit."""
+    for dtn in ("f32", "f64", "i32", "i64"):
+        for n in (1, 2, 5, 1000, 4097):
+            a = gen.gen(DT[dtn], n, 131, "wide")
+            da = smhip.to_device(a)
+            dummy = smhip.to_device(np.zeros(1, dtype=DT[dtn]))
+            for r in (1, 2, 3, 4, 5, 7, 8, 15, 16, 33):
+                dv = sma.DeviceArray(smhip, da.base_ptr, DT[dtn], (n, r), (1, 0), 0, da._owner)
+                got = smhip.binary(sma.OP_LEFT, dv, dummy).numpy().reshape(-1)
+                u = {4: np.uint32, 8: np.uint64}[a.itemsize]
+                assert np.array_equal(got.view(u), np.repeat(a, r).view(u)), (dtn, n, r)
+
+
 def test_1d_strided_is_walked_not_assumed_dense(smhip):
     """SURVEY 8a quirk 1: the reference reads any 1-D operand as dense (calculate.h:10);
     the HIP path honours the strides (checked against numpy, the reference being UB here)."""
