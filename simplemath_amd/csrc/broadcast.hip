@@ -388,6 +388,63 @@ int run_repeat(const void *src, void *out, size_t n_src, uint32_t r, hipStream_t
     return SMHIP_OK;
 }
 
+// ------------------------------------------------------------------ short rows against one value per row
+// out[i][k] = x[i][k] op y[i] for rows of fewer than 16 elements (per-pixel / per-sample scaling of interleaved data:
+// (N, 3) / (N, 1)).  x and out are dense, y is a dense vector.  A lane owns one 16-byte vector of x and finds its row with
+// one fast division; the workgroup's slice of y (at most 1024 / r + 2 values) is staged in LDS with coalesced loads --
+// the generic gather and a first version of this kernel read y with per-lane scalar loads and sat at 67 % of peak.
+template <typename T, typename Op, bool SWAPPED>
+__global__ __launch_bounds__(256) void short_rows_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out, FastDiv r,
+                                                         uint32_t n_vec, uint32_t n) {
+    constexpr int W = VecTraits<T>::width;
+    typedef typename VecTraits<T>::vec_t V;
+    __shared__ T ylds[256 * W / 2 + 2];
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t v0 = blockIdx.x * 256u, v = v0 + threadIdx.x;
+    const uint32_t q0 = r.div(v0 * W);
+    uint32_t last = (v0 + 256u) * W - 1;  // last element this workgroup can touch (FastDiv wants it < 2^31: clip to n - 1)
+    if (last >= n) last = n - 1;
+    const uint32_t q_last = r.div(last) + 1;
+    V xv;
+    if (v < n_vec) xv = load_stream(reinterpret_cast<const V *>(x + (size_t)v * W));
+    for (uint32_t i = threadIdx.x; q0 + i < q_last; i += 256) ylds[i] = y[q0 + i];
+    __syncthreads();
+    if (v > n_vec) return;
+    const uint32_t j0 = v * W;
+    uint32_t q, rem;
+    r.divmod(j0, q, rem);
+    if (v < n_vec) {
+        T xa[W], ya[W], res[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            xa[k] = xv[k];
+            ya[k] = ylds[q - q0];
+            if (++rem == r.d) { rem = 0; ++q; }
+        }
+        if (SWAPPED) apply_n<Op, T, W>(ctx, ya, xa, res);
+        else apply_n<Op, T, W>(ctx, xa, ya, res);
+        V rv;
+#pragma unroll
+        for (int k = 0; k < W; ++k) rv[k] = res[k];
+        store_stream(reinterpret_cast<V *>(out + j0), rv);
+    } else {
+        for (uint32_t j = j0; j < n; ++j) out[j] = SWAPPED ? Op::apply(y[j / r.d], x[j]) : Op::apply(x[j], y[j / r.d]);
+    }
+}
+
+template <typename T, typename Op>
+int run_short_rows(const void *x, const void *y, void *out, size_t rows, uint32_t r, bool swapped, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const size_t n = rows * r;
+    const uint32_t n_vec = (uint32_t)(n / W);
+    const dim3 grid((unsigned)(((size_t)n_vec + 1 + 255) / 256)), block(256);
+    if (swapped) hipLaunchKernelGGL((short_rows_kernel<T, Op, true>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n);
+    else hipLaunchKernelGGL((short_rows_kernel<T, Op, false>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n);
+    SMHIP_LAUNCH_CHECK("short_rows_kernel");
+    return SMHIP_OK;
+}
+
 // ------------------------------------------------------------------ strided copy
 // dst[sum idx_k * sd_k] = src[sum idx_k * ss_k]: the scatter side of SMArray's element-copy assignment
 // (`view = array`, reference SMArray.h:89-97), which the reference runs as a host loop.  Rows are the merged
@@ -530,6 +587,32 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
     Launch L;
     if (int rc = plan_launch(pl, (int)dtype_size(dtype), heavy, &L)) return rc;
     if (user) return jit_launch(op, dtype, L, a, b, out, s);
+    // rows of 2..15 elements against one value per row: x dense (r, 1), y a dense vector (1, 0)
+    if (L.kind == Launch::kGather && pl.ndim == 2 && pl.shape[1] >= 2 && pl.shape[1] < 16 && op != SMHIP_OP_LEFT) {
+        const bool y_is_b = pl.sa[0] == pl.shape[1] && pl.sa[1] == 1 && pl.sb[0] == 1 && pl.sb[1] == 0;
+        const bool y_is_a = pl.sb[0] == pl.shape[1] && pl.sb[1] == 1 && pl.sa[0] == 1 && pl.sa[1] == 0;
+        if (y_is_b || y_is_a) {
+            const void *x = y_is_b ? a : b, *y = y_is_b ? b : a;
+            const size_t rows = (size_t)pl.shape[0];
+            const uint32_t r = (uint32_t)pl.shape[1];
+#define SMHIP_SHORT_ROWS(T)                                                                                      \
+    switch (op) {                                                                                                \
+        case SMHIP_OP_ADD: return run_short_rows<T, AddOp<T>>(x, y, out, rows, r, y_is_a, s);                  \
+        case SMHIP_OP_SUB: return run_short_rows<T, SubtractOp<T>>(x, y, out, rows, r, y_is_a, s);             \
+        case SMHIP_OP_MUL: return run_short_rows<T, MultiplyOp<T>>(x, y, out, rows, r, y_is_a, s);             \
+        case SMHIP_OP_DIV: return run_short_rows<T, DivideOp<T>>(x, y, out, rows, r, y_is_a, s);               \
+        case SMHIP_OP_POW: return run_short_rows<T, PowOp<T>>(x, y, out, rows, r, y_is_a, s);                  \
+    }                                                                                                            \
+    break;
+            switch (dtype) {
+                case SMHIP_F32: SMHIP_SHORT_ROWS(float)
+                case SMHIP_F64: SMHIP_SHORT_ROWS(double)
+                case SMHIP_I32: SMHIP_SHORT_ROWS(int32_t)
+                case SMHIP_I64: SMHIP_SHORT_ROWS(int64_t)
+            }
+#undef SMHIP_SHORT_ROWS
+        }
+    }
 #define SMHIP_DISPATCH_OP(T)                                                                   \
     switch (op) {                                                                              \
         case SMHIP_OP_ADD: return launch_aot<T, AddOp<T>>(L, a, b, out, s);                \

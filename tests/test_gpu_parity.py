@@ -571,6 +571,25 @@ def test_flat_repeat_kernel(smhip):
                 assert np.array_equal(got.view(u), np.repeat(a, r).view(u)), (dtn, n, r)
 
 
+def test_short_rows_against_per_row_values(smhip, oracle):
+    """(N, r) op (N, 1) with r < 16 and N too large for the LDS kernel: its own kernel; either operand order, every
+    element type and Op, rows that straddle vectors and workgroups, element counts with every tail."""
+    for dtn, op in (("f32", "div"), ("f64", "mul"), ("i32", "sub"), ("i64", "add"), ("f32", "pow")):
+        dt = DT[dtn]
+        for n, r in ((20000, 3), (9001, 5), (10007, 15), (12345, 2), (8193, 7)):
+            kind = "positive" if op == "pow" else "uniform"
+            x = gen.gen(dt, n * r, 141, kind).reshape(n, r)
+            y = gen.gen(dt, n, 142, "nonzero" if dtn[0] == "i" else kind).reshape(n, 1)
+            dx, dy = smhip.to_device(x), smhip.to_device(y)
+            for lhs, rhs, dl, dr in ((x, y, dx, dy), (y, x, dy, dx)):
+                got = smhip.binary(sma.OPS[op], dl, dr).numpy()
+                want = oracle.binary(orc.OPS[op], lhs, rhs)
+                if op == "pow":
+                    assert orc.ulp_diff_f32(got, want).max() <= POW_ULP, (n, r)
+                else:
+                    util.assert_same_bits(got, want, f"{dtn} {op} ({n},{r}) {'x op y' if lhs is x else 'y op x'}")
+
+
 def test_1d_strided_is_walked_not_assumed_dense(smhip):
     """SURVEY 8a quirk 1: the reference reads any 1-D operand as dense (calculate.h:10);
     the HIP path honours the strides (checked against numpy, the reference being UB here)."""

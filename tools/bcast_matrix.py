@@ -49,7 +49,7 @@ case("A[1:-1,1:-1] + B[1:-1,1:-1] (8190,8190)[row, unaligned]", (M - 2, M - 2), 
 case("A[:, ::2] + B[:, ::2] (8192,4096)      [gather]", (M, M // 2), (M, 2), (M, 2))
 case("A[::2, :] + B[::2, :] (4096,8192)      [row]", (M // 2, M), (2 * M, 1), (2 * M, 1))
 case("column A[:,5] + B[:,7] (8192)          [gather]", (M,), (M,), (M,), off_a=5, off_b=7)
-case("(2^24,3) / (2^24,1) per-pixel scale     [gather]    ", (1 << 24, 3), (3, 1), (1, 0), op=3)
+case("(2^24,3) / (2^24,1) per-pixel scale     [short rows]", (1 << 24, 3), (3, 1), (1, 0), op=3)
 case("f64 (8192,4096) * (1,4096)             [row]", (M, 4096), (4096, 1), (0, 1), op=2, dt=np.float64)
 case("f64 A.T + B (4096,4096)                [tile]", (4096, 4096), (1, 4096), (4096, 1), dt=np.float64)
 case("i32 (8192,8192) + (1,8192)             [row]", (M, M), (M, 1), (0, 1), dt=np.int32)
