@@ -145,7 +145,10 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
         // one or four; one when both operands stream (three full streams behave like the contiguous kernel: 80 % vs
         // 74-77 %) and for pow, whose arithmetic already overlaps the next lane's loads.
         const bool three_streams = ia == 1 && ib == 1 && !L->ca && !L->cb;
-        L->rows = (three_streams || heavy) ? 1 : 2;
+        // no streamed read at all (a per-row scalar against a row-constant: an outer product) is a pure write stream: one
+        // row per lane, like the fill kernel (83 % of peak against 78 % with two)
+        const bool write_only = (ia == 0 && L->cb) || (ib == 0 && L->ca);
+        L->rows = (three_streams || write_only || heavy) ? 1 : 2;
         const int ty = 256 / L->tx;
         const size_t gx = (p.vpr + L->tx - 1) / L->tx;
         const size_t gy = ((size_t)p.rows + ty * L->rows - 1) / (ty * L->rows);
@@ -315,10 +318,10 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
                 else if (L.ca) go_tx(I1{}, I1{}, Tr{}, F{}, RN{});
                 else go_tx(I1{}, I1{}, F{}, F{}, I1{});  // three streams: one row per lane
             } else if (L.ia == 1) {
-                if (L.ca) go_tx(I1{}, I0{}, Tr{}, F{}, RN{});
+                if (L.ca) go_tx(I1{}, I0{}, Tr{}, F{}, I1{});  // write-only: one row per lane
                 else go_tx(I1{}, I0{}, F{}, F{}, RN{});
             } else {
-                if (L.cb) go_tx(I0{}, I1{}, F{}, Tr{}, RN{});
+                if (L.cb) go_tx(I0{}, I1{}, F{}, Tr{}, I1{});  // write-only: one row per lane
                 else go_tx(I0{}, I1{}, F{}, F{}, RN{});
             }
             if (!launched) return fail(SMHIP_ERR_INVALID, "row kernel: rows-per-lane mismatch between plan and launch");
