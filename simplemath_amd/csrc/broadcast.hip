@@ -391,6 +391,55 @@ int run_repeat(const void *src, void *out, size_t n_src, uint32_t r, hipStream_t
     return SMHIP_OK;
 }
 
+// ------------------------------------------------------------------ dense copy of an inner-strided view
+// out[row][i] = src[row * pitch + i * S] for S = 2, 3, 4 (every other column; one channel of interleaved data):
+// SMArray::contiguous() of such a view, which sm::expr, the reductions and repeat() call before they run.  The generic
+// gather reads it one element per lane (four 4-byte load instructions per 16 bytes of output); here a lane loads the S
+// consecutive vectors that contain its W outputs and keeps every S-th element: S full-width loads per 16 bytes of
+// output, every fetched line requested once.  The last slot of a row is done element by element (the S vectors would
+// read up to S - 1 elements past the last one the view owns).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__ src, T *__restrict__ out, int64_t pitch, uint32_t inner,
+                                                           FastDiv vpr, uint32_t slots) {
+    constexpr int W = VecTraits<T>::width;
+    typedef typename VecTraits<T>::vec_t V;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= slots) return;
+    uint32_t row, col;
+    vpr.divmod(slot, row, col);
+    const uint32_t e0 = col * W;
+    const T *s = src + (int64_t)row * pitch + (int64_t)e0 * S;
+    T *d = out + (size_t)row * inner + e0;
+    if (e0 + W < inner) {  // strictly inside the row: the over-read stays inside it too
+        V v[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) v[i] = load_stream(reinterpret_cast<const V *>(s) + i);
+        V r;
+#pragma unroll
+        for (int k = 0; k < W; ++k) r[k] = v[(k * S) / W][(k * S) % W];
+        store_stream(reinterpret_cast<V *>(d), r);
+    } else {
+        for (uint32_t k = 0; e0 + k < inner; ++k) d[k] = s[(int64_t)k * S];
+    }
+}
+
+template <typename T>
+int run_deinterleave(const void *src, void *out, size_t rows, uint32_t inner, int64_t pitch, int stride, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const size_t per_row = ((size_t)inner + W - 1) / W, slots = rows * per_row;
+    const dim3 grid((unsigned)((slots + 255) / 256)), block(256);
+    const T *a = static_cast<const T *>(src);
+    T *o = static_cast<T *>(out);
+    const FastDiv vpr((uint32_t)per_row);
+    switch (stride) {
+        case 2: hipLaunchKernelGGL((deinterleave_kernel<T, 2>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots); break;
+        case 3: hipLaunchKernelGGL((deinterleave_kernel<T, 3>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots); break;
+        default: hipLaunchKernelGGL((deinterleave_kernel<T, 4>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots); break;
+    }
+    SMHIP_LAUNCH_CHECK("deinterleave_kernel");
+    return SMHIP_OK;
+}
+
 // ------------------------------------------------------------------ short rows against one value per row
 // out[i][k] = x[i][k] op y[i] for rows of fewer than 16 elements (per-pixel / per-sample scaling of interleaved data:
 // (N, 3) / (N, 1)).  x and out are dense, y is a dense vector.  A lane owns one 16-byte vector of x and finds its row with
@@ -579,6 +628,17 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
             if (int rc = launch_plan(op, dtype, pa, pb, po, sub, s)) return rc;
         }
         return SMHIP_OK;
+    }
+    if (op == SMHIP_OP_LEFT && pl.ndim <= 2 && pl.sa[pl.ndim - 1] >= 2 && pl.sa[pl.ndim - 1] <= 4 && pl.shape[pl.ndim - 1] >= 64 &&
+        (pl.ndim == 1 || pl.sa[0] != 0)) {  // every S-th element of each row, made dense
+        const size_t rows = pl.ndim == 2 ? (size_t)pl.shape[0] : 1;
+        const uint32_t inner = (uint32_t)pl.shape[pl.ndim - 1];
+        const int64_t pitch = pl.ndim == 2 ? pl.sa[0] : 0;
+        const int stride = (int)pl.sa[pl.ndim - 1];
+        switch (dtype) {
+            case SMHIP_F32: case SMHIP_I32: return run_deinterleave<int32_t>(a, out, rows, inner, pitch, stride, s);  // only the width matters
+            case SMHIP_F64: case SMHIP_I64: return run_deinterleave<int64_t>(a, out, rows, inner, pitch, stride, s);
+        }
     }
     if (op == SMHIP_OP_LEFT && pl.ndim == 2 && pl.sa[0] == 1 && pl.sa[1] == 0 && pl.shape[1] < 16) {  // a flat repeat
         switch (dtype) {

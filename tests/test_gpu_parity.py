@@ -556,6 +556,25 @@ def test_left_op_gathers_views(smhip):
             assert np.array_equal(got.view(u), np.ascontiguousarray(view).view(u)), (dtn, view.shape)
 
 
+def test_dense_copy_of_inner_strided_views(smhip):
+    """contiguous() of a view that takes every 2nd / 3rd / 4th element along the inner axis (stepped slices, one channel
+    of interleaved data): the deinterleave kernel for rows of >= 64 outputs, the gather otherwise; against numpy, bit for
+    bit, including the last rows of the allocation (nothing may be read past the view's last element)."""
+    for dtn in ("f32", "f64", "i32", "i64"):
+        a = gen.gen(DT[dtn], 37 * 1000, 151, "wide").reshape(37, 1000)
+        da = smhip.to_device(a)
+        dummy = smhip.to_device(np.zeros(1, dtype=DT[dtn]))
+        flat = a.reshape(-1)
+        views = [a[:, ::2], a[:, 1::2], a[:, ::3], a[:, 2::3], a[:, ::4], a[:, 3::4], a[5:, 7:900:3], a[:, ::5], a[:, :100:2], a[36:, 1::2],
+                 flat[::2], flat[1::3], flat[36999 - 4 * 300::4]]
+        for view in views:
+            dv = sma.DeviceArray(smhip, da.base_ptr, DT[dtn], view.shape, [st // a.itemsize for st in view.strides],
+                                 (view.__array_interface__["data"][0] - a.__array_interface__["data"][0]) // a.itemsize, da._owner)
+            got = smhip.binary(sma.OP_LEFT, dv, dummy).numpy()
+            u = {4: np.uint32, 8: np.uint64}[a.itemsize]
+            assert np.array_equal(got.view(u), np.ascontiguousarray(view).view(u)), (dtn, view.shape, view.strides)
+
+
 def test_flat_repeat_kernel(smhip):
     """repeat(r) of a dense array -- the (N, r) view with strides (1, 0) -- has a kernel of its own for r < 16: every
     repeat count, element width and tail length against numpy.repeat, bit for bit."""
