@@ -86,6 +86,13 @@ def main():
             print(f"MISMATCH case {t} seed {seed}: {dtn} {op} a{av.shape} strides {tuple(s // av.itemsize for s in av.strides)} "
                   f"b{bv.shape} strides {tuple(s // bv.itemsize for s in bv.strides)}\n{e}")
             sys.exit(1)
+        # the dense copy of the view itself (SMHIP_OP_LEFT: contiguous(), with its repeat / deinterleave / tile special cases)
+        a_lo = a.__array_interface__["data"][0]
+        if a_lo <= av.__array_interface__["data"][0] < a_lo + a.nbytes:  # av is a view of a (not the swapped small operand)
+            dense = lib.binary(sma.OP_LEFT, da.view_like(av, a), lib.to_device(np.zeros(1, dtype=dt))).numpy()
+            if not np.array_equal(dense.view(np.uint8), np.ascontiguousarray(av).view(np.uint8)):
+                print(f"LEFT MISMATCH case {t} seed {seed}: {dtn} a{av.shape} strides {tuple(s // av.itemsize for s in av.strides)}")
+                sys.exit(1)
         # assignment: dst view of a  <-  source view broadcast to it
         dst_base = random_base(rng, dt, 30000 + t, "uniform")
         dv = random_view(rng, dst_base)
