@@ -31,6 +31,13 @@
 //                  then increment-and-carry; W consecutive outputs per lane with a vector store when the
 //                  inner strides are 0/1, one output per lane when an operand is strided along the inner
 //                  axis (each load instruction then stays inside a few cache lines).
+// The four bodies above live in bcast_kernels.hip.h (shared with jit.hip, which compiles them around user-defined Ops);
+// plan_launch() below chooses among them.  Four small kernels in this file cover shapes on which the gather is slow:
+//   short-rows     rows of 2-15 elements against one value per row ((N,3) / (N,1)), per-row values staged in LDS;
+//   repeat         SMHIP_OP_LEFT over (N, r) with strides (1, 0), r < 16: SMArray::repeat(r) of a dense array;
+//   deinterleave   SMHIP_OP_LEFT over a view that takes every 2nd / 3rd / 4th element of the inner axis;
+//   strided copy   assignment into a view whose rows have a pitch (smhip_copy_strided); destinations that are dense in
+//                  some axis order are written through SMHIP_OP_LEFT instead.
 // Every 16-byte access is only element-aligned (VecTraits, ops.hip.h): bases, pitches and row extents are
 // unconstrained, there are no per-element fallbacks for alignment.
 // Roofline: HBM-bound; algorithmic bytes = sizeof(T) * (|a| + |b| + |out|)
