@@ -109,6 +109,27 @@ __device__ __forceinline__ void consume(const OpCtx<Op> &ctx, A &acc, typename V
     }
 }
 
+// What a reduction hands back.  *out8 receives 8 bytes:
+//   floats            the fp64 total;
+//   ints, AS_DOUBLE   (double) of the exact 64-bit total         (sum, fused op+sum);
+//   ints, !AS_DOUBLE  the total wrapped to T, sign-extended to int64 (dot: per-rank partials add up mod 2^32 / 2^64
+//                     exactly like the reference's _mm256_add_epi32 accumulators, in any order).
+// *out_native (optional) receives the value narrowed to T (dot's return type).
+template <typename T, bool AS_DOUBLE>
+__device__ __forceinline__ void write_result(typename AccOf<T>::type acc, void *__restrict__ out8, T *__restrict__ out_native) {
+    if constexpr (std::is_floating_point<T>::value) {
+        if (out8) *static_cast<double *>(out8) = acc;
+        if (out_native) *out_native = (T)acc;
+    } else {
+        const T wrapped = (T)acc;
+        if (out8) {
+            if constexpr (AS_DOUBLE) *static_cast<double *>(out8) = (double)(int64_t)acc;
+            else *static_cast<int64_t *>(out8) = (int64_t)wrapped;
+        }
+        if (out_native) *out_native = wrapped;
+    }
+}
+
 // Each workgroup owns one tile of kBlock * kVecPerThread vectors.  Full tiles (all
 // but possibly the last) take a guard-free path: every load of the tile is issued
 // before the first use, so kVecPerThread (x2 operands) 16-byte loads are in flight
@@ -116,7 +137,8 @@ __device__ __forceinline__ void consume(const OpCtx<Op> &ctx, A &acc, typename V
 // in turn -- 2.6 TB/s instead of 6.)
 template <typename T, typename Op, int MODE>
 __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
-                                                           size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials) {
+                                                           size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials,
+                                                           void *__restrict__ out8, T *__restrict__ out_native) {
     typedef typename AccOf<T>::type A;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
@@ -160,7 +182,10 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
         }
     }
     acc = block_reduce<A, kBlock>(acc);
-    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1) write_result<T, MODE != kDot>(acc, out8, out_native);  // a small array: no second launch
+        else partials[blockIdx.x] = acc;
+    }
 }
 
 // Intermediate pass when there are many partials (one vector per lane means one partial per 4 KiB
@@ -176,13 +201,7 @@ __global__ __launch_bounds__(kBlock) void fold_kernel(const A *__restrict__ in, 
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
-// Last pass: fixed-order sum of the partials.  *out8 receives 8 bytes:
-//   floats            the fp64 total;
-//   ints, AS_DOUBLE   (double) of the exact 64-bit total         (sum, fused op+sum);
-//   ints, !AS_DOUBLE  the total wrapped to T, sign-extended to int64 (dot: per-rank
-//                     partials add up mod 2^32 / 2^64 exactly like the reference's
-//                     _mm256_add_epi32 accumulators, in any order).
-// *out_native (optional) receives the value narrowed to T (dot's return type).
+// Last pass: fixed-order sum of the partials (write_result above says what is handed back).
 template <typename T, bool AS_DOUBLE>
 __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(const typename AccOf<T>::type *__restrict__ partials, size_t count,
                                                                void *__restrict__ out8, T *__restrict__ out_native) {
@@ -190,19 +209,7 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(const typename Ac
     A acc = A(0);
     for (size_t i = threadIdx.x; i < count; i += kFinalBlock) acc += partials[i];
     acc = block_reduce<A, kFinalBlock>(acc);
-    if (threadIdx.x == 0) {
-        if constexpr (std::is_floating_point<T>::value) {
-            if (out8) *static_cast<double *>(out8) = acc;
-            if (out_native) *out_native = (T)acc;
-        } else {
-            const T wrapped = (T)acc;
-            if (out8) {
-                if constexpr (AS_DOUBLE) *static_cast<double *>(out8) = (double)(int64_t)acc;
-                else *static_cast<int64_t *>(out8) = (int64_t)wrapped;
-            }
-            if (out_native) *out_native = wrapped;
-        }
-    }
+    if (threadIdx.x == 0) write_result<T, AS_DOUBLE>(acc, out8, out_native);
 }
 
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -269,8 +276,10 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     double *scratch;
     if (int rc = reduce_scratch(blocks + folded, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
-    hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials);
+    hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
+                       static_cast<T *>(out_native));
     SMHIP_LAUNCH_CHECK("reduce");
+    if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
     if (blocks > (size_t)kFoldSpan) {
         hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)folded), dim3(kBlock), 0, s, partials, blocks, partials + blocks);
         SMHIP_LAUNCH_CHECK("reduce fold");
