@@ -7,7 +7,7 @@ import sys, ctypes as C
 sys.path.insert(0, "/root/repo")
 import numpy as np
 import simplemath_amd as sma
-lib = sma.load()
+lib = sma.load(sys.argv[1]) if len(sys.argv) > 1 else sma.load()
 def i64(seq): return (C.c_int64 * len(seq))(*[int(s) for s in seq])
 def timeit(fn, args, steps):
     for _ in range(5): fn(*args)
