@@ -320,6 +320,26 @@ def test_transposed_and_permuted_views(smhip, oracle):
     assert np.array_equal(got, oracle.binary(orc.ADD, av, b4))
 
 
+def test_dense_against_a_handful_of_values(smhip, oracle):
+    """A dense operand against a small one of at most 8 elements (per-channel mean / scale of interleaved data) through the
+    LDS kernel: every element type, either operand order, RGB / RGBA / 8-channel, patterns that are broadcast in the
+    middle, element counts with every tail.  (A register-resident variant of the kernel was tried for this shape and was
+    slower: 66 us against 50 us for the RGB bias of tools/bcast_matrix.py.)"""
+    cases = [((50, 60, 3), (3,)), ((7, 9, 11, 4), (1, 1, 1, 4)), ((1001, 3), (1, 3)), ((40, 50, 8), (8,)), ((6, 5, 100, 2), (6, 1, 1, 1)),
+             ((3, 333, 2), (3, 1, 2)), ((20011, 5), (5,)), ((2, 4, 1025, 2), (2, 1, 1, 2))]
+    for dtn, op in (("f32", "sub"), ("f64", "div"), ("i32", "mul"), ("i64", "add"), ("f32", "mul")):
+        dt = DT[dtn]
+        for big, small in cases:
+            x = gen.gen(dt, int(np.prod(big)), 161, "uniform").reshape(big)
+            y = gen.gen(dt, int(np.prod(small)), 162, "nonzero" if dtn[0] == "i" else "uniform").reshape(small)
+            dx, dy = smhip.to_device(x), smhip.to_device(y)
+            util.assert_same_bits(smhip.binary(sma.OPS[op], dx, dy).numpy(), oracle.binary(orc.OPS[op], x, y), f"{dtn} {op} {big} {small}")
+            if not (dtn[0] == "i" and op == "div"):
+                x2 = gen.gen(dt, int(np.prod(big)), 163, "nonzero" if dtn[0] == "i" else "uniform").reshape(big)
+                util.assert_same_bits(smhip.binary(sma.OPS[op], dy, smhip.to_device(x2)).numpy(), oracle.binary(orc.OPS[op], y, x2),
+                                      f"{dtn} {op} swapped {big} {small}")
+
+
 def test_fewer_elements_than_a_vector(smhip, oracle):
     """1-3 output elements through every broadcast kernel's tail path (a launch must still have one workgroup)."""
     for dtn in ("f32", "f64", "i32", "i64"):
