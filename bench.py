@@ -1,33 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py                                    # 1 GPU, 200 timed steps
+    python bench.py --gpus 8 --steps 20 --warmup 5     # starts its own 8 ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W        # the same ranks, started by a launcher
+    python bench.py --gpus 8 --mode single             # ONE process driving 8 GPUs (smhip_set_devices: what sm::Sharded uses)
 
-metric   "Gelem/s" of the contiguous float32 add c = a + b (BASELINE.json `metric`,
-         configs[1]): one step = one pass of smhip_contiguous over N = 2^28 elements,
-         inputs already resident in HBM (generated on device by the counter-based
-         hash), output preallocated.
-N GPUs   one process per GPU; each rank owns one outer-dimension shard of 2^28 elements
-         of the N * 2^28 array (config 5's partitioning) -- elementwise work has no
-         data-path collective, so scaling is "weak" and value = all ranks' elements / time.
-         The reduction path of config 5 (fused add + sum, then ONE RCCL all-reduce of an
-         fp64 scalar over xGMI) is timed after the headline region and reported under "c5".
-roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024>;
-         algorithmic bytes 12 B/elem (2 reads + 1 write) * 2^28 = 3 221 225 472 B per launch;
-         duration = HIP events (smhip_event_*, recorded on the stream the kernel runs on)
-         over the timed region / launches; peak = 8000 GB/s (MI355X HBM3E spec).
-cpu_baseline  rank 0, N = 1 only: the reference's own operator path (oracle/_ref, kind
-         "reference": SMArray<float>::operator+ exactly as benchmark/add.cpp drives it, result
-         new[]-allocated inside the call, one core) if the prebuilt .so travelled, else the
-         oracle's restatement (kind "port"); on a bounded 2^26-element sample.
+metric   "Gelem/s" of the contiguous float32 add c = a + b (BASELINE.json `metric`, configs[1]): one step = one pass
+         of smhip_contiguous over N = 2^28 elements per GPU, inputs already resident in HBM (generated on device by the
+         counter-based hash), output preallocated.
+N GPUs   each GPU owns one outer-dimension shard of 2^28 elements of the N * 2^28 array (config 5's partitioning).
+         Elementwise work has no data-path collective, so scaling is "weak" and value = all GPUs' elements / time.
+         --mode ranks (default): one process per GPU.  Plain `--gpus N` starts the N ranks itself through
+         torch.distributed.run BEFORE this process has touched HIP; under a launcher (RANK in the environment) this
+         process is one of the ranks.  torch.distributed (backend nccl = RCCL) provides the barrier and the
+         max-over-ranks of the timings only.
+         --mode single: one process, one host thread, N devices through libsmhip's device group.
+         Config 5's exchange step (fused add + sum per shard, then ONE ncclAllReduce of an fp64 scalar over xGMI, issued
+         by libsmhip itself: smhip_allreduce_sum_async / smhip_sharded_contiguous_sum) is timed after the headline
+         region and reported under "c5" (operands: config 5's seeds 6/7 in [0,1)).
+roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024>; algorithmic bytes 12 B/elem (2 reads +
+         1 write) * 2^28 = 3 221 225 472 B per launch; duration = HIP events (smhip_event_*, recorded on the stream the
+         kernel runs on) over the timed region / launches; peak = 8000 GB/s (MI355X HBM3E spec).  `traffic` is NOT
+         measured by this run: it is the HBM byte count of the last committed rocprofv3 --pmc passes
+         (tools/pmc_traffic.sh -> profiles/traffic_latest.json) and `traffic_source` says so; null if that file is absent.
+cpu_baseline  rank 0, N = 1 only, on a bounded sample: `value` = the reference's own operator path as shipped (oracle/_ref,
+         kind "reference") if the prebuilt .so travelled, else the oracle's restatement (kind "port"); `best_effort` =
+         the restatement on every core this process may use (cgroup quota / affinity / SMT accounted for), output
+         preallocated -- the number that does not flatter the GPU.  Per workload, as BASELINE.md section 3 lists them.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -53,53 +62,150 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="add", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "single"],
+                    help="ranks = one process per GPU (started here if no launcher did); single = one process, N devices")
     ap.add_argument("--log2n", type=int, default=None, help="elements per GPU = 2^log2n (default: the config's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 path, e.g. 2 ranks sharing one GPU")
+                    help="torch.distributed backend for the barrier and the max over ranks: nccl = RCCL; gloo = CPU rehearsal")
     ap.add_argument("--cpu-log2n", type=int, default=26)
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steps before the W warm-up steps (clock ramp)")
     return ap.parse_args()
 
 
-def cpu_baseline(log2n):
-    """Reference / oracle timed on this box's host cores.  Checker code: used here only
-    as the thing measured BESIDE the GPU, never on the product path."""
+# ------------------------------------------------------------------------------------------- CPU baseline
+
+def usable_cores():
+    """Physical cores this process may really use: affinity mask, SMT siblings and the cgroup CPU quota accounted for."""
+    info = {}
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except AttributeError:
+        logical = os.cpu_count() or 1
+    smt = 1
+    try:
+        with open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list") as f:
+            txt = f.read().strip()
+        smt = 0
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            smt += (int(hi) - int(lo) + 1) if hi else 1
+        smt = max(smt, 1)
+    except (OSError, ValueError):
+        pass
+    cores = max(logical // smt, 1)
+    info.update(logical_cpus=logical, smt=smt, physical_cores=cores)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            q, p = f.read().split()
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:  # cgroup v1
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        info["cgroup_cpu_quota"] = quota
+        cores = max(min(cores, int(quota)), 1)
+    env = os.environ.get("SMHIP_BENCH_CPU_THREADS")
+    if env:
+        cores = max(int(env), 1)
+        info["override"] = "SMHIP_BENCH_CPU_THREADS"
+    return cores, info
+
+
+def cpu_baseline(wl, log2n):
+    """Reference / oracle timed on this box's host cores.  Checker code: used here only as the thing measured
+    BESIDE the GPU, never on the product path."""
+    cores, core_info = usable_cores()                  # before libgomp loads: with a binding policy it pins this thread to one core
+    os.environ.setdefault("OMP_PLACES", "cores")       # read by libgomp when it is first loaded
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
     import numpy as np
     from oracle import oracle as orc
 
-    n = 1 << log2n
     o = orc.Oracle()
-    a = o.uniform_f32(n, 1, -1.0, 1.0)
-    b = o.uniform_f32(n, 2, -1.0, 1.0)
-    out = np.empty_like(a)
+    ref = orc.Reference() if orc.Reference.available() else None
+    res = {"unit": "Gelem/s", "threads_visible": o.num_threads(), "usable_cores": cores, "core_accounting": core_info}
 
-    def best(fn, reps):
+    def med(fn, reps):
         ts = []
         for _ in range(reps):
             t = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t)
-        return min(ts), sorted(ts)[len(ts) // 2]
+        return sorted(ts)[len(ts) // 2]
 
-    res = {"unit": "Gelem/s", "sample": f"1D float32 add, N=2^{log2n} of the 2^28 workload, uniform[-1,1) seeds 1/2",
-           "threads_available": o.num_threads()}
-    o.contiguous(orc.ADD, a, b, out=out)  # warm
-    tmin, tmed = best(lambda: o.contiguous(orc.ADD, a, b, out=out), 5)
-    res["port_1core_prealloc"] = n / tmed / 1e9
-    tmin, tmed = best(lambda: o.contiguous(orc.ADD, a, b, out=out, mt=True), 5)
-    res["port_allcores_prealloc"] = n / tmed / 1e9
-    if orc.Reference.available():
-        r = orc.Reference()
-        r.bench_add_f32(a, b)
-        tmin, tmed = best(lambda: r.bench_add_f32(a, b), 5)
-        res.update(kind="reference", value=n / tmed / 1e9, cores=1,
-                   note="SMArray<float>::operator+ (SMArray.h:217-225 -> calculate.h:101-134): single thread, "
-                        "result new[]-allocated and first-touched inside the timed call, as benchmark/add.cpp times it")
+    def both(fn_shipped, threads_shipped, fn_best, units, reps=5):
+        """(as shipped, best effort) Gelem/s; each leg warmed once."""
+        out = {}
+        o.set_threads(threads_shipped)
+        fn_shipped()
+        out["shipped"] = units / med(fn_shipped, reps) / 1e9
+        o.set_threads(cores)
+        fn_best()
+        out["best"] = units / med(fn_best, reps) / 1e9
+        return out
+
+    if wl in ("add", "add_sum"):
+        n = 1 << log2n
+        o.set_threads(cores)  # parallel first touch by the threads that will stream the pages
+        seeds, lo = ((1, 2), -1.0) if wl == "add" else ((6, 7), 0.0)
+        a, b = o.uniform_f32(n, seeds[0], lo, 1.0), o.uniform_f32(n, seeds[1], lo, 1.0)
+        out = np.empty_like(a)
+        o.contiguous(orc.ADD, a, b, out=out, mt=True)
+        if wl == "add":
+            res["sample"] = f"1D float32 add, N=2^{log2n} of the 2^28 workload, uniform[-1,1) seeds 1/2"
+            if ref is not None:
+                r = both(lambda: ref.bench_add_f32(a, b), 1, lambda: o.contiguous(orc.ADD, a, b, out=out, mt=True), n)
+                res.update(kind="reference", value=r["shipped"], cores=1,
+                           note="SMArray<float>::operator+ (SMArray.h:217-225 -> calculate.h:101-134): single thread (the contiguous "
+                                "path has no OpenMP), result new[]-allocated and first-touched inside the timed call, as benchmark/add.cpp times it")
+            else:
+                r = both(lambda: o.contiguous(orc.ADD, a, b, out=out), 1, lambda: o.contiguous(orc.ADD, a, b, out=out, mt=True), n)
+                res.update(kind="port", value=r["shipped"], cores=1,
+                           note="oracle restatement of handle_contiguous_arrays (calculate.h:101-134), single thread as the reference runs it, output preallocated")
+            o.set_threads(1)
+            res["port_1core_prealloc"] = n / med(lambda: o.contiguous(orc.ADD, a, b, out=out), 5) / 1e9
+        else:
+            res["sample"] = f"1D float32 add + fp64 sum, N=2^{log2n} of the 2^28-per-GPU workload, uniform[0,1) seeds 6/7"
+            r = both(lambda: o.contiguous_sum(orc.ADD, a, b), 1, lambda: o.contiguous_sum_mt(orc.ADD, a, b, out=out), n)
+            res.update(kind="port", value=r["shipped"], cores=1,
+                       note="the reference has no sum(): its contiguous add (one thread, calculate.h:101-134) followed by an fp64 "
+                            "accumulation pass over the result, restated in oracle/sm_oracle.c")
+        res["best_effort"] = {"value": r["best"], "cores": cores,
+                              "what": "oracle restatement, contiguous blocks over all usable cores (proc_bind spread), output preallocated and first-touched in parallel"}
+    elif wl == "bcast_mul":
+        rows = cols = 4096
+        o.set_threads(cores)
+        A, row = o.uniform_f32(rows * cols, 3, -1.0, 1.0), o.uniform_f32(cols, 4, -1.0, 1.0)
+        res["sample"] = "the full config: (4096x4096) * (1x4096) float32, seeds 3/4"
+        eng = ref if ref is not None else o
+        fn = lambda: eng.elementwise(orc.MUL, A, [cols, 1], row, [0, 1], [rows, cols])
+        # element_wise_op's general loop IS the all-thread form (OpenMP static over 1024-element chunks, calculate.h:47-49)
+        r = both(fn, cores, fn, rows * cols, reps=3)
+        res.update(kind="reference" if ref is not None else "port", value=r["best"], cores=cores,
+                   note="element_wise_op<float, MultiplyOp> (calculate.h:5-99): scalar unravel with ndim div+mod per element, OpenMP over "
+                        "1024-element chunks on all usable cores, result allocated per call as SMArray::operator* does")
+    elif wl == "pow":
+        n = 1 << min(log2n, 24)
+        o.set_threads(cores)
+        a = o.uniform_f32(n, 5, 0.01, 100.0)
+        out = np.empty_like(a)
+        res["sample"] = f"pow(a, 2.5f) on the first 2^{min(log2n, 24)} of the 2^26 elements, a in (0.01,100) seed 5"
+        r = both(lambda: o.array_scalar(orc.POW, a, np.float32(2.5), out=out), 1,
+                 lambda: o.array_scalar_mt(orc.POW, a, np.float32(2.5), out=out), n, reps=3)
+        res.update(kind="port", value=r["best"], cores=cores, one_core=r["shipped"],
+                   note="the reference's float pow has no array body that links (pow.h:12-13); its arithmetic is PowOp<float>::apply = "
+                        "std::pow per element (pow.h:8-10), run here as array_scalar_op's OpenMP loop would (calculate.h:152) on all usable cores")
     else:
-        res.update(kind="port", value=res["port_1core_prealloc"], cores=1,
-                   note="oracle restatement of handle_contiguous_arrays (calculate.h:101-134), single thread as the "
-                        "reference runs it, output preallocated")
+        return None
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
@@ -108,37 +214,142 @@ def cpu_baseline(log2n):
                     break
     except OSError:
         pass
-    res["nproc"] = os.cpu_count()
     res["flags"] = "reference: g++ -std=c++20 -O3 -DNDEBUG -fopenmp -mavx2 -mfma; port: gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp"
-    # BASELINE config 1: the reference's own CPU-runnable case (benchmark/add.cpp million_check, N = 1e6,
-    # published 666 833 ns on a Ryzen 5 3600): reference / port on this host, same operator path
-    m = 1_000_000
-    am, bm = o.uniform_f32(m, 1, -1.0, 1.0), o.uniform_f32(m, 2, -1.0, 1.0)
-    om = np.empty_like(am)
-    c1 = {"n": m}
-    tmin, tmed = best(lambda: o.contiguous(orc.ADD, am, bm, out=om), 200)
-    c1["port_1core_ns"] = tmed * 1e9
-    if orc.Reference.available():
-        r = orc.Reference()
-        tmin, tmed = best(lambda: r.bench_add_f32(am, bm), 200)
-        c1["reference_ns"] = tmed * 1e9
-    res["config1_million_check"] = c1
+    if wl == "add":
+        # BASELINE config 1: the reference's own CPU-runnable case (benchmark/add.cpp million_check, N = 1e6,
+        # published 666 833 ns on a Ryzen 5 3600): reference / port on this host, same operator path
+        o.set_threads(1)
+        m = 1_000_000
+        am, bm = o.uniform_f32(m, 1, -1.0, 1.0), o.uniform_f32(m, 2, -1.0, 1.0)
+        om = np.empty_like(am)
+        c1 = {"n": m, "port_1core_ns": med(lambda: o.contiguous(orc.ADD, am, bm, out=om), 200) * 1e9}
+        if ref is not None:
+            c1["reference_ns"] = med(lambda: ref.bench_add_f32(am, bm), 200) * 1e9
+        res["config1_million_check"] = c1
     return res
 
 
-def main():
-    args = parse()
+# ----------------------------------------------------------------------------------------------- launching
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as children.  This process
+    has not imported torch or touched HIP, and it never becomes a rank itself."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def traffic_from_profiles(wl):
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(tpath) as f:
+            tj = json.load(f)
+        t = tj.get(wl, {}).get("hbm_bytes_per_launch")
+        meta = tj.get("_meta", {})
+    except (OSError, ValueError):
+        return None, None
+    if t is None:
+        return None, None
+    src = ("NOT measured in this run: profiles/traffic_latest.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+           f"`bench.py --workload {wl}` (tools/pmc_traffic.sh; FETCH_SIZE doubled per the guide's gfx950 correction)")
+    if meta:
+        src += f"; collected {meta.get('date', '?')} at commit {meta.get('commit', '?')}"
+    return t, src
+
+
+def build_workload(lib, sma, np, C, wl, args, rank, bound):
+    """(step, units, algorithmic bytes, kernel name, workload text, keep-alive objects, extras) on the current device."""
+    F32 = np.float32
+    i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
+    if wl in ("add", "add_sum"):
+        log2n = args.log2n or 28
+        n = 1 << log2n
+        first = rank * n  # this rank's shard of the global array
+        seeds, lo = ((1, 2), -1.0) if wl == "add" else ((6, 7), 0.0)
+        a = lib.uniform_f32(n, seeds[0], lo, 1.0, first=first)
+        b = lib.uniform_f32(n, seeds[1], lo, 1.0, first=first)
+        c = lib.empty((n,), F32)
+        sum_ptr = lib.alloc(8)
+        if wl == "add":
+            step = bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+                         C.c_void_p(c.ptr), C.c_size_t(n))
+            kernel = "contiguous_vec_kernel<float, AddOp<float>, 1024>"
+        else:
+            step = bound(lib.c.smhip_contiguous_sum_async, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+                         C.c_void_p(c.ptr), C.c_size_t(n), C.c_void_p(sum_ptr))
+            kernel = "reduce_kernel<float, AddOp<float>, kFused>"
+        text = f"1D float32 {'add' if wl == 'add' else 'fused add+sum'}, N=2^{log2n} per GPU, contiguous, HBM-resident"
+        return step, n, 12 * n, kernel, text, (a, b, c), {"log2n": log2n, "n": n, "sum_ptr": sum_ptr}
+    if wl == "bcast_mul":
+        rows = cols = 4096
+        A = lib.uniform_f32(rows * cols, 3, -1.0, 1.0)
+        r = lib.uniform_f32(cols, 4, -1.0, 1.0)
+        out = lib.empty((rows, cols), F32)
+        step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([cols, 1]),
+                     C.c_void_p(r.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr))
+        return (step, rows * cols, 4 * (2 * rows * cols + cols), "row_kernel<float, MultiplyOp<float>, 1, 1, false, true, 256, 2>",
+                "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident", (A, r, out), {})
+    if wl == "transpose_add":
+        rows = cols = 8192
+        A = lib.uniform_f32(rows * cols, 8, -1.0, 1.0)
+        B = lib.uniform_f32(rows * cols, 9, -1.0, 1.0)
+        out = lib.empty((cols, rows), F32)
+        step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([1, cols]),
+                     C.c_void_p(B.ptr), i64([rows, 1]), i64([cols, rows]), C.c_int(2), C.c_void_p(out.ptr))
+        return (step, rows * cols, 12 * rows * cols, "tile_kernel<float, AddOp<float>, true, 1, 0>",
+                "2D float32 A.T + B, 8192x8192, A read through a transposed view, HBM-resident", (A, B, out), {})
+    log2n = args.log2n or 26
+    n = 1 << log2n
+    a = lib.uniform_f32(n, 5, 0.01, 100.0)
+    out = lib.empty((n,), F32)
+    exponent = C.c_float(2.5)
+    step = bound(lib.c.smhip_array_scalar, C.c_int(sma.OP_POW), C.c_int(sma.F32), C.c_void_p(a.ptr), C.byref(exponent),
+                 C.c_size_t(n), C.c_void_p(out.ptr))
+    return (step, n, 8 * n, "heavy_vec_kernel<float, PowOp<float>, 1>",
+            f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident", (a, out, exponent), {"log2n": log2n})
+
+
+def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra):
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_source = traffic_from_profiles(wl)
+    line = {
+        "metric": BASELINE_METRIC if wl == "add" else f"Gelem/s, {WORKLOADS[wl][1]}",
+        "value": value, "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "elements_per_gpu": units, "sharding": f"outer-dim x{world}, no data-path collective",
+                   "kernel": kernel, "processes": "one per GPU" if mode == "ranks" else "one process, one host thread, all GPUs (smhip_set_devices)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                     "kernel_ms_median_of_20_single_launches": singles[len(singles) // 2], "kernel_ms_min": singles[0],
+                     "per_gpu": "slowest GPU's average launch" if world > 1 else "the GPU's average launch",
+                     "peak_source": "MI355X HBM3E 8.0 TB/s spec (MI355X_MICROARCH.md); the guide's measured float4 copy is 6.29 TB/s"},
+    }
+    if c5:
+        line["c5"] = c5
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
+# ------------------------------------------------------------------------------------- one process per GPU
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run (one rank per GPU)")
 
     dist = torch = None
     if world > 1:
-        # torch first: libsmhip must bind to the HIP runtime torch already loaded (one runtime per process)
+        # torch first: libsmhip then binds to the HIP runtime and the RCCL torch already loaded (same sonames)
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -149,27 +360,28 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    import ctypes as C
     import numpy as np
     import simplemath_amd as sma
 
     lib = sma.load()  # raises if the HIP library is missing: no CPU fallback
     lib.set_device(local_rank)
-    if torch is not None:
-        # One explicit side stream shared by libsmhip's kernels and torch's collectives, so the all-reduce of
-        # a partial sum is ordered after the kernel that produced it.  (torch's default stream is the null
-        # stream, whose handle 0 libsmhip reads as "use your own stream" -- hence a real stream object.)
-        side = torch.cuda.Stream()
-        torch.cuda.set_stream(side)
-        lib.set_stream(side.cuda_stream)
+
+    use_lib_comm = world > 1 and args.dist_backend == "nccl"
+    if use_lib_comm:
+        # libsmhip's own communicator for config 5's all-reduce: the unique id travels over torch.distributed
+        box = [lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        lib.comm_init_rank(world, rank, box[0])
 
     def barrier():
         lib.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
-
-    import ctypes as C
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
 
     def bound(fn, *cargs):
         """One step = one C-ABI call with its arguments converted once, outside the timed region
@@ -181,66 +393,10 @@ def main():
         return call
 
     wl = args.workload
-    F32 = np.float32
-    if wl == "add" or wl == "add_sum":
-        log2n = args.log2n or 28
-        n = 1 << log2n
-        first = rank * n  # this rank's shard of the global array
-        a = lib.uniform_f32(n, 1 if wl == "add" else 6, -1.0 if wl == "add" else 0.0, 1.0, first=first)
-        b = lib.uniform_f32(n, 2 if wl == "add" else 7, -1.0 if wl == "add" else 0.0, 1.0, first=first)
-        c = lib.empty((n,), F32)
-        sum_ptr = lib.alloc(8)
-        units, alg_bytes = n, 12 * n
-        if wl == "add":
-            step = bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
-                         C.c_void_p(c.ptr), C.c_size_t(n))
-            kernel = "contiguous_vec_kernel<float, AddOp<float>, 1024>"
-        else:
-            step = bound(lib.c.smhip_contiguous_sum_async, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
-                         C.c_void_p(c.ptr), C.c_size_t(n), C.c_void_p(sum_ptr))
-            kernel = "reduce_kernel<float, AddOp<float>, kFused>"
-        workload = f"1D float32 {'add' if wl == 'add' else 'fused add+sum'}, N=2^{log2n} per GPU, contiguous, HBM-resident"
-    elif wl == "bcast_mul":
-        rows = cols = 4096
-        A = lib.uniform_f32(rows * cols, 3, -1.0, 1.0)
-        r = lib.uniform_f32(cols, 4, -1.0, 1.0)
-        A2 = sma.DeviceArray(lib, A.base_ptr, F32, (rows, cols), (cols, 1), 0, A._owner)
-        r2 = sma.DeviceArray(lib, r.base_ptr, F32, (1, cols), (cols, 1), 0, r._owner)
-        out = lib.empty((rows, cols), F32)
-        units, alg_bytes = rows * cols, 4 * (2 * rows * cols + cols)
-        i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
-        step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A2.ptr), i64([cols, 1]),
-                     C.c_void_p(r2.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr))
-        kernel = "row_kernel<float, MultiplyOp<float>, 1, 1, false, true, 256, 2>"
-        workload = "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident"
-    elif wl == "transpose_add":
-        rows = cols = 8192
-        A = lib.uniform_f32(rows * cols, 8, -1.0, 1.0)
-        B = lib.uniform_f32(rows * cols, 9, -1.0, 1.0)
-        AT = sma.DeviceArray(lib, A.base_ptr, F32, (cols, rows), (1, cols), 0, A._owner)  # A.transpose()
-        B2 = sma.DeviceArray(lib, B.base_ptr, F32, (cols, rows), (rows, 1), 0, B._owner)
-        out = lib.empty((cols, rows), F32)
-        units, alg_bytes = rows * cols, 12 * rows * cols
-        i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
-        step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(AT.ptr), i64([1, cols]),
-                     C.c_void_p(B2.ptr), i64([rows, 1]), i64([cols, rows]), C.c_int(2), C.c_void_p(out.ptr))
-        kernel = "tile_kernel<float, AddOp<float>, true, 1, 0>"
-        workload = "2D float32 A.T + B, 8192x8192, A read through a transposed view, HBM-resident"
-    else:  # pow
-        log2n = args.log2n or 26
-        n = 1 << log2n
-        a = lib.uniform_f32(n, 5, 0.01, 100.0)
-        out = lib.empty((n,), F32)
-        units, alg_bytes = n, 8 * n
-        exponent = C.c_float(2.5)
-        step = bound(lib.c.smhip_array_scalar, C.c_int(sma.OP_POW), C.c_int(sma.F32), C.c_void_p(a.ptr), C.byref(exponent),
-                     C.c_size_t(n), C.c_void_p(out.ptr))
-        kernel = "heavy_vec_kernel<float, PowOp<float>, 1>"
-        workload = f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident"
+    step, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, rank, bound)
 
-    # Clock ramp: the chip needs tens of milliseconds of continuous work to leave its idle clocks (a
-    # VALU-heavy launch measures 115 us cold and 94 us ramped, tools/powexp2.py), and W short steps may
-    # not last that long.  Untimed pre-warm for ~0.2 s, then the contract's W warm-up steps.
+    # Clock ramp: the chip needs tens of milliseconds of continuous work to leave its idle clocks (a VALU-heavy launch
+    # measures 115 us cold and 94 us ramped), and W short steps may not last that long.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm:
         for _ in range(20):
@@ -283,16 +439,21 @@ def main():
     # config 5's exchange step: fused add+sum per shard, then ONE all-reduce of the fp64 scalar
     c5 = None
     if wl == "add" and world > 1:
-        part = torch.zeros(1, dtype=torch.float64, device="cuda")
+        n, log2n = info["n"], info["log2n"]
+        del keep, step  # the headline operands go back to the pool; config 5 has its own (seeds 6/7 in [0,1))
+        a5 = lib.uniform_f32(n, 6, 0.0, 1.0, first=rank * n)
+        b5 = lib.uniform_f32(n, 7, 0.0, 1.0, first=rank * n)
+        c5out = lib.empty((n,), np.float32)
+        part = info["sum_ptr"]
 
         def c5_step():
-            lib.contiguous_sum_async(sma.OP_ADD, a, b, c, part.data_ptr())  # partial sum stays in HBM
-            if coll_dev == "cuda":
-                dist.all_reduce(part)  # RCCL, same stream: 8 bytes per rank
-                return part
-            host = part.cpu()  # gloo rehearsal: the collective runs on the host copy
+            lib.contiguous_sum_async(sma.OP_ADD, a5, b5, c5out, part)  # the partial sum stays in HBM
+            if use_lib_comm:
+                lib.allreduce_sum_async(np.float64, part, 1)  # RCCL from libsmhip, same stream: 8 bytes per rank
+                return None
+            host = torch.tensor([lib.read_f64(part)], dtype=torch.float64)  # gloo rehearsal: the exchange runs on the host
             dist.all_reduce(host)
-            return host
+            return float(host[0])
 
         for _ in range(3):
             total = c5_step()
@@ -303,60 +464,173 @@ def main():
             total = c5_step()
         barrier()
         tc = (time.perf_counter() - tc) / reps
-        part = total
+        if use_lib_comm:
+            total = lib.read_f64(part)
         tt = torch.tensor([tc], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        c5 = {"workload": f"fused add+sum over {world} x 2^{log2n} f32 + one RCCL all-reduce (1 x fp64)",
-              "ms_per_step": float(tt[0]) * 1e3, "value": world * n / float(tt[0]) / 1e9, "unit": "Gelem/s",
-              "global_sum": float(part[0])}
+        backend = "libsmhip -> ncclAllReduce (RCCL over xGMI), on the kernel's stream" if use_lib_comm else "gloo on the host (rehearsal, not RCCL)"
+        c5 = {"workload": f"fused add+sum over {world} x 2^{log2n} f32 (uniform[0,1), seeds 6/7) + one all-reduce of 1 x fp64",
+              "allreduce": backend, "ms_per_step": float(tt[0]) * 1e3, "value": world * n / float(tt[0]) / 1e9, "unit": "Gelem/s",
+              "global_sum": total, "expected_sum_approx": float(world) * n}
 
     if rank == 0:
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                traffic = tj.get(wl, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
-        line = {
-            "metric": BASELINE_METRIC if wl == "add" else f"Gelem/s, {WORKLOADS[wl][1]}",
-            "value": value, "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "elements_per_gpu": units, "sharding": f"outer-dim x{world}, no data-path collective",
-                       "kernel": kernel},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
-                         "kernel_ms_median_of_20_single_launches": singles[len(singles) // 2], "kernel_ms_min": singles[0],
-                         "peak_source": "MI355X HBM3E 8.0 TB/s spec (MI355X_MICROARCH.md); the guide's measured float4 copy is 6.29 TB/s"},
-        }
-        if c5:
-            line["c5"] = c5
-        if world == 1 and not args.no_cpu_baseline and wl == "add":
-            line["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
-            # the same million_check body on the GPU (operands resident, result from the pool)
-            m = 1_000_000
-            am, bm = lib.uniform_f32(m, 1, -1.0, 1.0), lib.uniform_f32(m, 2, -1.0, 1.0)
-            om = lib.empty((m,), F32)
-            small = bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(am.ptr), C.c_void_p(bm.ptr),
-                          C.c_void_p(om.ptr), C.c_size_t(m))
-            for _ in range(200):
-                small()
-            lib.synchronize()
-            tq = time.perf_counter()
-            for _ in range(2000):
-                small()
-            lib.synchronize()
-            line["cpu_baseline"]["config1_million_check"]["gpu_ns"] = (time.perf_counter() - tq) / 2000 * 1e9
-        print(json.dumps(line), flush=True)
+        extra = {}
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(wl, args.cpu_log2n)
+            if cb is not None:
+                extra["cpu_baseline"] = cb
+            if wl == "add":
+                # the same million_check body on the GPU (operands resident, result from the pool)
+                m = 1_000_000
+                am, bm = lib.uniform_f32(m, 1, -1.0, 1.0), lib.uniform_f32(m, 2, -1.0, 1.0)
+                om = lib.empty((m,), np.float32)
+                small = bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(am.ptr), C.c_void_p(bm.ptr),
+                              C.c_void_p(om.ptr), C.c_size_t(m))
+                for _ in range(200):
+                    small()
+                lib.synchronize()
+                tq = time.perf_counter()
+                for _ in range(2000):
+                    small()
+                lib.synchronize()
+                cb["config1_million_check"]["gpu_ns"] = (time.perf_counter() - tq) / 2000 * 1e9
+        emit(args, wl, world, "ranks", value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra)
 
+    if use_lib_comm:
+        lib.synchronize()
+        lib.comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+# ----------------------------------------------------------------------------- one process, N devices
+
+def run_single(args):
+    """The product's own multi-GPU form: smhip_set_devices(N), per-device pointer tables, one host thread."""
+    import ctypes as C
+    import numpy as np
+    import simplemath_amd as sma
+
+    if args.workload != "add":
+        raise SystemExit("--mode single runs the headline `add` workload (and its config-5 leg)")
+    lib = sma.load()
+    G = args.gpus
+    lib.set_devices(G)
+    log2n = args.log2n or 28
+    n = 1 << log2n
+    F32 = np.float32
+    arrays = []
+
+    def on_each(seed_a, seed_b, lo):
+        aa, bb, cc = [], [], []
+        for g in range(G):
+            lib.set_device(g)
+            aa.append(lib.uniform_f32(n, seed_a, lo, 1.0, first=g * n))
+            bb.append(lib.uniform_f32(n, seed_b, lo, 1.0, first=g * n))
+            cc.append(lib.empty((n,), F32))
+        lib.set_device(0)
+        return aa, bb, cc
+
+    aa, bb, cc = on_each(1, 2, -1.0)
+    pt = lambda arrs: (C.c_void_p * G)(*[x.ptr for x in arrs])
+    ns = (C.c_size_t * G)(*([n] * G))
+    pa, pb, pc = pt(aa), pt(bb), pt(cc)
+
+    def step():
+        rc = lib.c.smhip_sharded_contiguous(C.c_int(sma.OP_ADD), C.c_int(sma.F32), pa, pb, pc, ns)
+        if rc < 0:
+            raise sma.SmhipError(rc, lib.c.smhip_last_error().decode())
+
+    def events():
+        ev = []
+        for g in range(G):
+            lib.set_device(g)
+            ev.append((lib.event(), lib.event()))
+        lib.set_device(0)
+        return ev
+
+    def record(ev, which):
+        for g in range(G):
+            lib.set_device(g)
+            lib.record(ev[g][which])
+        lib.set_device(0)
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm:
+        for _ in range(20):
+            step()
+        lib.sharded_synchronize()
+    for _ in range(args.warmup):
+        step()
+    ev = events()
+    lib.sharded_synchronize()
+    t0 = time.perf_counter()
+    record(ev, 0)
+    for _ in range(args.steps):
+        step()
+    record(ev, 1)
+    lib.sharded_synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = max(lib.elapsed_ms(e0, e1) for e0, e1 in ev) / args.steps
+
+    lib.set_device(0)
+    singles = []
+    for _ in range(20):
+        lib.record(ev[0][0])
+        step()
+        lib.record(ev[0][1])
+        lib.sharded_synchronize()
+        singles.append(lib.elapsed_ms(ev[0][0], ev[0][1]))
+    singles.sort()
+
+    # config 5: fused add+sum on every device + ONE ncclAllReduce inside ncclGroupStart/End, scalar back to the host
+    del aa, bb, cc
+    a5, b5, c5o = on_each(6, 7, 0.0)
+    pa, pb, pc = pt(a5), pt(b5), pt(c5o)
+    total = C.c_double(0)
+
+    def c5_step():
+        rc = lib.c.smhip_sharded_contiguous_sum(C.c_int(sma.OP_ADD), C.c_int(sma.F32), pa, pb, pc, ns, C.byref(total))
+        if rc < 0:
+            raise sma.SmhipError(rc, lib.c.smhip_last_error().decode())
+
+    for _ in range(3):
+        c5_step()
+    lib.sharded_synchronize()
+    tc = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        c5_step()
+    lib.sharded_synchronize()
+    tc = (time.perf_counter() - tc) / reps
+    c5 = {"workload": f"fused add+sum over {G} x 2^{log2n} f32 (uniform[0,1), seeds 6/7) + one all-reduce of 1 x fp64",
+          "allreduce": "smhip_sharded_contiguous_sum -> ncclGroupStart / ncclAllReduce x devices / ncclGroupEnd (RCCL), scalar read back each step",
+          "ms_per_step": tc * 1e3, "value": G * n / tc / 1e9, "unit": "Gelem/s", "global_sum": total.value,
+          "expected_sum_approx": float(G) * n}
+
+    extra = {}
+    if G == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline("add", args.cpu_log2n)
+        if cb is not None:
+            extra["cpu_baseline"] = cb
+    emit(args, "add", G, "single", G * n / (wall / args.steps) / 1e9, wall / args.steps * 1e3, n, 12 * n, kern_ms, singles,
+         "contiguous_vec_kernel<float, AddOp<float>, 1024>",
+         f"1D float32 add, N=2^{log2n} per GPU, contiguous, HBM-resident", c5, extra)
+    lib.set_devices(0)
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.mode == "single":
+        return run_single(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)  # before anything has touched the GPU
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

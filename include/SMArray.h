@@ -66,8 +66,10 @@ struct Storage {
     bool host_valid = false;  // host mirror holds the current values
     bool dev_valid = false;   // device buffer holds the current values
 
-    explicit Storage(std::size_t n) : count(n) {}
-    Storage(T *adopted, std::size_t n) : host(adopted), count(n), host_valid(true) {}  // takes ownership of new T[]
+    int device = 0;           // the GPU the device buffer lives on (the creating thread's current device)
+
+    explicit Storage(std::size_t n) : count(n) { smhip_get_device(&device); }
+    Storage(T *adopted, std::size_t n) : host(adopted), count(n), host_valid(true) { smhip_get_device(&device); }  // takes ownership of new T[]
     Storage(const Storage &) = delete;
     Storage &operator=(const Storage &) = delete;
     ~Storage() {
@@ -79,7 +81,10 @@ struct Storage {
     const T *host_ro() {
         if (!host) host = new T[count ? count : 1];
         if (!host_valid) {
-            if (dev_valid) hip::check(smhip_download(host, dev, count * sizeof(T)));
+            if (dev_valid) {
+                hip::DeviceGuard on(device);
+                hip::check(smhip_download(host, dev, count * sizeof(T)));
+            }
             host_valid = true;  // nothing valid anywhere: uninitialised, like sm::empty
         }
         return host;
@@ -92,10 +97,13 @@ struct Storage {
     }
     // device side current, host mirror stays valid
     T *dev_ro() {
-        if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
-        if (!dev_valid) {
-            if (host_valid) hip::check(smhip_upload(dev, host, count * sizeof(T)));
-            dev_valid = true;
+        if (!dev || !dev_valid) {
+            hip::DeviceGuard on(device);
+            if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
+            if (!dev_valid) {
+                if (host_valid) hip::check(smhip_upload(dev, host, count * sizeof(T)));
+                dev_valid = true;
+            }
         }
         return static_cast<T *>(dev);
     }
@@ -107,7 +115,10 @@ struct Storage {
     }
     // device side about to be overwritten entirely
     T *dev_wo() {
-        if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
+        if (!dev) {
+            hip::DeviceGuard on(device);
+            hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
+        }
         dev_valid = true;
         host_valid = false;
         return static_cast<T *>(dev);
@@ -407,6 +418,7 @@ public:
     T *device_data_mut() { return data.storage()->dev_wo() + data.offset(); }
     bool is_dense() const { return is_contiguous(_shape, _strides); }
     bool is_view() const { return isView; }
+    int device() const { return data.storage()->device; }  // the GPU this array's elements live on
 
     // A new dense array whose elements exist only in HBM so far.
     static SMArray device_empty(std::vector<std::size_t> &&shape) {

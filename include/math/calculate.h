@@ -43,6 +43,21 @@ inline void check(int rc) {
     if (rc < 0) throw std::runtime_error(std::string("smhip: ") + smhip_last_error());
 }
 
+// Makes `device` the calling thread's current GPU for a scope (a no-op when it already is).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device) {
+        smhip_get_device(&prev_);
+        if (device != prev_) { check(smhip_set_device(device)); switched_ = true; }
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    ~DeviceGuard() { if (switched_) smhip_set_device(prev_); }
+private:
+    int prev_ = 0;
+    bool switched_ = false;
+};
+
 // RAII pooled device buffer (smhip_alloc / smhip_free).
 class DeviceBuffer {
 public:

@@ -3,3 +3,4 @@
 #pragma once
 
 #include "UserFunctions.h"  // brings SMArray.h, the Op policies and the loop entry points with it
+#include "Sharded.h"        // sm::set_devices, sm::Sharded<T>: the same operators over the GPUs of one node

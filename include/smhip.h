@@ -79,7 +79,9 @@ int smhip_device_count(int *count);
 int smhip_set_device(int device);
 int smhip_get_device(int *device);
 /* Use the caller's hipStream_t (e.g. torch's current stream) for this thread;
- * NULL restores the library's own stream. */
+ * NULL restores the library's own stream.  The new stream is ordered after the
+ * thread's previous one (buffers used before the switch may be freed after it).
+ * The stream must stay alive until the thread has switched away from it. */
 int smhip_set_stream(void *hip_stream);
 int smhip_get_stream(void **hip_stream);
 int smhip_synchronize(void);
@@ -167,6 +169,68 @@ int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, 
  * (SMArray.h:217-305 x 2) at 2/3 (array c) or 1/2 (scalar c) of their HBM traffic. */
 int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const void *b, const void *c,
                            const void *c_scalar_host, void *out, size_t n);
+
+/* ----------------------------------------------------------- multi-GPU */
+/* The reference's only fan-out is the OpenMP `parallel for` over chunks of the output (calculate.h:47, :152).  Its
+ * MI355X counterpart is the RESULT's outermost dimension cut into one block per GPU of the node: elementwise blocks
+ * are independent (no data-path collective at all); a whole-array reduction ends in ONE RCCL all-reduce of an 8-byte
+ * scalar over xGMI.  Two ways to drive it:
+ *   (1) one process, n devices:  smhip_set_devices(n) makes devices 0..n-1 a group (one library stream per device,
+ *       communicators from ncclCommInitAll) and the smhip_sharded_* entry points take PER-DEVICE POINTER TABLES
+ *       (entry g = a buffer on device g, e.g. from smhip_set_device(g) + smhip_alloc).  This is what sm::set_devices /
+ *       sm::Sharded<T> (include/Sharded.h) use.
+ *   (2) one process per GPU (torchrun-style):  rank 0 calls smhip_comm_unique_id, every rank smhip_comm_init_rank
+ *       with its device selected; each rank then runs the ordinary single-device entry points on its shard and
+ *       smhip_allreduce_sum_async on its partial.
+ * RCCL (librccl.so.1) is loaded when one of these is first called; a process that never does needs no RCCL. */
+
+/* Near-equal contiguous blocks of `n` items over `world` ranks: the first n % world ranks get one extra. Host only. */
+int smhip_split_range(int64_t n, int world, int rank, int64_t *start, int64_t *count);
+/* Rank `rank`'s block of the broadcast problem (shape, stride_a, stride_b as smhip_broadcast returns them), cut along
+ * dim 0: its result shape, the element offsets of its block in a, b and the dense result, and whether an operand is
+ * broadcast along dim 0 and therefore needed whole on every device (bit 0: a, bit 1: b).  Host only. */
+int smhip_shard_outer(const int64_t *shape, const int64_t *stride_a, const int64_t *stride_b, int ndim, int world, int rank,
+                      int64_t *shard_shape, int64_t *offset_a, int64_t *offset_b, int64_t *offset_out, int *replicated_mask);
+
+/* Devices 0..n-1 become the group (n >= 1; n = 1 still goes through RCCL with a one-rank communicator).  Replaces an
+ * earlier group; n = 0 dissolves it.  Not to be called while sharded work of another thread is in flight. */
+int smhip_set_devices(int n);
+int smhip_get_devices(int *n);
+/* Blocks until every device of the group has finished its queued work. */
+int smhip_sharded_synchronize(void);
+
+/* handle_contiguous_arrays per device: out[g][i] = a[g][i] op b[g][i], i < n[g].  Asynchronous, no collective. */
+int smhip_sharded_contiguous(int op, int dtype, const void *const *a, const void *const *b, void *const *out, const size_t *n);
+/* array_scalar_op per device. */
+int smhip_sharded_array_scalar(int op, int dtype, const void *const *a, const void *value_host, const size_t *n, void *const *out);
+/* element_wise_op over the group: `shape` is the GLOBAL result shape; device g computes block g of dim 0
+ * (smhip_shard_outer).  a[g] / b[g] point at the FIRST ELEMENT OF DEVICE g's BLOCK of that operand when its dim-0
+ * stride is non-zero (the operand is sharded like the result), or at device g's full copy when the stride is 0 (the
+ * operand is broadcast along dim 0 and replicated, e.g. BASELINE config 3's 16 KiB row); the inner strides are the
+ * same on every device.  out[g] is device g's dense block.  Asynchronous, no collective. */
+int smhip_sharded_elementwise(int op, int dtype, const void *const *a, const int64_t *stride_a, const void *const *b,
+                              const int64_t *stride_b, const int64_t *shape, int ndim, void *const *out);
+/* BASELINE config 5: out[g] = a[g] op b[g] and the sum of ALL results, fused per device (12 B/elem for f32), then ONE
+ * ncclAllReduce(1 x fp64, sum) inside ncclGroupStart/End; the total is written to *sum_host (every device also holds
+ * it).  Synchronous for the scalar only: the other devices' streams are not waited for. */
+int smhip_sharded_contiguous_sum(int op, int dtype, const void *const *a, const void *const *b, void *const *out, const size_t *n,
+                                 double *sum_host);
+/* Whole-array sum / dot of a sharded array: per-device partial + one all-reduce.  dot: the element type's value to
+ * *out_host (f32/f64 via fp64 partials; i32/i64 wrap exactly like the single-device and the reference's result). */
+int smhip_sharded_sum(int dtype, const void *const *a, const size_t *n, double *sum_host);
+int smhip_sharded_dot(int dtype, const void *const *a, const void *const *b, const size_t *n, void *out_host);
+
+/* One process per GPU.  id128: NCCL_UNIQUE_ID_BYTES (128) bytes, produced on one rank and carried to the others by
+ * the launcher's own channel (bench.py: torch.distributed broadcast; MPI_Bcast; a file).  smhip_comm_init_rank binds
+ * the communicator to the calling thread's current device and is collective over the ranks. */
+int smhip_comm_unique_id(void *id128);
+int smhip_comm_init_rank(int nranks, int rank, const void *id128);
+int smhip_comm_info(int *nranks, int *rank);
+int smhip_comm_destroy(void);
+/* In-place sum over the ranks of `count` values in device memory, on the calling thread's stream (so it is ordered
+ * after the kernel that produced them): SMHIP_F32 / SMHIP_F64 as floats, SMHIP_I32 / SMHIP_I64 wrapping (modulo 2^32 /
+ * 2^64).  Asynchronous. */
+int smhip_allreduce_sum_async(int dtype, void *inout_dev, size_t count);
 
 /* -------------------------------------------------------------- timing */
 /* HIP events on the calling thread's stream (what bench.py brackets the

@@ -66,6 +66,9 @@ class Oracle(_Lib):
         L.smo_elementwise.restype = C.c_int
         L.smo_contiguous.restype = C.c_int
         L.smo_contiguous_mt.restype = C.c_int
+        L.smo_array_scalar_mt.restype = C.c_int
+        L.smo_contiguous_sum_mt.restype = C.c_double
+        L.smo_set_threads.restype = None
         L.smo_array_scalar.restype = C.c_int
         L.smo_powi32.restype = C.c_int32
         L.smo_powi32.argtypes = [C.c_int32, C.c_int32]
@@ -173,6 +176,25 @@ class Oracle(_Lib):
 
     def num_threads(self):
         return int(self.lib.smo_num_threads())
+
+    # -- all-core forms (bench.py's CPU baseline only) ----------------------
+    def set_threads(self, n):
+        self.lib.smo_set_threads(C.c_int(int(n)))
+
+    def array_scalar_mt(self, op, a, value, out=None):
+        v = np.array([value], dtype=a.dtype)
+        if out is None:
+            out = np.empty(a.size, dtype=a.dtype)
+        rc = self.lib.smo_array_scalar_mt(C.c_int(op), C.c_int(DTYPES[a.dtype]), _ptr(a), _ptr(v), C.c_size_t(a.size), _ptr(out))
+        if rc:
+            raise ValueError(f"smo_array_scalar_mt rc={rc}")
+        return out
+
+    def contiguous_sum_mt(self, op, a, b, out=None):
+        if out is None:
+            out = np.empty_like(a)
+        s = self.lib.smo_contiguous_sum_mt(C.c_int(op), C.c_int(DTYPES[a.dtype]), _ptr(a), _ptr(b), _ptr(out), C.c_size_t(a.size))
+        return out, float(s)
 
 
 class Reference(_Lib):

@@ -172,22 +172,31 @@ int smo_contiguous(int op, int dtype, const void *a, const void *b, void *r, siz
     return -1;
 }
 
+/* Best-effort all-core forms for the CPU baseline beside the GPU: the same loops cut into one
+ * contiguous block per thread (64-element aligned so vector bodies stay aligned), threads spread over the cores.
+ * The thread count is whatever smo_set_threads() last set -- bench.py caps it at the physical cores this process may
+ * actually use (cgroup quota, affinity): 256 unbound SMT threads under a 16-CPU quota ran SLOWER than one core. */
+static void mt_block(size_t n, size_t *lo, size_t *hi) {
+#ifdef _OPENMP
+    const size_t nt = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+#else
+    const size_t nt = 1, t = 0;
+#endif
+    size_t per = ((n + nt - 1) / nt + 63) & ~(size_t)63;
+    *lo = t * per;
+    *hi = *lo + per;
+    if (*lo > n) *lo = n;
+    if (*hi > n) *hi = n;
+}
+
 int smo_contiguous_mt(int op, int dtype, const void *a, const void *b, void *r, size_t n) {
     if (op < SMO_ADD || op > SMO_POW) return -1;
     const size_t esz = (dtype == SMO_F64 || dtype == SMO_I64) ? 8 : 4;
     int rc = 0;
-#pragma omp parallel
+#pragma omp parallel proc_bind(spread)
     {
-#ifdef _OPENMP
-        const size_t nt = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
-#else
-        const size_t nt = 1, t = 0;
-#endif
-        /* contiguous blocks, 64-element aligned so vector bodies stay aligned */
-        size_t per = ((n + nt - 1) / nt + 63) & ~(size_t)63;
-        size_t lo = t * per, hi = lo + per;
-        if (lo > n) lo = n;
-        if (hi > n) hi = n;
+        size_t lo, hi;
+        mt_block(n, &lo, &hi);
         if (hi > lo) {
             int c = smo_contiguous(op, dtype, (const char *)a + lo * esz,
                                    (const char *)b + lo * esz, (char *)r + lo * esz, hi - lo);
@@ -392,6 +401,66 @@ double smo_sum_f64acc(int dtype, const void *a, size_t n) {
 double smo_contiguous_sum(int op, int dtype, const void *a, const void *b, void *result, size_t n) {
     if (smo_contiguous(op, dtype, a, b, result, n)) return NAN;
     return smo_sum_f64acc(dtype, result, n);
+}
+
+/* array_scalar_op over all cores, as the reference runs it (`#pragma omp parallel for` over the SIMD iterations,
+ * calculate.h:152); float pow is std::pow per element (pow.h:8-10). */
+int smo_array_scalar_mt(int op, int dtype, const void *a, const void *value, size_t n, void *result) {
+    if (op < SMO_ADD || op > SMO_POW) return -1;
+    const size_t esz = (dtype == SMO_F64 || dtype == SMO_I64) ? 8 : 4;
+    int rc = 0;
+#pragma omp parallel proc_bind(spread)
+    {
+        size_t lo, hi;
+        mt_block(n, &lo, &hi);
+        if (hi > lo) {
+            int c = smo_array_scalar(op, dtype, (const char *)a + lo * esz, value, hi - lo, (char *)result + lo * esz, 0);
+            if (c) {
+#pragma omp atomic write
+                rc = c;
+            }
+        }
+    }
+    return rc;
+}
+
+/* a op b stored + the fp64 sum of the results, all cores: per-thread partial sums added in thread order. */
+double smo_contiguous_sum_mt(int op, int dtype, const void *a, const void *b, void *result, size_t n) {
+    const size_t esz = (dtype == SMO_F64 || dtype == SMO_I64) ? 8 : 4;
+    double partial[1024] = {0};
+    int bad = 0, used = 1;
+#pragma omp parallel proc_bind(spread)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#pragma omp single
+        used = omp_get_num_threads();
+#else
+        const int t = 0;
+#endif
+        size_t lo, hi;
+        mt_block(n, &lo, &hi);
+        if (hi > lo && t < 1024) {
+            if (smo_contiguous(op, dtype, (const char *)a + lo * esz, (const char *)b + lo * esz, (char *)result + lo * esz, hi - lo)) {
+#pragma omp atomic write
+                bad = 1;
+            }
+            partial[t] = smo_sum_f64acc(dtype, (const char *)result + lo * esz, hi - lo);
+        }
+    }
+    if (bad || used > 1024) return NAN;
+    double s = 0;
+    for (int t = 0; t < used; ++t) s += partial[t];
+    return s;
+}
+
+/* Threads the *_mt forms (and every later OpenMP region of this thread, the compiled reference's included) use. */
+void smo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 /* ------------------------------------------------------ synthetic inputs */

@@ -99,6 +99,13 @@ void smo_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first,
 
 int smo_num_threads(void);
 
+/* All-core forms for the CPU baseline timed beside the GPU (bench.py cpu_baseline); results are
+ * those of the single-thread functions.  smo_set_threads: threads every later OpenMP region of the calling thread
+ * uses, including the compiled reference's (same libgomp). */
+void smo_set_threads(int n);
+int smo_array_scalar_mt(int op, int dtype, const void *a, const void *value, size_t n, void *result);
+double smo_contiguous_sum_mt(int op, int dtype, const void *a, const void *b, void *result, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

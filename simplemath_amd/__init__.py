@@ -339,6 +339,93 @@ class Smhip:
         self.download(out, ptr)
         return int(out[0])
 
+    # -- multi-GPU ----------------------------------------------------------------
+    def split_range(self, n, world, rank):
+        st, ct = C.c_int64(0), C.c_int64(0)
+        self._ck(self.c.smhip_split_range(C.c_int64(n), C.c_int(world), C.c_int(rank), C.byref(st), C.byref(ct)))
+        return st.value, ct.value
+
+    def shard_outer(self, shape, strides_a, strides_b, world, rank):
+        """The C planner behind sm::Sharded / smhip_sharded_elementwise; same answer as simplemath_amd.sharding.shard_outer."""
+        nd = len(shape)
+        local = _i64([0] * nd)
+        oa, ob, oo = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        mask = C.c_int(0)
+        self._ck(self.c.smhip_shard_outer(_i64(shape), _i64(strides_a), _i64(strides_b), C.c_int(nd), C.c_int(world), C.c_int(rank),
+                                          local, C.byref(oa), C.byref(ob), C.byref(oo), C.byref(mask)))
+        return tuple(local[:nd]), oa.value, ob.value, oo.value, bool(mask.value & 1), bool(mask.value & 2)
+
+    def set_devices(self, n):
+        self._ck(self.c.smhip_set_devices(C.c_int(n)))
+
+    def get_devices(self):
+        n = C.c_int(0)
+        self._ck(self.c.smhip_get_devices(C.byref(n)))
+        return n.value
+
+    def sharded_synchronize(self):
+        self._ck(self.c.smhip_sharded_synchronize())
+
+    @staticmethod
+    def _ptr_table(ptrs):
+        return (C.c_void_p * len(ptrs))(*ptrs)
+
+    @staticmethod
+    def _size_table(ns):
+        return (C.c_size_t * len(ns))(*ns)
+
+    def sharded_contiguous(self, op, dtype, a_ptrs, b_ptrs, out_ptrs, ns):
+        self._ck(self.c.smhip_sharded_contiguous(C.c_int(op), C.c_int(DTYPES[np.dtype(dtype)]), self._ptr_table(a_ptrs),
+                                                 self._ptr_table(b_ptrs), self._ptr_table(out_ptrs), self._size_table(ns)))
+
+    def sharded_array_scalar(self, op, dtype, a_ptrs, value, ns, out_ptrs):
+        v = np.array([value], dtype=dtype)
+        self._ck(self.c.smhip_sharded_array_scalar(C.c_int(op), C.c_int(DTYPES[np.dtype(dtype)]), self._ptr_table(a_ptrs),
+                                                   v.ctypes.data_as(C.c_void_p), self._size_table(ns), self._ptr_table(out_ptrs)))
+
+    def sharded_elementwise(self, op, dtype, a_ptrs, sa, b_ptrs, sb, shape, out_ptrs):
+        self._ck(self.c.smhip_sharded_elementwise(C.c_int(op), C.c_int(DTYPES[np.dtype(dtype)]), self._ptr_table(a_ptrs), _i64(sa),
+                                                  self._ptr_table(b_ptrs), _i64(sb), _i64(shape), C.c_int(len(shape)),
+                                                  self._ptr_table(out_ptrs)))
+
+    def sharded_contiguous_sum(self, op, dtype, a_ptrs, b_ptrs, out_ptrs, ns):
+        total = C.c_double(0)
+        self._ck(self.c.smhip_sharded_contiguous_sum(C.c_int(op), C.c_int(DTYPES[np.dtype(dtype)]), self._ptr_table(a_ptrs),
+                                                     self._ptr_table(b_ptrs), self._ptr_table(out_ptrs), self._size_table(ns),
+                                                     C.byref(total)))
+        return total.value
+
+    def sharded_sum(self, dtype, a_ptrs, ns):
+        total = C.c_double(0)
+        self._ck(self.c.smhip_sharded_sum(C.c_int(DTYPES[np.dtype(dtype)]), self._ptr_table(a_ptrs), self._size_table(ns), C.byref(total)))
+        return total.value
+
+    def sharded_dot(self, dtype, a_ptrs, b_ptrs, ns):
+        out = np.zeros(1, dtype=dtype)
+        self._ck(self.c.smhip_sharded_dot(C.c_int(DTYPES[np.dtype(dtype)]), self._ptr_table(a_ptrs), self._ptr_table(b_ptrs),
+                                          self._size_table(ns), out.ctypes.data_as(C.c_void_p)))
+        return out[0]
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._ck(self.c.smhip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, nranks, rank, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._ck(self.c.smhip_comm_init_rank(C.c_int(nranks), C.c_int(rank), C.c_char_p(unique_id)))
+
+    def comm_info(self):
+        n, r = C.c_int(0), C.c_int(0)
+        self._ck(self.c.smhip_comm_info(C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def comm_destroy(self):
+        self._ck(self.c.smhip_comm_destroy())
+
+    def allreduce_sum_async(self, dtype, ptr, count=1):
+        self._ck(self.c.smhip_allreduce_sum_async(C.c_int(DTYPES[np.dtype(dtype)]), C.c_void_p(ptr), C.c_size_t(count)))
+
     # -- timing -----------------------------------------------------------------
     def event(self):
         e = C.c_void_p(0)

@@ -19,9 +19,39 @@ int acquire(hipStream_t *stream);
 // Compute units of the calling thread's current device (256 on MI355X); valid after acquire().
 int compute_units();
 
-// Per-device scratch for reductions: `count` doubles, stable until the next
-// call with a larger count on the same device.
-int reduce_scratch(size_t count, double **ptr);
+// Device the calling thread's work goes to.
+int current_device();
+
+// Runs the enclosed calls on device `device`'s library stream (whatever stream the thread brought), then puts the
+// thread back: how the sharded entry points walk the device group from one host thread.
+class ThreadDeviceScope {
+public:
+    explicit ThreadDeviceScope(int device);
+    ~ThreadDeviceScope();
+    ThreadDeviceScope(const ThreadDeviceScope &) = delete;
+    ThreadDeviceScope &operator=(const ThreadDeviceScope &) = delete;
+private:
+    int prev_device_;
+    bool prev_use_user_;
+};
+
+// The partials of ONE reduction call: `count` doubles from the pool, handed back when the lease ends.  The pool's
+// stream-ordered reuse makes that safe while the kernels are still queued, and two reductions queued on different
+// streams never share a buffer.
+class ScratchLease {
+public:
+    ScratchLease() = default;
+    ScratchLease(const ScratchLease &) = delete;
+    ScratchLease &operator=(const ScratchLease &) = delete;
+    ~ScratchLease() { if (p_) smhip_free(p_); }
+    int take(size_t count, double **ptr) {
+        if (int rc = smhip_alloc(&p_, (count ? count : 1) * sizeof(double))) return rc;
+        *ptr = static_cast<double *>(p_);
+        return SMHIP_OK;
+    }
+private:
+    void *p_ = nullptr;
+};
 int reduce_finish(int dtype, void *partials, size_t blocks, double *out8, hipStream_t s);
 constexpr int kReduceFoldSpan = 1024;  // = reduce.hip's kFoldSpan: partial buffers need blocks + blocks / span + 1 slots
 

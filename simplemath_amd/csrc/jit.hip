@@ -21,6 +21,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -34,12 +36,25 @@ namespace {
 
 struct UserOp {
     std::string expr;
-    hipModule_t module[4] = {};  // per dtype
-    hipFunction_t contig[4] = {}, scalar[4] = {};
-    std::map<std::string, hipFunction_t> bcast[4];  // broadcast-body variants, by instantiation text
 };
 std::mutex g_jit_mutex;
 std::vector<UserOp *> g_ops;  // id = SMHIP_OP_USER_BASE + index; never freed (ids stay valid)
+
+// One compiled program (source + defines): the gfx950 code object, built once per process (or read from the disk
+// cache), and the module it is loaded as on each device that has launched it -- a hipModule_t belongs to the device
+// that was current when it was loaded, so modules and functions are kept per device (smhip_set_device /
+// smhip_set_devices let one process drive several).
+constexpr int kJitMaxDevices = 64;
+struct Program {
+    int state = 0;  // 0: a thread is building it, 1: ready, 2: failed
+    int rc = SMHIP_OK;
+    std::string error;
+    std::vector<char> code;
+    hipModule_t module[kJitMaxDevices] = {};
+    std::map<std::pair<int, std::string>, hipFunction_t> functions;  // (device, kernel name)
+};
+std::condition_variable g_jit_cv;
+std::map<std::string, Program *> g_programs;  // never freed: modules stay loaded for the life of the process
 
 const char *kTypeName[4] = {"float", "double", "int", "long long"};
 
@@ -224,7 +239,7 @@ uint64_t fnv1a(uint64_t h, const std::string &s) {
 }
 
 int hiprtc_build(const std::string &source, const std::vector<std::string> &defines, const char *what, const std::string &expr,
-                 hipModule_t *mod) {
+                 std::vector<char> *code_out) {
     static const std::string dir = cache_dir();
     std::string path;
     if (!dir.empty()) {
@@ -244,8 +259,11 @@ int hiprtc_build(const std::string &source, const std::vector<std::string> &defi
             size_t got;
             while ((got = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + got);
             fclose(f);
-            if (!code.empty() && hipModuleLoadData(mod, code.data()) == hipSuccess) return SMHIP_OK;
-            // unreadable or stale entry: fall through and rebuild it
+            // an ELF code object of plausible size; a truncated or foreign file is rebuilt (and overwritten) below
+            if (code.size() > 64 && !memcmp(code.data(), "\x7f" "ELF", 4)) {
+                code_out->swap(code);
+                return SMHIP_OK;
+            }
         }
     }
     hiprtcProgram prog;
@@ -267,7 +285,6 @@ int hiprtc_build(const std::string &source, const std::vector<std::string> &defi
     std::vector<char> code(size);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
-    SMHIP_TRY(hipModuleLoadData(mod, code.data()));
     if (!path.empty()) {  // publish atomically: write a private file, then rename it into place
         char tmp[32];
         snprintf(tmp, sizeof tmp, ".%ld.tmp", (long)getpid());
@@ -278,29 +295,67 @@ int hiprtc_build(const std::string &source, const std::vector<std::string> &defi
             if (!ok || rename(tpath.c_str(), path.c_str()) != 0) remove(tpath.c_str());
         }
     }
+    code_out->swap(code);
     return SMHIP_OK;
 }
 
-int compile(UserOp &op, int dtype) {
-    if (op.module[dtype]) return SMHIP_OK;
-    hipModule_t mod;
-    if (int rc = hiprtc_build(kSource, {std::string("-DTYPE=") + kTypeName[dtype],
-                                        std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"),
-                                        "-DEXPR=" + op.expr},
-                              kTypeName[dtype], op.expr, &mod))
-        return rc;
-    SMHIP_TRY(hipModuleGetFunction(&op.contig[dtype], mod, "smhip_user_contig"));
-    SMHIP_TRY(hipModuleGetFunction(&op.scalar[dtype], mod, "smhip_user_scalar"));
-    op.module[dtype] = mod;
+// The kernel `name` of the program `key` on the calling thread's device.  The first caller of a key builds it with
+// g_jit_mutex RELEASED (a 0.3 s hipRTC compile does not stall other threads' launches of other kernels); callers
+// that arrive meanwhile for the same key wait for that build instead of repeating it.
+int get_function(const std::string &key, const std::function<int(std::vector<char> *)> &build, const char *name, hipFunction_t *fn) {
+    const int dev = current_device();
+    if (dev < 0 || dev >= kJitMaxDevices) return fail(SMHIP_ERR_INVALID, "jit: device %d", dev);
+    std::unique_lock<std::mutex> lock(g_jit_mutex);
+    Program *p;
+    auto it = g_programs.find(key);
+    if (it == g_programs.end()) {
+        p = new Program;
+        g_programs.emplace(key, p);
+        lock.unlock();
+        std::vector<char> code;
+        const int rc = build(&code);
+        lock.lock();
+        p->code.swap(code);
+        p->rc = rc;
+        if (rc) p->error = smhip_last_error();
+        p->state = rc ? 2 : 1;
+        g_jit_cv.notify_all();
+    } else {
+        p = it->second;
+        g_jit_cv.wait(lock, [&] { return p->state != 0; });
+    }
+    if (p->state == 2) return fail(p->rc, "%s", p->error.c_str());
+    auto f = p->functions.find({dev, name});
+    if (f != p->functions.end()) {
+        *fn = f->second;
+        return SMHIP_OK;
+    }
+    if (!p->module[dev]) SMHIP_TRY(hipModuleLoadData(&p->module[dev], p->code.data()));
+    SMHIP_TRY(hipModuleGetFunction(fn, p->module[dev], name));
+    p->functions[{dev, name}] = *fn;
     return SMHIP_OK;
 }
 
-int lookup(int op, int dtype, UserOp **out) {
+int user_expr(int op, std::string *expr) {
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     const int idx = op - SMHIP_OP_USER_BASE;
     if (idx < 0 || idx >= (int)g_ops.size()) return fail(SMHIP_ERR_INVALID, "op %d was never registered", op);
-    *out = g_ops[idx];
-    return compile(**out, dtype);
+    *expr = g_ops[idx]->expr;
+    return SMHIP_OK;
+}
+
+// The flat kernels (contig / scalar) of a user Op for one element type.
+int flat_function(int op, int dtype, const char *name, hipFunction_t *fn) {
+    std::string expr;
+    if (int rc = user_expr(op, &expr)) return rc;
+    return get_function(std::string("flat|") + kTypeName[dtype] + "|" + expr,
+                        [&](std::vector<char> *code) {
+                            return hiprtc_build(kSource, {std::string("-DTYPE=") + kTypeName[dtype],
+                                                          std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"),
+                                                          "-DEXPR=" + expr},
+                                                kTypeName[dtype], expr, code);
+                        },
+                        name, fn);
 }
 
 }  // namespace
@@ -320,8 +375,8 @@ int jit_register(const char *expr, int *op_id) {
 }
 
 int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s) {
-    UserOp *u;
-    if (int rc = lookup(op, dtype, &u)) return rc;
+    hipFunction_t fn;
+    if (int rc = flat_function(op, dtype, "smhip_user_contig", &fn)) return rc;
     const unsigned long long w = (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 2 : 4;
     int vec = 1;
     unsigned long long n_vec = n / w, nn = n;
@@ -329,13 +384,13 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
     const size_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
     void *args[] = {&a, &b, &out, &n_vec, &nn, &vec};
-    SMHIP_TRY(hipModuleLaunchKernel(u->contig[dtype], (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }
 
 int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s) {
-    UserOp *u;
-    if (int rc = lookup(op, dtype, &u)) return rc;
+    hipFunction_t fn;
+    if (int rc = flat_function(op, dtype, "smhip_user_scalar", &fn)) return rc;
     const unsigned long long w = (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 2 : 4;
     unsigned long long n_vec = n / w, nn = n;
     int swapped = 0;
@@ -344,7 +399,7 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
     unsigned char scalar[8];
     memcpy(scalar, value_host, dtype_size(dtype));
     void *args[] = {&a, scalar, &out, &n_vec, &nn, &swapped};
-    SMHIP_TRY(hipModuleLaunchKernel(u->scalar[dtype], (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }
 
@@ -373,63 +428,44 @@ int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void
             params = "GatherParams";
             break;
     }
+    std::string expr;
+    if (int rc = user_expr(op, &expr)) return rc;
     hipFunction_t fn = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_jit_mutex);
-        const int idx = op - SMHIP_OP_USER_BASE;
-        if (idx < 0 || idx >= (int)g_ops.size()) return fail(SMHIP_ERR_INVALID, "op %d was never registered", op);
-        UserOp &u = *g_ops[idx];
-        auto it = u.bcast[dtype].find(body);
-        if (it == u.bcast[dtype].end()) {
-            const std::string source = std::string(kBcastPrelude) + kBcastKernelsSrc + kBcastWrapper;
-            hipModule_t mod;
-            if (int rc = hiprtc_build(source, {std::string("-DTYPE=") + kStdTypeName[dtype], "-DEXPR=" + u.expr, std::string("-DPARAMS=") + params,
-                                               std::string("-DBODY=") + body},
-                                      kStdTypeName[dtype], u.expr, &mod))
-                return rc;
-            SMHIP_TRY(hipModuleGetFunction(&fn, mod, "smhip_user_bcast"));
-            u.bcast[dtype][body] = fn;  // the module stays loaded for the life of the process
-        } else {
-            fn = it->second;
-        }
-    }
+    if (int rc = get_function(std::string("bcast|") + kStdTypeName[dtype] + "|" + body + "|" + expr,
+                              [&](std::vector<char> *code) {
+                                  const std::string source = std::string(kBcastPrelude) + kBcastKernelsSrc + kBcastWrapper;
+                                  return hiprtc_build(source, {std::string("-DTYPE=") + kStdTypeName[dtype], "-DEXPR=" + expr,
+                                                               std::string("-DPARAMS=") + params, std::string("-DBODY=") + body},
+                                                      kStdTypeName[dtype], expr, code);
+                              },
+                              "smhip_user_bcast", &fn))
+        return rc;
     void *pblock = const_cast<void *>(static_cast<const void *>(&L.p));
     void *args[] = {&x, &y, &out, pblock};
     SMHIP_TRY(hipModuleLaunchKernel(fn, L.grid, 1, 1, 256, 1, 1, (unsigned)L.lds_bytes, s, args, nullptr));
     return SMHIP_OK;
 }
 
-namespace {
-struct ExprKernel { hipFunction_t fn = nullptr, fn_sum = nullptr; };
-std::map<std::string, ExprKernel> g_exprs;  // key: dtype | operand count | expression
-}  // namespace
-
 int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int n_operands, const void *scalars_host, int n_scalars,
                    void *out, size_t n, double *sum_dev, hipStream_t s) {
     hipFunction_t fn = nullptr;
     {
-        std::lock_guard<std::mutex> lock(g_jit_mutex);
-        char head[32];
-        snprintf(head, sizeof head, "%d|%d|", dtype, n_operands);
-        const std::string key = std::string(head) + expr;
-        auto it = g_exprs.find(key);
-        if (it == g_exprs.end()) {
-            char nops[24];
-            snprintf(nops, sizeof nops, "-DNOPS=%d", n_operands);
-            hipModule_t mod;
-            const bool integer = dtype == SMHIP_I32 || dtype == SMHIP_I64;
-            if (int rc = hiprtc_build(kExprSource, {std::string("-DTYPE=") + kTypeName[dtype],
-                                                    std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"), nops,
-                                                    std::string("-DEXPR=") + expr, integer ? "-DACC=unsigned long long" : "-DACC=double",
-                                                    integer ? "-DWIDEN=(A)(long long)x" : "-DWIDEN=(A)x"},
-                                      kTypeName[dtype], expr, &mod))
-                return rc;
-            ExprKernel k;
-            SMHIP_TRY(hipModuleGetFunction(&k.fn, mod, "smhip_user_expr"));
-            SMHIP_TRY(hipModuleGetFunction(&k.fn_sum, mod, "smhip_user_expr_sum"));
-            it = g_exprs.emplace(key, k).first;
-        }
-        fn = sum_dev ? it->second.fn_sum : it->second.fn;
+        char head[48];
+        snprintf(head, sizeof head, "expr|%d|%d|", dtype, n_operands);
+        const bool integer = dtype == SMHIP_I32 || dtype == SMHIP_I64;
+        if (int rc = get_function(std::string(head) + expr,
+                                  [&](std::vector<char> *code) {
+                                      char nops[24];
+                                      snprintf(nops, sizeof nops, "-DNOPS=%d", n_operands);
+                                      return hiprtc_build(kExprSource,
+                                                          {std::string("-DTYPE=") + kTypeName[dtype],
+                                                           std::string("-DWIDTH=") + ((dtype == SMHIP_F64 || dtype == SMHIP_I64) ? "2" : "4"), nops,
+                                                           std::string("-DEXPR=") + expr, integer ? "-DACC=unsigned long long" : "-DACC=double",
+                                                           integer ? "-DWIDEN=(A)(long long)x" : "-DWIDEN=(A)x"},
+                                                          kTypeName[dtype], expr, code);
+                                  },
+                                  sum_dev ? "smhip_user_expr_sum" : "smhip_user_expr", &fn))
+            return rc;
     }
     struct { const void *p[8]; } in;
     for (int k = 0; k < 8; ++k) in.p[k] = operands[k < n_operands ? k : 0];
@@ -446,7 +482,8 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     }
     // expression + sum: per-workgroup partials, then the built-in reductions' fixed-order fold and final pass
     double *scratch;
-    if (int rc = reduce_scratch(grid + grid / kReduceFoldSpan + 2, &scratch)) return rc;
+    ScratchLease lease;
+    if (int rc = lease.take(grid + grid / kReduceFoldSpan + 2, &scratch)) return rc;
     int store = out != nullptr;
     void *args[] = {&in, sc, &out, &store, &n_vec, &nn, &scratch};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));

@@ -274,7 +274,8 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);
     const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
     double *scratch;
-    if (int rc = reduce_scratch(blocks + folded, &scratch)) return rc;
+    ScratchLease lease;
+    if (int rc = lease.take(blocks + folded, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
     hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
                        static_cast<T *>(out_native));
@@ -318,7 +319,8 @@ int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStr
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "complex dot too large (%zu workgroups)", blocks);
     const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
     double *scratch;
-    if (int rc = reduce_scratch(2 * blocks + 2 * folded, &scratch)) return rc;
+    ScratchLease lease;
+    if (int rc = lease.take(2 * blocks + 2 * folded, &scratch)) return rc;
     hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, blocks);
     SMHIP_LAUNCH_CHECK("cdot");
     const double *re = scratch, *im = scratch + blocks;

@@ -9,8 +9,10 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -27,13 +29,11 @@ struct ThreadState {
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
     std::string error;
-    double *scratch[kMaxDevices] = {};
-    size_t scratch_count[kMaxDevices] = {};
     // pinned staging ring for small uploads (per thread and device): copy in, enqueue, return
     unsigned char *ring[kMaxDevices] = {};
     size_t ring_head[kMaxDevices] = {};
     hipStream_t ring_stream[kMaxDevices] = {};
-    ~ThreadState();  // a thread that ends hands its scratch back to the pool and its ring to the next thread
+    ~ThreadState();  // a thread that ends hands its pinned ring to the next thread
 };
 thread_local ThreadState tls;
 
@@ -60,23 +60,56 @@ int g_device_count = -1;
 // (2) placement.  The 2R+1W stream's rate follows the RELATIVE physical placement of its three buffers:
 // three separate hipMallocs land anywhere between 6.27 and 6.66 TB/s from one process to the next, three
 // carvings of one slab are at 6.49-6.51 TB/s every time (profiles/r01_placement_notes.txt).
-// Stream-ordered reuse: every free extent remembers the stream its last owner worked on; handing it to a
-// different stream waits for that stream first.
+// Stream-ordered reuse.  A block remembers the stream it was handed to; when it is freed, the streams that may still
+// be working on its bytes are that one and the freeing thread's current one (smhip_set_stream orders a thread's new
+// stream after its old one, so a switch between use and free is covered as well).  The device's library stream is
+// remembered as a flag and ordered lazily -- an event recorded on it when the bytes are reused covers everything queued
+// before the free; a caller-owned stream may be destroyed by then, so an event is recorded on it at free time.  The
+// next owner's stream WAITS on those events (hipStreamWaitEvent: nothing blocks on the host); bytes that come back on the
+// stream that freed them need no wait at all.  A stream that cannot be recorded on makes the reuse synchronise the device.
 constexpr size_t kLargeMin = (size_t)1 << 20, kLargeAlign = (size_t)2 << 20;
 constexpr size_t kArenaFloor = (size_t)256 << 20, kArenaSolo = (size_t)4 << 30;
-hipStream_t const kMixedStreams = reinterpret_cast<hipStream_t>(~(uintptr_t)0);  // extent merged from owners on different streams
 
-struct Extent { size_t off, size; hipStream_t stream; };
+// An event recorded on a caller-owned stream when bytes it may be using were freed.  Shared by the extents the bytes end
+// up in (splits copy it, merges keep the later one per stream); it returns to the event pool with its last holder.
+struct Recorded {
+    int device;
+    hipEvent_t ev;
+    ~Recorded();
+};
+struct Pending { hipStream_t stream; uint64_t seq; std::shared_ptr<Recorded> rec; };
+struct Tag {
+    bool lib = false;      // the library stream of the device may still be using the bytes
+    bool unknown = false;  // so may a stream no event could be recorded on
+    std::vector<Pending> pending;  // at most one per caller-owned stream: a later record on a stream covers the earlier ones
+    void add(const Pending &p) {
+        for (Pending &q : pending)
+            if (q.stream == p.stream) {
+                if (q.seq < p.seq) q = p;
+                return;
+            }
+        pending.push_back(p);
+    }
+    void merge(const Tag &o) {
+        lib |= o.lib;
+        unknown |= o.unknown;
+        for (const Pending &p : o.pending) add(p);
+    }
+};
+struct Extent { size_t off, size; Tag tag; };
 struct Arena {
     char *base = nullptr;
     size_t size = 0, used = 0;
     int device = 0;
     std::vector<Extent> free;  // sorted by offset, coalesced
 };
-struct Block { size_t cls; int device; Arena *arena; size_t off; };
-std::unordered_map<void *, Block> g_live;                                              // handed out
-std::map<std::pair<int, size_t>, std::vector<std::pair<void *, hipStream_t>>> g_free;  // small blocks, cached
+struct Block { size_t cls; int device; Arena *arena; size_t off; hipStream_t stream; std::thread::id owner; };
+std::unordered_map<void *, Block> g_live;                                      // handed out
+std::map<std::pair<int, size_t>, std::vector<std::pair<void *, Tag>>> g_free;  // small blocks, cached
 std::vector<Arena *> g_arenas;
+std::mutex g_event_mutex;
+std::vector<hipEvent_t> g_event_pool[kMaxDevices];  // timing-disabled events, recycled
+uint64_t g_record_seq = 0;
 size_t g_bytes_live = 0, g_bytes_cached = 0;
 
 size_t size_class(size_t bytes) {
@@ -88,7 +121,7 @@ size_t size_class(size_t bytes) {
 }
 
 // First fit in this device's arenas.  Caller holds g_mutex.
-bool carve(int dev, size_t need, Arena **arena, size_t *off, hipStream_t *last) {
+bool carve(int dev, size_t need, Arena **arena, size_t *off, Tag *tag) {
     for (Arena *a : g_arenas) {
         if (a->device != dev) continue;
         for (size_t i = 0; i < a->free.size(); ++i) {
@@ -96,7 +129,7 @@ bool carve(int dev, size_t need, Arena **arena, size_t *off, hipStream_t *last) 
             if (e.size < need) continue;
             *arena = a;
             *off = e.off;
-            *last = e.stream;
+            *tag = e.tag;  // a split leaves both parts with the same obligations
             if (e.size == need) a->free.erase(a->free.begin() + i);
             else { e.off += need; e.size -= need; }
             a->used += need;
@@ -107,22 +140,90 @@ bool carve(int dev, size_t need, Arena **arena, size_t *off, hipStream_t *last) 
 }
 
 // Return [off, off + size) to its arena, merging with neighbours.  Caller holds g_mutex.
-void release(Arena *a, size_t off, size_t size, hipStream_t stream) {
+void release(Arena *a, size_t off, size_t size, Tag &&tag) {
     size_t i = 0;
     while (i < a->free.size() && a->free[i].off < off) ++i;
-    a->free.insert(a->free.begin() + i, Extent{off, size, stream});
+    a->free.insert(a->free.begin() + i, Extent{off, size, std::move(tag)});
     auto merge = [&](size_t lo) {  // merge free[lo] and free[lo + 1] if adjacent
         if (lo + 1 >= a->free.size()) return false;
         Extent &x = a->free[lo], &y = a->free[lo + 1];
         if (x.off + x.size != y.off) return false;
         x.size += y.size;
-        if (x.stream != y.stream) x.stream = kMixedStreams;
+        x.tag.merge(y.tag);
         a->free.erase(a->free.begin() + lo + 1);
         return true;
     };
     merge(i);
     if (i > 0) merge(i - 1);
     a->used -= size;
+}
+
+// A recycled (or new) timing-disabled event of device `dev`; nullptr if none can be made.
+hipEvent_t take_event(int dev) {
+    {
+        std::lock_guard<std::mutex> lock(g_event_mutex);
+        if (!g_event_pool[dev].empty()) {
+            hipEvent_t e = g_event_pool[dev].back();
+            g_event_pool[dev].pop_back();
+            return e;
+        }
+    }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+    return e;
+}
+void give_event(int dev, hipEvent_t e) {
+    std::lock_guard<std::mutex> lock(g_event_mutex);
+    g_event_pool[dev].push_back(e);
+}
+Recorded::~Recorded() { give_event(device, ev); }
+
+// Marks `tag` with "stream `t` of device `dev` may still be working on these bytes".  `t` must be alive: the library's
+// stream, or the calling thread's CURRENT stream (smhip_set_stream's contract) -- a stream handle that may have been
+// destroyed is never passed to HIP.
+void tag_stream(Tag &tag, int dev, hipStream_t t) {
+    if (t == g_streams[dev]) { tag.lib = true; return; }
+    hipEvent_t e = take_event(dev);
+    if (e && hipEventRecord(e, t) == hipSuccess) {
+        uint64_t seq;
+        {
+            std::lock_guard<std::mutex> lock(g_event_mutex);
+            seq = ++g_record_seq;
+        }
+        tag.add(Pending{t, seq, std::shared_ptr<Recorded>(new Recorded{dev, e})});
+        return;
+    }
+    (void)hipGetLastError();
+    if (e) give_event(dev, e);
+    tag.unknown = true;
+}
+
+// Orders stream `s` (device `dev`) after everything `tag` names.
+int order_after(Tag &tag, int dev, hipStream_t s) {
+    hipError_t err = hipSuccess;
+    if (tag.unknown) {
+        err = hipDeviceSynchronize();
+    } else {
+        for (const Pending &p : tag.pending)
+            if (err == hipSuccess && p.stream != s) err = hipStreamWaitEvent(s, p.rec->ev, 0);
+        if (err == hipSuccess && tag.lib && s != g_streams[dev] && g_streams[dev]) {
+            hipEvent_t e = take_event(dev);
+            if (!e) {
+                err = hipStreamSynchronize(g_streams[dev]);
+            } else {
+                err = hipEventRecord(e, g_streams[dev]);
+                if (err == hipSuccess) err = hipStreamWaitEvent(s, e, 0);
+                give_event(dev, e);
+            }
+        }
+    }
+    tag.pending.clear();
+    if (err != hipSuccess) return fail(SMHIP_ERR_HIP, "pool: ordering a reused block: %s", hipGetErrorString(err));
+    return SMHIP_OK;
 }
 
 }  // namespace
@@ -178,26 +279,20 @@ int compute_units() {
     return g_cus[d] > 0 ? g_cus[d] : 256;
 }
 
-int reduce_scratch(size_t count, double **ptr) {
-    const int d = tls.device;
-    if (tls.scratch_count[d] < count) {
-        size_t want = count < 4096 ? 4096 : count * 2;
-        void *p = nullptr;
-        if (int rc = smhip_alloc(&p, want * sizeof(double))) return rc;
-        if (tls.scratch[d]) smhip_free(tls.scratch[d]);
-        tls.scratch[d] = static_cast<double *>(p);
-        tls.scratch_count[d] = want;
-    }
-    *ptr = tls.scratch[d];
-    return SMHIP_OK;
+int current_device() { return tls.device < 0 ? 0 : tls.device; }
+
+ThreadDeviceScope::ThreadDeviceScope(int device) : prev_device_(tls.device), prev_use_user_(tls.use_user_stream) {
+    tls.device = device;
+    tls.use_user_stream = false;
+}
+ThreadDeviceScope::~ThreadDeviceScope() {
+    tls.device = prev_device_;
+    tls.use_user_stream = prev_use_user_;
+    if (prev_device_ >= 0) (void)hipSetDevice(prev_device_);
 }
 
 ThreadState::~ThreadState() {
     for (int d = 0; d < kMaxDevices; ++d) {
-        if (scratch[d]) {
-            smhip_free(scratch[d]);  // pool bookkeeping only, no HIP call
-            scratch[d] = nullptr;
-        }
         if (ring[d]) {
             std::lock_guard<std::mutex> lock(g_ring_mutex);
             g_spare_rings[d].push_back({ring[d], ring_stream[d]});
@@ -250,8 +345,23 @@ int smhip_get_device(int *device) {
 }
 
 int smhip_set_stream(void *hip_stream) {
-    tls.user_stream = static_cast<hipStream_t>(hip_stream);
-    tls.use_user_stream = hip_stream != nullptr;
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (tls.device >= 0) {
+        // Order the new stream after the old one, so that buffers this thread used on the old stream and frees (or
+        // reuses) under the new one stay stream-ordered (the pool tags a freed block with the CURRENT stream).
+        hipStream_t prev = tls.use_user_stream ? tls.user_stream : g_streams[tls.device];
+        hipStream_t now = next ? next : g_streams[tls.device];
+        if (prev && now && prev != now) {
+            hipEvent_t e = take_event(tls.device);
+            if (e) {
+                if (hipEventRecord(e, prev) == hipSuccess) (void)hipStreamWaitEvent(now, e, 0);
+                (void)hipGetLastError();  // a previous stream that is already gone has nothing left to order
+                give_event(tls.device, e);
+            }
+        }
+    }
+    tls.user_stream = next;
+    tls.use_user_stream = next != nullptr;
     return SMHIP_OK;
 }
 
@@ -276,14 +386,14 @@ int smhip_alloc(void **dptr, size_t bytes) {
     const size_t cls = size_class(bytes);
     const int dev = tls.device;
     void *p = nullptr;
-    hipStream_t last = s;
+    Tag tag;
     Arena *arena = nullptr;
     size_t off = 0;
     if (cls >= kLargeMin) {
         bool found;
         {
             std::lock_guard<std::mutex> lock(g_mutex);
-            found = carve(dev, cls, &arena, &off, &last);
+            found = carve(dev, cls, &arena, &off, &tag);
         }
         if (!found) {
             // a new slab: room for the request and the operands that usually come with it
@@ -306,10 +416,10 @@ int smhip_alloc(void **dptr, size_t bytes) {
             a->base = static_cast<char *>(base);
             a->size = want;
             a->device = dev;
-            a->free.push_back(Extent{0, want, s});
+            a->free.push_back(Extent{0, want, Tag{}});
             g_arenas.push_back(a);
             g_bytes_cached += want;
-            found = carve(dev, cls, &arena, &off, &last);
+            found = carve(dev, cls, &arena, &off, &tag);
             if (!found) return fail(SMHIP_ERR_HIP, "pool: fresh arena could not satisfy %zu bytes", cls);
         }
         p = arena->base + off;
@@ -319,7 +429,7 @@ int smhip_alloc(void **dptr, size_t bytes) {
             auto it = g_free.find({dev, cls});
             if (it != g_free.end() && !it->second.empty()) {
                 p = it->second.back().first;
-                last = it->second.back().second;
+                tag = std::move(it->second.back().second);
                 it->second.pop_back();
             }
         }
@@ -335,11 +445,17 @@ int smhip_alloc(void **dptr, size_t bytes) {
             g_bytes_cached += cls;
         }
     }
-    // stream-ordered reuse: work queued by the previous owner on another stream must drain first
-    if (last == kMixedStreams) SMHIP_TRY(hipDeviceSynchronize());
-    else if (last != s) SMHIP_TRY(hipStreamSynchronize(last));
+    // stream-ordered reuse: work queued by the previous owner on another stream is ordered before ours
+    if (int rc = order_after(tag, dev, s)) {
+        std::lock_guard<std::mutex> lock(g_mutex);  // hand the bytes back rather than leak them
+        Tag lost;
+        lost.unknown = true;
+        if (arena) release(arena, off, cls, std::move(lost));
+        else g_free[{dev, cls}].push_back({p, std::move(lost)});
+        return rc;
+    }
     std::lock_guard<std::mutex> lock(g_mutex);
-    g_live[p] = Block{cls, dev, arena, off};
+    g_live[p] = Block{cls, dev, arena, off, s, std::this_thread::get_id()};
     g_bytes_live += cls;
     g_bytes_cached -= cls;
     *dptr = p;
@@ -348,17 +464,34 @@ int smhip_alloc(void **dptr, size_t bytes) {
 
 int smhip_free(void *dptr) {
     if (!dptr) return SMHIP_OK;
+    Block b;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto it = g_live.find(dptr);
+        if (it == g_live.end()) return fail(SMHIP_ERR_INVALID, "free: %p was not allocated by smhip_alloc", dptr);
+        b = it->second;
+        g_live.erase(it);
+        g_bytes_live -= b.cls;
+        g_bytes_cached += b.cls;
+    }
+    // Who may still be working on it: the stream it was handed to, and the stream this thread's work goes to now.
+    //   handed to the library stream                      -> flag, ordered lazily at reuse;
+    //   handed to the stream this thread is on            -> an event recorded on it now;
+    //   handed to another stream BY THIS THREAD           -> covered: smhip_set_stream ordered every later stream of this
+    //                                                        thread after it, and the current one is tagged below;
+    //   handed to another thread's own stream             -> that stream may be gone by now and cannot be asked: the
+    //                                                        next owner synchronises the device (rare, always safe).
+    Tag tag;
+    const int here = tls.device < 0 ? 0 : tls.device;
+    hipStream_t cur = nullptr;
+    if (here == b.device) cur = tls.use_user_stream ? tls.user_stream : g_streams[b.device];
+    if (b.stream == g_streams[b.device]) tag.lib = true;
+    else if (b.stream == cur) tag_stream(tag, b.device, cur);
+    else if (b.owner != std::this_thread::get_id()) tag.unknown = true;
+    if (cur && cur != b.stream) tag_stream(tag, b.device, cur);
     std::lock_guard<std::mutex> lock(g_mutex);
-    auto it = g_live.find(dptr);
-    if (it == g_live.end()) return fail(SMHIP_ERR_INVALID, "free: %p was not allocated by smhip_alloc", dptr);
-    const Block b = it->second;
-    g_live.erase(it);
-    g_bytes_live -= b.cls;
-    g_bytes_cached += b.cls;
-    // the stream this thread's work (and so the block's last use) went to
-    hipStream_t s = tls.use_user_stream ? tls.user_stream : g_streams[b.device];
-    if (b.arena) release(b.arena, b.off, b.cls, s);
-    else g_free[{b.device, b.cls}].push_back({dptr, s});
+    if (b.arena) release(b.arena, b.off, b.cls, std::move(tag));
+    else g_free[{b.device, b.cls}].push_back({dptr, std::move(tag)});
     return SMHIP_OK;
 }
 

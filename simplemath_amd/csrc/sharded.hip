@@ -1,0 +1,374 @@
+// sharded.hip -- the hot path over the GPUs of one node.
+//
+// The reference's only fan-out is `#pragma omp parallel for` over 1024-element chunks of the output
+// (include/math/calculate.h:47) and over SIMD iterations of array_scalar_op (:152): shared memory, one socket.  On a
+// node of 8 MI355X the same independence is used one level up: the RESULT's outermost dimension is cut into one
+// block per GPU, every GPU runs the single-device kernels on its block (operands broadcast along that dimension are
+// replicated), and nothing crosses xGMI on the data path.  Only a whole-array reduction has an exchange step: each
+// GPU's fp64 partial meets the others in ONE ncclAllReduce of one value -- latency-bound, so neither the 7 x 153 GB/s
+// links nor ring-vs-tree matter for it.
+//
+// Two launch models, same kernels:
+//   smhip_set_devices(n)        one process, one host thread walking the devices (ncclCommInitAll, one stream per
+//                               device, the all-reduce inside ncclGroupStart/End);
+//   smhip_comm_init_rank(...)   one process per GPU (ncclCommInitRank), the all-reduce on the rank's own stream.
+// RCCL is dlopen'ed on first use: a single-GPU program never loads it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "internal.h"
+
+namespace smhip {
+namespace {
+
+constexpr int kMaxGroup = 64;
+
+struct Rccl {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+std::mutex g_mutex;  // guards everything below
+Rccl g_rccl;
+bool g_rccl_loaded = false;
+
+int g_ndev = 0;                        // devices 0..g_ndev-1 form the single-process group (0: none)
+ncclComm_t g_comms[kMaxGroup] = {};    // from ncclCommInitAll, by device
+void *g_slot[kMaxGroup] = {};          // 16 bytes of pooled device memory per device: the partial / the total
+
+ncclComm_t g_rank_comm = nullptr;      // one-process-per-GPU communicator
+int g_nranks = 0, g_rank = -1, g_rank_device = -1;
+
+int load_rccl() {  // caller holds g_mutex
+    if (g_rccl_loaded) return SMHIP_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(SMHIP_ERR_UNSUPPORTED, "multi-GPU needs RCCL and librccl.so.1 cannot be loaded: %s", dlerror());
+#define SMHIP_SYM(field, name)                                                                         \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                            \
+    if (!g_rccl.field) return fail(SMHIP_ERR_UNSUPPORTED, "librccl has no symbol %s", name)
+    SMHIP_SYM(GetUniqueId, "ncclGetUniqueId");
+    SMHIP_SYM(CommInitRank, "ncclCommInitRank");
+    SMHIP_SYM(CommInitAll, "ncclCommInitAll");
+    SMHIP_SYM(CommDestroy, "ncclCommDestroy");
+    SMHIP_SYM(AllReduce, "ncclAllReduce");
+    SMHIP_SYM(GroupStart, "ncclGroupStart");
+    SMHIP_SYM(GroupEnd, "ncclGroupEnd");
+    SMHIP_SYM(GetErrorString, "ncclGetErrorString");
+#undef SMHIP_SYM
+    g_rccl_loaded = true;
+    return SMHIP_OK;
+}
+
+#define SMHIP_NCCL(expr)                                                                                       \
+    do {                                                                                                       \
+        ncclResult_t nccl_r_ = (expr);                                                                         \
+        if (nccl_r_ != ncclSuccess) return fail(SMHIP_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(nccl_r_)); \
+    } while (0)
+
+int dissolve_group() {  // caller holds g_mutex
+    for (int g = 0; g < g_ndev; ++g) {
+        ThreadDeviceScope scope(g);
+        hipStream_t s;
+        if (acquire(&s) == SMHIP_OK) (void)hipStreamSynchronize(s);
+        if (g_comms[g]) (void)g_rccl.CommDestroy(g_comms[g]);
+        g_comms[g] = nullptr;
+        if (g_slot[g]) smhip_free(g_slot[g]);
+        g_slot[g] = nullptr;
+    }
+    g_ndev = 0;
+    return SMHIP_OK;
+}
+
+int group_size(const char *who, int *n) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_ndev <= 0) return fail(SMHIP_ERR_INVALID, "%s: no device group (call smhip_set_devices(n) first)", who);
+    *n = g_ndev;
+    return SMHIP_OK;
+}
+
+ncclDataType_t wire_type(int dtype) {  // integers travel unsigned: sums wrap modulo 2^32 / 2^64, like the reference's lanes
+    switch (dtype) {
+        case SMHIP_F32: return ncclFloat32;
+        case SMHIP_F64: return ncclFloat64;
+        case SMHIP_I32: return ncclUint32;
+        default: return ncclUint64;
+    }
+}
+
+// One all-reduce of `count` values per device of the group, in place in slot[g], each on its device's stream.
+int group_allreduce(int n, ncclDataType_t type, size_t count) {
+    hipStream_t streams[kMaxGroup];
+    for (int g = 0; g < n; ++g) {
+        ThreadDeviceScope scope(g);
+        if (int rc = acquire(&streams[g])) return rc;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    SMHIP_NCCL(g_rccl.GroupStart());
+    for (int g = 0; g < n; ++g) {
+        const ncclResult_t r = g_rccl.AllReduce(g_slot[g], g_slot[g], count, type, ncclSum, g_comms[g], streams[g]);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail(SMHIP_ERR_HIP, "ncclAllReduce on device %d: %s", g, g_rccl.GetErrorString(r));
+        }
+    }
+    SMHIP_NCCL(g_rccl.GroupEnd());
+    return SMHIP_OK;
+}
+
+// Device 0's slot to host memory (waits for device 0's stream only).
+int read_slot0(void *dst_host, size_t bytes) {
+    ThreadDeviceScope scope(0);
+    return smhip_download(dst_host, g_slot[0], bytes);
+}
+
+bool tables_ok(int n, const void *const *a, const void *const *b, const void *const *out, const size_t *count) {
+    if (!count) return false;
+    for (int g = 0; g < n; ++g)
+        if (count[g] && ((a && !a[g]) || (b && !b[g]) || (out && !out[g]))) return false;
+    return true;
+}
+
+}  // namespace
+}  // namespace smhip
+
+using namespace smhip;
+
+extern "C" {
+
+int smhip_split_range(int64_t n, int world, int rank, int64_t *start, int64_t *count) {
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || !start || !count) return fail(SMHIP_ERR_INVALID, "split_range: bad arguments");
+    const int64_t base = n / world, extra = n % world;
+    *start = rank * base + (rank < extra ? rank : extra);
+    *count = base + (rank < extra ? 1 : 0);
+    return SMHIP_OK;
+}
+
+int smhip_shard_outer(const int64_t *shape, const int64_t *stride_a, const int64_t *stride_b, int ndim, int world, int rank,
+                      int64_t *shard_shape, int64_t *offset_a, int64_t *offset_b, int64_t *offset_out, int *replicated_mask) {
+    if (!shape || !stride_a || !stride_b || ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "shard_outer: bad arguments");
+    int64_t start, count;
+    if (int rc = smhip_split_range(shape[0], world, rank, &start, &count)) return rc;
+    int64_t inner = 1;
+    for (int i = 1; i < ndim; ++i) inner *= shape[i];
+    if (shard_shape) {
+        shard_shape[0] = count;
+        for (int i = 1; i < ndim; ++i) shard_shape[i] = shape[i];
+    }
+    if (offset_a) *offset_a = start * stride_a[0];
+    if (offset_b) *offset_b = start * stride_b[0];
+    if (offset_out) *offset_out = start * inner;
+    if (replicated_mask) *replicated_mask = ((stride_a[0] == 0 && shape[0] > 1) ? 1 : 0) | ((stride_b[0] == 0 && shape[0] > 1) ? 2 : 0);
+    return SMHIP_OK;
+}
+
+int smhip_set_devices(int n) {
+    if (n < 0 || n > kMaxGroup) return fail(SMHIP_ERR_INVALID, "set_devices: %d", n);
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_ndev > 0) dissolve_group();
+    if (n == 0) return SMHIP_OK;
+    int have = 0;
+    smhip_device_count(&have);
+    if (have < 1) return fail(SMHIP_ERR_NO_DEVICE, "set_devices: no HIP device available; libsmhip has no CPU fallback");
+    if (n > have) return fail(SMHIP_ERR_INVALID, "set_devices: %d devices asked for, %d present", n, have);
+    if (int rc = load_rccl()) return rc;
+    int devlist[kMaxGroup];
+    for (int g = 0; g < n; ++g) {
+        devlist[g] = g;
+        ThreadDeviceScope scope(g);
+        hipStream_t s;
+        if (int rc = acquire(&s)) return rc;  // checks the architecture and creates the device's stream
+        if (int rc = smhip_alloc(&g_slot[g], 16)) return rc;
+    }
+    {
+        // ncclCommInitAll leaves the last device current; put this thread back afterwards
+        ThreadDeviceScope scope(current_device());
+        SMHIP_NCCL(g_rccl.CommInitAll(g_comms, n, devlist));
+    }
+    g_ndev = n;
+    return SMHIP_OK;
+}
+
+int smhip_get_devices(int *n) {
+    if (!n) return fail(SMHIP_ERR_INVALID, "get_devices: null");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    *n = g_ndev;
+    return SMHIP_OK;
+}
+
+int smhip_sharded_synchronize(void) {
+    int n;
+    if (int rc = group_size("sharded_synchronize", &n)) return rc;
+    for (int g = 0; g < n; ++g) {
+        ThreadDeviceScope scope(g);
+        hipStream_t s;
+        if (int rc = acquire(&s)) return rc;
+        SMHIP_TRY(hipStreamSynchronize(s));
+    }
+    return SMHIP_OK;
+}
+
+int smhip_sharded_contiguous(int op, int dtype, const void *const *a, const void *const *b, void *const *out, const size_t *n) {
+    int nd;
+    if (int rc = group_size("sharded_contiguous", &nd)) return rc;
+    if (!a || !b || !out || !tables_ok(nd, a, b, out, n)) return fail(SMHIP_ERR_INVALID, "sharded_contiguous: null table or entry");
+    for (int g = 0; g < nd; ++g) {
+        ThreadDeviceScope scope(g);
+        if (int rc = smhip_contiguous(op, dtype, a[g], b[g], out[g], n[g])) return rc;
+    }
+    return SMHIP_OK;
+}
+
+int smhip_sharded_array_scalar(int op, int dtype, const void *const *a, const void *value_host, const size_t *n, void *const *out) {
+    int nd;
+    if (int rc = group_size("sharded_array_scalar", &nd)) return rc;
+    if (!a || !out || !value_host || !tables_ok(nd, a, nullptr, out, n)) return fail(SMHIP_ERR_INVALID, "sharded_array_scalar: null table or entry");
+    for (int g = 0; g < nd; ++g) {
+        ThreadDeviceScope scope(g);
+        if (int rc = smhip_array_scalar(op, dtype, a[g], value_host, n[g], out[g])) return rc;
+    }
+    return SMHIP_OK;
+}
+
+int smhip_sharded_elementwise(int op, int dtype, const void *const *a, const int64_t *stride_a, const void *const *b,
+                              const int64_t *stride_b, const int64_t *shape, int ndim, void *const *out) {
+    int nd;
+    if (int rc = group_size("sharded_elementwise", &nd)) return rc;
+    if (!a || !b || !out || !stride_a || !stride_b || !shape) return fail(SMHIP_ERR_INVALID, "sharded_elementwise: null table");
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "sharded_elementwise: ndim %d outside 1..%d", ndim, SMHIP_MAX_NDIM);
+    for (int g = 0; g < nd; ++g) {
+        int64_t local[SMHIP_MAX_NDIM];
+        if (int rc = smhip_shard_outer(shape, stride_a, stride_b, ndim, nd, g, local, nullptr, nullptr, nullptr, nullptr)) return rc;
+        if (local[0] == 0) continue;  // more devices than rows
+        ThreadDeviceScope scope(g);
+        if (int rc = smhip_elementwise(op, dtype, a[g], stride_a, b[g], stride_b, local, ndim, out[g])) return rc;
+    }
+    return SMHIP_OK;
+}
+
+int smhip_sharded_contiguous_sum(int op, int dtype, const void *const *a, const void *const *b, void *const *out, const size_t *n,
+                                 double *sum_host) {
+    int nd;
+    if (int rc = group_size("sharded_contiguous_sum", &nd)) return rc;
+    if (!a || !b || !out || !sum_host || !tables_ok(nd, a, b, out, n)) return fail(SMHIP_ERR_INVALID, "sharded_contiguous_sum: null table or entry");
+    for (int g = 0; g < nd; ++g) {
+        ThreadDeviceScope scope(g);
+        if (int rc = smhip_contiguous_sum_async(op, dtype, a[g], b[g], out[g], n[g], static_cast<double *>(g_slot[g]))) return rc;
+    }
+    if (int rc = group_allreduce(nd, ncclFloat64, 1)) return rc;
+    return read_slot0(sum_host, sizeof(double));
+}
+
+int smhip_sharded_sum(int dtype, const void *const *a, const size_t *n, double *sum_host) {
+    int nd;
+    if (int rc = group_size("sharded_sum", &nd)) return rc;
+    if (!a || !sum_host || !tables_ok(nd, a, nullptr, nullptr, n)) return fail(SMHIP_ERR_INVALID, "sharded_sum: null table or entry");
+    for (int g = 0; g < nd; ++g) {
+        ThreadDeviceScope scope(g);
+        if (int rc = smhip_sum_async(dtype, a[g], n[g], static_cast<double *>(g_slot[g]))) return rc;
+    }
+    if (int rc = group_allreduce(nd, ncclFloat64, 1)) return rc;
+    return read_slot0(sum_host, sizeof(double));
+}
+
+int smhip_sharded_dot(int dtype, const void *const *a, const void *const *b, const size_t *n, void *out_host) {
+    int nd;
+    if (int rc = group_size("sharded_dot", &nd)) return rc;
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "sharded_dot: bad dtype %d", dtype);
+    if (!a || !b || !out_host || !tables_ok(nd, a, b, nullptr, n)) return fail(SMHIP_ERR_INVALID, "sharded_dot: null table or entry");
+    for (int g = 0; g < nd; ++g) {
+        ThreadDeviceScope scope(g);
+        // 8 bytes per device: the fp64 partial (floats) or the wrapped partial sign-extended to int64 (integers)
+        if (int rc = smhip_dot_async(dtype, a[g], b[g], n[g], static_cast<double *>(g_slot[g]))) return rc;
+    }
+    const bool integer = dtype == SMHIP_I32 || dtype == SMHIP_I64;
+    if (int rc = group_allreduce(nd, integer ? ncclUint64 : ncclFloat64, 1)) return rc;
+    unsigned char raw[8];
+    if (int rc = read_slot0(raw, 8)) return rc;
+    switch (dtype) {
+        case SMHIP_F32: { double d; memcpy(&d, raw, 8); const float f = (float)d; memcpy(out_host, &f, 4); break; }
+        case SMHIP_F64: memcpy(out_host, raw, 8); break;
+        case SMHIP_I32: memcpy(out_host, raw, 4); break;  // low 32 bits (little endian): the sum modulo 2^32
+        default: memcpy(out_host, raw, 8); break;
+    }
+    return SMHIP_OK;
+}
+
+/* -------------------------------------------------- one process per GPU */
+
+int smhip_comm_unique_id(void *id128) {
+    if (!id128) return fail(SMHIP_ERR_INVALID, "comm_unique_id: null");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (int rc = load_rccl()) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "smhip.h promises 128 bytes");
+    ncclUniqueId id;
+    SMHIP_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return SMHIP_OK;
+}
+
+int smhip_comm_init_rank(int nranks, int rank, const void *id128) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id128) return fail(SMHIP_ERR_INVALID, "comm_init_rank: bad arguments");
+    hipStream_t s;
+    if (int rc = acquire(&s)) return rc;  // selects this thread's device (hipSetDevice) for the communicator
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (int rc = load_rccl()) return rc;
+    if (g_rank_comm) {
+        (void)g_rccl.CommDestroy(g_rank_comm);
+        g_rank_comm = nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    SMHIP_NCCL(g_rccl.CommInitRank(&g_rank_comm, nranks, id, rank));
+    g_nranks = nranks;
+    g_rank = rank;
+    g_rank_device = current_device();
+    return SMHIP_OK;
+}
+
+int smhip_comm_info(int *nranks, int *rank) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (nranks) *nranks = g_rank_comm ? g_nranks : 0;
+    if (rank) *rank = g_rank_comm ? g_rank : -1;
+    return SMHIP_OK;
+}
+
+int smhip_comm_destroy(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_rank_comm) {
+        (void)g_rccl.CommDestroy(g_rank_comm);
+        g_rank_comm = nullptr;
+        g_nranks = 0;
+        g_rank = -1;
+    }
+    return SMHIP_OK;
+}
+
+int smhip_allreduce_sum_async(int dtype, void *inout_dev, size_t count) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "allreduce: bad dtype %d", dtype);
+    if (count == 0) return SMHIP_OK;
+    if (!inout_dev) return fail(SMHIP_ERR_INVALID, "allreduce: null buffer");
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!g_rank_comm) return fail(SMHIP_ERR_INVALID, "allreduce: no communicator (call smhip_comm_init_rank first)");
+    }
+    hipStream_t s;
+    if (int rc = acquire(&s)) return rc;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_rank_comm) return fail(SMHIP_ERR_INVALID, "allreduce: no communicator (call smhip_comm_init_rank first)");
+    if (current_device() != g_rank_device)
+        return fail(SMHIP_ERR_INVALID, "allreduce: the communicator lives on device %d, this thread is on device %d", g_rank_device, current_device());
+    SMHIP_NCCL(g_rccl.AllReduce(inout_dev, inout_dev, count, wire_type(dtype), ncclSum, g_rank_comm, s));
+    return SMHIP_OK;
+}
+
+}  // extern "C"

@@ -21,12 +21,32 @@ def _bench():
 
 def test_cpu_baseline_object(oracle):
     b = _bench()
-    r = b.cpu_baseline(20)  # 2^20-element sample keeps this test to a second or two
+    r = b.cpu_baseline("add", 20)  # 2^20-element sample keeps this test to a second or two
     assert r["kind"] in ("reference", "port") and r["cores"] == 1 and r["unit"] == "Gelem/s"
-    assert r["value"] > 0 and r["port_1core_prealloc"] > 0 and r["port_allcores_prealloc"] > 0
+    assert r["value"] > 0 and r["port_1core_prealloc"] > 0
+    be = r["best_effort"]  # all usable cores (cgroup quota / affinity / SMT accounted for), output preallocated
+    assert be["value"] > 0 and 1 <= be["cores"] == r["usable_cores"] <= (os.cpu_count() or 1)
     assert "2^20" in r["sample"]
     c1 = r["config1_million_check"]  # BASELINE config 1: the reference's own CPU-runnable case
     assert c1["n"] == 1_000_000 and c1["port_1core_ns"] > 0
+
+
+def test_cpu_baseline_for_the_other_configs(oracle):
+    """BASELINE.md section 3's CPU legs beside configs 3-5: all-thread element_wise_op, all-thread std::pow, add + fp64 sum."""
+    b = _bench()
+    r = b.cpu_baseline("pow", 16)
+    assert r["value"] > 0 and r["one_core"] > 0 and r["cores"] == r["usable_cores"] and "std::pow" in r["note"]
+    r = b.cpu_baseline("add_sum", 18)
+    assert r["value"] > 0 and r["best_effort"]["value"] > 0 and "seeds 6/7" in r["sample"]
+    assert b.cpu_baseline("transpose_add", 16) is None
+
+
+def test_usable_cores_accounts_for_quota(monkeypatch):
+    b = _bench()
+    n, info = b.usable_cores()
+    assert 1 <= n <= info["logical_cpus"] and info["smt"] >= 1
+    monkeypatch.setenv("SMHIP_BENCH_CPU_THREADS", "3")
+    assert b.usable_cores()[0] == 3
 
 
 def test_metric_string_is_baselines():
@@ -37,10 +57,17 @@ def test_metric_string_is_baselines():
     assert b.HBM_PEAK_GBS == 8000.0
 
 
-def test_multi_gpu_needs_torchrun():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+def test_plain_multi_gpu_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher starts one process per GPU itself (before touching HIP).  Here, without
+    a GPU, every rank must then fail loudly -- there is no CPU fallback -- and the failure is the children's, not a refusal
+    to start."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+    text = r.stderr + r.stdout
+    assert r.returncode != 0
+    assert "no CPU fallback" in text or "no HIP device" in text or "No HIP GPUs" in text or "ProcessGroupNCCL" in text, text[-2000:]
+    assert "launch multi-GPU runs with" not in text
 
 
 import json
@@ -65,6 +92,21 @@ def test_two_ranks_rehearsal_on_one_gpu():
     assert abs(d["value"] - 2 * (1 << 24) / (d["ms_per_step"] * 1e-3) * 1e-9) < 1e-6 * d["value"]   # units of ALL ranks / max time
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     c5 = d["c5"]
-    # sum over both shards of (a + b), a and b uniform[-1,1): 2 * 2^24 terms of mean 0, variance 2/3 -- a 6-sigma band
+    # config 5's operands (seeds 6/7, uniform[0,1)): 2 * 2^24 terms a + b of mean 1, variance 1/6 -- a 6-sigma band
     n = 2 * (1 << 24)
-    assert abs(c5["global_sum"]) < 6 * (n * 2.0 / 3.0) ** 0.5 and c5["value"] > 0
+    assert abs(c5["global_sum"] - n) < 6 * (n / 6.0) ** 0.5 and c5["value"] > 0
+    assert "gloo" in c5["allreduce"] and "seeds 6/7" in c5["workload"]
+
+
+@pytest.mark.gpu
+def test_single_process_mode_through_rccl():
+    """`--mode single`: one process, the device group (here one device), the sharded entry points, and config 5's
+    ncclAllReduce issued by libsmhip inside ncclGroupStart/End."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "single", "--steps", "5", "--warmup", "2",
+                        "--log2n", "24", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "one process" in d["config"]["processes"] and 0 < d["roofline"]["frac"] < 1
+    n = 1 << 24
+    c5 = d["c5"]
+    assert abs(c5["global_sum"] - n) < 6 * (n / 6.0) ** 0.5 and "ncclAllReduce" in c5["allreduce"]

@@ -51,3 +51,11 @@ def test_pow_exhaustive_over_all_positive_floats():
         assert r.returncode == 0, r.stdout + r.stderr
         m = re.search(r"0 ULP \d+ \(([\d.]+) %\)  1 ULP \d+ \([\d.]+ %\)  2 ULP (\d+)  >2 ULP (\d+)", r.stdout)
         assert m and int(m.group(2)) == 0 and int(m.group(3)) == 0 and float(m.group(1)) >= floor, r.stdout
+
+
+def test_pool_stream_ordering_across_threads_and_stream_switches():
+    """tests/cpp/pool_streams.hip: a block used on one thread's stream and freed by another thread, a stream switch
+    between use and free, a destroyed stream, two async reductions on two streams."""
+    r = subprocess.run([_exe("pool_streams")], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
