@@ -89,6 +89,15 @@ struct Storage {
         }
         return host;
     }
+    // One element for reading, without mirroring the whole array: element (i) of a device-born result costs one
+    // sizeof(T) copy, not a full download.
+    T fetch(std::size_t index) {
+        if (host_valid || !dev_valid) return host_ro()[index];
+        T v;
+        hip::DeviceGuard on(device);
+        hip::check(smhip_download(&v, static_cast<const T *>(dev) + index, sizeof(T)));
+        return v;
+    }
     // host side current and possibly about to be written: device side goes stale
     T *host_rw() {
         host_ro();
@@ -147,6 +156,7 @@ public:
     }
 
     const T *read() const { return st_->host_ro() + offset_; }  // no invalidation
+    T fetch(std::size_t i) const { return st_->fetch(offset_ + i); }  // one element, no mirror needed
     const std::shared_ptr<Storage<T>> &storage() const { return st_; }
     std::size_t offset() const { return offset_; }
 
@@ -236,7 +246,7 @@ public:
         requires((std::is_integral_v<std::remove_cvref_t<Args>> || std::is_same_v<std::remove_cvref_t<Args>, Slice>) && ...)
     auto operator()(Args &&...args) const {
         if constexpr ((std::is_integral_v<std::remove_cvref_t<Args>> && ...)) {
-            return data.read()[offset_of({static_cast<std::size_t>(args)...}, false)];
+            return data.fetch(offset_of({static_cast<std::size_t>(args)...}, false));
         } else {
             return make_view({processIndex(std::forward<Args>(args))...});
         }
@@ -320,7 +330,8 @@ public:
             arr.copy_dense_to(fb.data());
             return dot_product<T>(fa.data(), fb.data(), totalSize);  // staged: complex arrays have no resident form yet
         } else {
-            throw std::runtime_error("operator%: this element type has no gfx950 kernels yet (no CPU fallback)");
+            static_assert(dependent_false<T>::value, "operator%: this element type has no gfx950 dot-product kernel (float, double, "
+                                                     "signed 32/64-bit integers and std::complex<double> do)");
         }
     }
 
@@ -414,6 +425,9 @@ public:
     // ---- MI355X extensions (not in the reference) -------------------------------
     // Device pointer to this array's first element, values current.  Valid until the
     // array (and its views) die.  Work is stream-ordered on libsmhip's stream.
+    // The host mirror for READING: brought up to date if needed, and -- unlike `data`, whose every use must assume a write
+    // (`arr.data[i] = v` is the reference's idiom) -- the device copy stays valid, so a later operator uploads nothing.
+    const T *cdata() const { return data.read(); }
     const T *device_data() const { return data.storage()->dev_ro() + data.offset(); }
     T *device_data_mut() { return data.storage()->dev_wo() + data.offset(); }
     bool is_dense() const { return is_contiguous(_shape, _strides); }

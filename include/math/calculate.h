@@ -20,16 +20,21 @@
 // a failing device call throws std::runtime_error, the library's single
 // exception type (SMUtils.h:76-78).
 //
-// User-defined Ops: SM_DEVICE_OP(MyOp, "(a + b) * 2") (math/ops.h) gives an Op its device form -- the
-// expression is compiled for gfx950 with hipRTC on first use -- and it then runs through the same
-// entry points as the built-ins.  An Op with no device functor (sm::hip::device_op<Op>::available == false)
-// is refused with a std::runtime_error naming it: there is no host arithmetic path in this library.
+// User-defined Ops: SM_DEVICE_OP(MyOp, "(a + b) * 2") or SM_DEFINE_OP(MyOp, (a + b) * 2) (math/ops.h) gives an Op its
+// device form -- the expression is compiled for gfx950 with hipRTC on first use -- and it then runs through the same
+// entry points as the built-ins.  An Op WITHOUT a device form (the README recipe as written: apply() plus an x86
+// apply_simd<__m256> body, README.md:86-117) is a COMPILE-TIME error whose message says which line to add: nothing in
+// this library silently computes on the host.  A build that really wants such an Op evaluated by its host apply() --
+// e.g. to bring an existing plugin up unmodified before writing its device string -- opts in with
+// -DSM_ALLOW_HOST_USER_OPS: the three templates below then run the reference's scalar loop (calculate.h:52-63,96 /
+// :131-133 / :166-168) for USER Ops on HOST pointers.  The five built-in Ops never take that path, with or without it.
 #pragma once
 
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <typeinfo>
 #include <vector>
 
@@ -106,12 +111,25 @@ void array_scalar_op_device(const T *a, T value, std::size_t n, T *result) {
     check(smhip_array_scalar(device_op<Op>::id(), dtype_of<T>::id, a, &value, n, result));
 }
 
+template <typename Op> struct is_builtin_op : std::false_type {};
+template <typename T> struct is_builtin_op<AddOp<T>> : std::true_type {};
+template <typename T> struct is_builtin_op<SubtractOp<T>> : std::true_type {};
+template <typename T> struct is_builtin_op<MultiplyOp<T>> : std::true_type {};
+template <typename T> struct is_builtin_op<DivideOp<T>> : std::true_type {};
+template <typename T> struct is_builtin_op<PowOp<T>> : std::true_type {};
+
+// What happens to an (element type, Op) pair that has no gfx950 kernel.
 template <typename T, typename Op>
-[[noreturn]] void refuse_host_op() {
-    throw std::runtime_error(std::string("simpleMath/MI355X: Op '") + typeid(Op).name() +
-                             "' has no device functor (sm::hip::device_op<Op>::available == false) or its element type has no "
-                             "kernels; there is no CPU fallback. Give the Op its device form with "
-                             "SM_DEVICE_OP(MyOp, \"<HIP expression in a and b>\") (math/ops.h).");
+constexpr void no_device_form() {
+    static_assert(dtype_of<T>::id >= 0 || !is_builtin_op<Op>::value,
+                  "simpleMath/MI355X: this element type has no gfx950 kernels (float, double and signed 32/64-bit integers do; "
+                  "std::complex has a dot product only) and the library has no CPU arithmetic path");
+#ifndef SM_ALLOW_HOST_USER_OPS
+    static_assert(dependent_false<Op>::value,
+                  "simpleMath/MI355X: this Op has no device form. After the Op add  SM_DEVICE_OP(MyOp, \"<its arithmetic as a HIP "
+                  "expression in a and b>\")  -- or define it in one line with  SM_DEFINE_OP(MyOp, (a + b) * 2)  (math/ops.h). "
+                  "To run an unmodified plugin through its host apply() instead, compile with -DSM_ALLOW_HOST_USER_OPS.");
+#endif
 }
 
 }  // namespace sm::hip
@@ -135,8 +153,22 @@ void element_wise_op(const T *a, const std::vector<std::size_t> &stride_a, const
                                              dr.template as<T>(), shape);
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
-        (void)a; (void)stride_a; (void)b; (void)stride_b; (void)n; (void)result; (void)shape;
-        refuse_host_op<T, Operation>();
+        no_device_form<T, Operation>();
+        // opt-in only (SM_ALLOW_HOST_USER_OPS), user Ops only: the reference's scalar statement, result[linear] =
+        // Op::apply(a[offA], b[offB]) with the row-major unravel of `linear` (calculate.h:52-63, :96), as an odometer
+        std::vector<std::size_t> idx(shape.size(), 0);
+        std::size_t offA = 0, offB = 0;
+        for (std::size_t linear = 0; linear < n; ++linear) {
+            result[linear] = Operation::apply(a[offA], b[offB]);
+            for (std::size_t k = shape.size(); k-- > 0;) {
+                offA += stride_a[k];
+                offB += stride_b[k];
+                if (++idx[k] < shape[k]) break;
+                offA -= stride_a[k] * shape[k];
+                offB -= stride_b[k] * shape[k];
+                idx[k] = 0;
+            }
+        }
     }
 }
 
@@ -151,8 +183,8 @@ void handle_contiguous_arrays(const T *a, const T *b, T *result, std::size_t n) 
         check(smhip_contiguous(device_op<Operation>::id(), dtype_of<T>::id, da.get(), db.get(), dr.get(), n));
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
-        (void)a; (void)b; (void)result; (void)n;
-        refuse_host_op<T, Operation>();
+        no_device_form<T, Operation>();
+        for (std::size_t i = 0; i < n; ++i) result[i] = Operation::apply(a[i], b[i]);  // opt-in only, user Ops only
     }
 }
 
@@ -166,7 +198,7 @@ void array_scalar_op(const T *a, T value, const std::size_t n, T *result) {
         array_scalar_op_device<T, Operation>(da.template as<T>(), value, n, dr.template as<T>());
         check(smhip_download(result, dr.get(), n * sizeof(T)));
     } else {
-        (void)a; (void)value; (void)n; (void)result;
-        refuse_host_op<T, Operation>();
+        no_device_form<T, Operation>();
+        for (std::size_t i = 0; i < n; ++i) result[i] = Operation::apply(a[i], value);  // opt-in only, user Ops only
     }
 }

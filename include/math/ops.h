@@ -9,14 +9,17 @@
 // loop runs: sm::hip::device_op<Op>::id names the functor libsmhip's gfx950
 // kernels instantiate for it (simplemath_amd/csrc/ops.hip.h).  The five
 // built-in Ops always run on the device; a user Op gets its device form from
-// SM_DEVICE_OP (below) and is refused loudly without one -- nothing computes on the host.
+// SM_DEVICE_OP / SM_DEFINE_OP (below).  Without one it does not compile (a static_assert says what to add), unless the
+// build opts in to evaluating USER Ops with their host apply() by defining SM_ALLOW_HOST_USER_OPS (math/calculate.h).
 #pragma once
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <typeinfo>
 
 #include "helpers.h"
 #include "smhip.h"
@@ -84,21 +87,98 @@ inline int register_expr(const char *hip_expression) {
 template <typename T, typename Op>
 inline constexpr bool on_device_v = (dtype_of<T>::id >= 0) && device_op<Op>::available;
 
+// SM_DEVICE_OP's string is a second statement of what Op::apply() says.  On an Op's first use per element type the two are
+// compared: 4096 sample pairs (both signs, magnitudes in [1/4, 4], never zero) go through the compiled kernel and through
+// the host Op::apply(); integers must agree exactly, floats to a relative 1e-5 / 1e-12 (the point is to catch a different
+// FORMULA, not a contracted multiply-add).  A mismatch throws std::runtime_error naming the Op.  SMHIP_VERIFY_USER_OPS=0
+// in the environment skips the check.
+template <typename T, typename Op>
+inline void verify_user_op(int id, const char *hip_expression) {
+    if constexpr (dtype_of<T>::id >= 0) {
+        if (const char *env = std::getenv("SMHIP_VERIFY_USER_OPS"))
+            if (env[0] == '0') return;
+        constexpr std::size_t kN = 4096;
+        T a[kN], b[kN], want[kN], got[kN];
+        std::uint64_t state = 0x243F6A8885A308D3ull;
+        auto next = [&state] {  // splitmix64
+            std::uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto sample = [&next]() -> T {
+            const std::uint64_t r = next();
+            if constexpr (std::is_integral_v<T>) {
+                const T m = static_cast<T>(1 + (r >> 8) % 64);
+                return (r & 1) ? m : static_cast<T>(-m);
+            } else {
+                const double m = 0.25 * std::exp2(4.0 * static_cast<double>(r >> 11) / 9007199254740992.0);  // [1/4, 4)
+                return static_cast<T>((r & 1) ? m : -m);
+            }
+        };
+        for (std::size_t i = 0; i < kN; ++i) { a[i] = sample(); b[i] = sample(); want[i] = Op::apply(a[i], b[i]); }
+        void *da = nullptr, *db = nullptr, *dr = nullptr;
+        auto ok = [](int rc) { if (rc < 0) throw std::runtime_error(std::string("smhip: ") + smhip_last_error()); };
+        ok(smhip_alloc(&da, sizeof a)); ok(smhip_alloc(&db, sizeof b)); ok(smhip_alloc(&dr, sizeof got));
+        int rc = smhip_upload(da, a, sizeof a);
+        if (rc >= 0) rc = smhip_upload(db, b, sizeof b);
+        if (rc >= 0) rc = smhip_contiguous(id, dtype_of<T>::id, da, db, dr, kN);
+        if (rc >= 0) rc = smhip_download(got, dr, sizeof got);
+        smhip_free(da); smhip_free(db); smhip_free(dr);
+        ok(rc);
+        for (std::size_t i = 0; i < kN; ++i) {
+            bool same;
+            if constexpr (std::is_integral_v<T>) {
+                same = got[i] == want[i];
+            } else {
+                const double g = static_cast<double>(got[i]), w = static_cast<double>(want[i]);
+                const double tol = (sizeof(T) == 4 ? 1e-5 : 1e-12) * std::fmax(std::fabs(w), 1e-30);
+                same = (std::isnan(g) && std::isnan(w)) || g == w || std::fabs(g - w) <= tol;
+            }
+            if (!same)
+                throw std::runtime_error(std::string("simpleMath/MI355X: user Op '") + typeid(Op).name() + "': its device form \"" +
+                                         hip_expression + "\" disagrees with Op::apply() -- apply(" + std::to_string(a[i]) + ", " +
+                                         std::to_string(b[i]) + ") = " + std::to_string(want[i]) + " on the host, " +
+                                         std::to_string(got[i]) + " from the kernel. Fix the SM_DEVICE_OP string (or define the Op once "
+                                         "with SM_DEFINE_OP); SMHIP_VERIFY_USER_OPS=0 disables this check.");
+        }
+    }
+}
+
+template <typename T, typename Op>
+inline int register_and_verify(const char *hip_expression) {
+    const int id = register_expr(hip_expression);
+    verify_user_op<T, Op>(id, hip_expression);
+    return id;
+}
+
 }  // namespace sm::hip
 
 // Give a user-defined Op template its device form (the gfx950 counterpart of writing an
 // apply_simd<__m256> specialisation, README.md:105-117): the same arithmetic as apply(), as a HIP
-// expression in `a` and `b`.  At global scope, after the Op:
+// expression in `a` and `b` (the element type is `T`).  At global scope, after the Op:
 //     template <typename T> struct MyOp { static T apply(const T& a, const T& b) { return (a + b) * 2; } ... };
 //     SM_DEVICE_OP(MyOp, "(a + b) * 2")
-// The expression is compiled for gfx950 by hipRTC on first use and cached.
-#define SM_DEVICE_OP(OpTemplate, hip_expression)                                   \
-    namespace sm::hip {                                                            \
-    template <typename T> struct device_op<OpTemplate<T>> {                        \
-        static constexpr bool available = true;                                    \
-        static int id() {                                                          \
-            static const int v = register_expr(hip_expression);                    \
-            return v;                                                              \
-        }                                                                          \
-    };                                                                             \
+// The expression is compiled for gfx950 by hipRTC on first use and cached; that first use also checks it against
+// apply() on sample values (sm::hip::verify_user_op above).
+#define SM_DEVICE_OP(OpTemplate, hip_expression)                                             \
+    namespace sm::hip {                                                                      \
+    template <typename T> struct device_op<OpTemplate<T>> {                                  \
+        static constexpr bool available = true;                                              \
+        static int id() {                                                                    \
+            static const int v = register_and_verify<T, OpTemplate<T>>(hip_expression);      \
+            return v;                                                                        \
+        }                                                                                    \
+    };                                                                                       \
     }
+
+// One source of truth: the whole Op -- the struct with apply() / apply_simd (the reference's contract,
+// include/math/add.h:5-14) AND its device form -- from one expression in `a`, `b` and `T`:
+//     SM_DEFINE_OP(MyOp, (a + b) * 2)
+// apply() is the expression compiled by the host compiler, the gfx950 kernel is the same tokens compiled by hipRTC.
+#define SM_DEFINE_OP(OpName, ...)                                                            \
+    template <typename T> struct OpName {                                                    \
+        static T apply(const T &a, const T &b) { return static_cast<T>(__VA_ARGS__); }       \
+        template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b); \
+    };                                                                                       \
+    SM_DEVICE_OP(OpName, #__VA_ARGS__)

@@ -517,11 +517,6 @@ TEST(HostPointerLoops) {
 }
 
 template <typename T>
-struct MyOp {  // README.md:94-103 -- a user Op with no device functor
-    static T apply(const T &a, const T &b) { return (a + b) * 2; }
-    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
-};
-template <typename T>
 struct ScaledSum {  // the same plugin, given its device form: runs on the GPU through hipRTC
     static T apply(const T &a, const T &b) { return (a + b) * 2; }
     template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
@@ -543,13 +538,38 @@ TEST(PluginWithDeviceExpression) {
     handle_contiguous_arrays<float, ScaledSum<float>>(x, y, z, 4);  // the host-pointer loop template, same Op
     CHECK_EQ(z[3], 10.0f);
 }
-TEST(PluginWithoutDeviceFunctorIsRefused) {
+SM_DEFINE_OP(Hyp, a * a + b * b)  // the struct (apply / apply_simd) and its device form from ONE expression
+TEST(PluginDefinedOnce) {
+    sm::SMArray<float> a = {3, 5}, b = {4, 12};
+    auto r = a.apply<Hyp<float>>(b);
+    CHECK_EQ(r(0), 25.0f); CHECK_EQ(r(1), 169.0f);
+    CHECK_EQ(Hyp<float>::apply(3.0f, 4.0f), 25.0f);  // the host meaning is the same tokens
+    sm::SMArray<long long> ia = {3}, ib = {4};
+    CHECK_EQ(ia.apply<Hyp<long long>>(ib)(0), 25);
+}
+template <typename T>
+struct Mismatched {  // apply() says one thing, the device string another: caught on first use, naming the Op
+    static T apply(const T &a, const T &b) { return (a + b) * 2; }
+    template <typename SIMD_T> static SIMD_T apply_simd(const SIMD_T &a, const SIMD_T &b);
+};
+SM_DEVICE_OP(Mismatched, "(a + b) * 3")
+TEST(PluginDeviceStringIsCheckedAgainstApply) {
     sm::SMArray<float> a = {1, 2}, b = {3, 4};
-    bool refused = false;
-    try { auto r = a.apply<MyOp<float>>(b); (void)r; } catch (const std::runtime_error &e) {
-        refused = std::string(e.what()).find("no device functor") != std::string::npos;
+    bool caught = false;
+    try { auto r = a.apply<Mismatched<float>>(b); (void)r; } catch (const std::runtime_error &e) {
+        const std::string what = e.what();
+        caught = what.find("disagrees with Op::apply()") != std::string::npos && what.find("Mismatched") != std::string::npos;
     }
-    CHECK(refused);  // loud, never a silent CPU fallback
+    CHECK(caught);
+}
+TEST(ElementReadDoesNotMirrorTheArray) {
+    auto big = sm::ones<float>(1 << 20) * 3.0f;          // device-born
+    const auto &cbig = big;
+    CHECK_EQ(cbig(12345), 3.0f);                          // one 4-byte copy
+    CHECK(!cbig.data.storage()->host_valid);              // no host mirror was made
+    CHECK_EQ(cbig.cdata()[777], 3.0f);                    // the read-only mirror ...
+    CHECK(cbig.data.storage()->dev_valid);                // ... leaves the device copy current
+    CHECK_EQ(sm::sum(big), 3.0 * (1 << 20));
 }
 
 int main() {

@@ -59,3 +59,9 @@ def test_pool_stream_ordering_across_threads_and_stream_switches():
     r = subprocess.run([_exe("pool_streams")], capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_readme_plugin_recipe_on_the_gpu():
+    """The reference's plugin recipe (README.md:86-133) plus SM_DEVICE_OP: element_wise_op<T, MyOp<T>> runs on the GPU."""
+    r = subprocess.run([_exe("readme_recipe")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "device form" in r.stdout and " 0 mismatches" in r.stdout, r.stdout + r.stderr
