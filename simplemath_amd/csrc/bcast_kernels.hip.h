@@ -9,6 +9,7 @@
 // All kernels are launched with 256 threads per workgroup.
 
 constexpr int kMaxOuter = SMHIP_MAX_NDIM - 1;
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 struct RowParams {
     int64_t sa[kMaxOuter], sb[kMaxOuter];  // outer strides, elements, innermost-outer first
@@ -18,6 +19,7 @@ struct RowParams {
     uint32_t inner;   // inner extent in elements
     uint32_t vpr;     // vector slots per row = ceil(inner / W)
     uint32_t grid_x;  // workgroups along the row; the launch is 1-D (grid y is limited to 65 535)
+    uint32_t nt;      // read the streamed operand(s) non-temporally: set when the launch reads more than the Infinity Cache holds
 };
 
 // INNER_x: 1 = dense along the inner axis, 0 = broadcast along it.
@@ -43,7 +45,11 @@ __device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__res
     T va[ROWS][W], vb[ROWS][W];
     // streamed: the operand changes from row to row (read once, non-temporal like the contiguous kernels);
     // a row-constant operand is read through the caches
-    auto load = [&](const T *base, int64_t off, int inner_mode, bool streamed, T (&dst)[W]) {
+    // `streamed` is a TYPE (BoolTag), not a value: written as `if (streamed) load_stream(p) else *p` the two loads are
+    // merged into one plain load while the lambda is optimised on its own -- before inlining could fold the flag --
+    // and the non-temporal hint is silently gone.  (That is what round 1's row kernels did, and why their 1R+1W shapes
+    // ran at 90 %: at those sizes plain loads are the better policy.  It is now a decision: p.nt, see load_stream_if.)
+    auto load = [&](const T *base, int64_t off, int inner_mode, auto streamed, T (&dst)[W]) {
         if (inner_mode == 0) {
             const T s = base[off];
 #pragma unroll
@@ -51,7 +57,7 @@ __device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__res
         } else if (whole) {
             const V *src = reinterpret_cast<const V *>(base + off + col_elem);
             V v;
-            if (streamed) v = load_stream(src);
+            if constexpr (decltype(streamed)::value) v = load_stream_if(T, src, p.nt);
             else v = *src;
 #pragma unroll
             for (int k = 0; k < W; ++k) dst[k] = v[k];
@@ -62,8 +68,8 @@ __device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__res
     };
 
     T ca[W], cb[W];
-    if constexpr (CONST_A) load(a, 0, INNER_A, false, ca);
-    if constexpr (CONST_B) load(b, 0, INNER_B, false, cb);
+    if constexpr (CONST_A) load(a, 0, INNER_A, BoolTag<false>{}, ca);
+    if constexpr (CONST_B) load(b, 0, INNER_B, BoolTag<false>{}, cb);
 
     const uint32_t row0 = (by * ROWS) * TY + ty;
     uint32_t rows_here = 0;
@@ -86,8 +92,8 @@ __device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__res
             if constexpr (!CONST_A) offA += (int64_t)rem * p.sa[p.n_outer - 1];
             if constexpr (!CONST_B) offB += (int64_t)rem * p.sb[p.n_outer - 1];
         }
-        if constexpr (!CONST_A) load(a, offA, INNER_A, INNER_B == 1, va[r]);
-        if constexpr (!CONST_B) load(b, offB, INNER_B, INNER_A == 1, vb[r]);
+        if constexpr (!CONST_A) load(a, offA, INNER_A, BoolTag<INNER_B == 1>{}, va[r]);
+        if constexpr (!CONST_B) load(b, offB, INNER_B, BoolTag<INNER_A == 1>{}, vb[r]);
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {

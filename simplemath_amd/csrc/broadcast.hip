@@ -133,6 +133,14 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             cb &= pl.sb[src] == 0;
         }
         p.vpr = (uint32_t)((inner + W - 1) / W);
+        {   // bytes the launch reads: each operand's distinct elements (a stride-0 axis is read once)
+            size_t da = 1, db = 1;
+            for (int d = 0; d < nd; ++d) {
+                if (pl.sa[d] != 0) da *= (size_t)pl.shape[d];
+                if (pl.sb[d] != 0) db *= (size_t)pl.shape[d];
+            }
+            p.nt = (uint32_t)stream_reads((da + db) * (size_t)esz);
+        }
         L->kind = Launch::kRow;
         L->ia = (int)ia;
         L->ib = (int)ib;
@@ -150,12 +158,13 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
         // Rows per lane (tools/bcast_matrix.py, profiles/r01_bcast_matrix.txt): two when one side is a row-constant or a
         // per-row scalar -- two independent 16-byte loads in flight per lane, 83 % of peak on config 3 against 80 % with
         // one or four; one when both operands stream (three full streams behave like the contiguous kernel: 80 % vs
-        // 74-77 %) and for pow, whose arithmetic already overlaps the next lane's loads.
+        // 74-77 %).
         const bool three_streams = ia == 1 && ib == 1 && !L->ca && !L->cb;
         // no streamed read at all (a per-row scalar against a row-constant: an outer product) is a pure write stream: one
         // row per lane, like the fill kernel (83 % of peak against 78 % with two)
         const bool write_only = (ia == 0 && L->cb) || (ib == 0 && L->ca);
-        L->rows = (three_streams || write_only || heavy) ? 1 : 2;
+        (void)heavy;  // float pow took one row per lane in round 1; with the lighter core two loads in flight per lane win there too
+        L->rows = (three_streams || write_only) ? 1 : 2;
         const int ty = 256 / L->tx;
         const size_t gx = (p.vpr + L->tx - 1) / L->tx;
         const size_t gy = ((size_t)p.rows + ty * L->rows - 1) / (ty * L->rows);
@@ -300,7 +309,7 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
     const dim3 grid(L.grid), block(256);
     switch (L.kind) {
         case Launch::kRow: {
-            constexpr int kRows = (std::is_same<Op, PowOp<T>>::value && std::is_floating_point<T>::value) ? 1 : 2;  // what plan_launch gives non-three-stream forms
+            constexpr int kRows = 2;  // what plan_launch gives non-three-stream forms
             bool launched = false;
             auto go_tx = [&](auto ia_t, auto ib_t, auto ca_t, auto cb_t, auto rows_t) {
                 constexpr int IA = decltype(ia_t)::value, IB = decltype(ib_t)::value, ROWS = decltype(rows_t)::value;

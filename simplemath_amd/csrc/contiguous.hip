@@ -36,15 +36,15 @@ constexpr size_t kBigThreshold = (size_t)1 << 20;
 // by the first thread past the body.
 template <typename T, typename Op, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restrict__ a, const T *__restrict__ b,
-                                                               T *__restrict__ out, size_t n_vec, int tail) {
+                                                               T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
     ctx.init();
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
-        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
-        const V vb = load_stream(reinterpret_cast<const V *>(b) + i);
+        const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
+        const V vb = load_stream_if(T, reinterpret_cast<const V *>(b) + i, nt);
         store_stream(reinterpret_cast<V *>(out) + i, apply_vec<Op, T>(ctx, va, vb));
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) out[n_vec * W + k] = Op::apply(a[n_vec * W + k], b[n_vec * W + k]);
@@ -55,14 +55,14 @@ __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restri
 // lives in SGPRs -- the `set1` of calculate.h:141-146 costs nothing here.
 template <typename T, typename Op, int BLOCK, bool SWAPPED>
 __global__ __launch_bounds__(BLOCK) void scalar_vec_kernel(const T *__restrict__ a, T s, T *__restrict__ out,
-                                                           size_t n_vec, int tail) {
+                                                           size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
     ctx.init();
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
-        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
+        const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
         store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s));
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void scalar_vec_kernel(const T *__restrict__
 // operand, e.g. `A + one_element_array`): a wave-uniform load.
 template <typename T, typename Op, int BLOCK, bool SWAPPED>
 __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restrict__ a, const T *__restrict__ sp,
-                                                              T *__restrict__ out, size_t n_vec, int tail) {
+                                                              T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
     const T s = *sp;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
-        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
+        const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
         store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s));
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
@@ -94,54 +94,61 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
     }
 }
 
-// Arithmetic-heavy Ops (pow): the streaming kernels above give each wave one load, a
-// long stretch of VALU work, one store -- memory and VALU time add up instead of
-// overlapping.  This form is persistent (grid = CUs x 32 workgroups of 512) and
-// software-pipelined one vector deep: the next vector's loads are in flight while
-// the current one is evaluated, and the per-workgroup LDS table of PowOp<float> is
-// staged once per workgroup instead of once per 16 KiB.  profiles/r01_sweep_pow.txt:
-// 91 us vs 104-147 us for config 4, a plain copy of the same bytes being 85 us.
+// Arithmetic-heavy Ops (float / double pow): with ONE vector per lane the streaming kernels above give each wave one
+// load, a long stretch of VALU work, one store -- memory and VALU time add up instead of overlapping (97-99 us for
+// config 4).  Round 1 answered with a persistent, software-pipelined kernel (91-94 us); its prefetch never overlapped
+// anything within a wave, though: `current = next` at the end of the loop makes the compiler put s_waitcnt vmcnt(0)
+// right behind the prefetch.  A two-register-set pipeline that really prefetches (vmcnt(1)/(2)) reaches 87.9 us --
+// and the one-shot form below, with TWO vectors per lane, 84.3 us (tools/sweep_pow2.hip, profiles/r02_sweep_pow2.txt).
 // KIND 0: a[i] op b[i];  1: a[i] op s;  2: s op a[i].
-constexpr int kHeavyBlock = 512;
-constexpr int kHeavyGridPerCU = 32;
-
-template <typename T, typename Op, int KIND>
-__global__ __launch_bounds__(kHeavyBlock) void heavy_vec_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
-                                                                T *__restrict__ out, size_t n_vec, int tail) {
+// The one-shot form for arithmetic-heavy Ops whose arithmetic is light enough to hide: U vectors per lane, all U (x2
+// operands) loads issued before the first use, then U evaluations and stores; one tile of BLOCK * U vectors per
+// workgroup, no loop.  With round 2's f32 pow core (27 instructions per element instead of 45) this beats every
+// persistent shape: 84.3 us for config 4 against 87.9 us for the best two-register-set pipeline and 82.4 us for a plain
+// copy of the same bytes (tools/sweep_pow2.hip, profiles/r02_sweep_pow2.txt); one vector per lane is 97-99 us -- the
+// second load in flight is what covers the arithmetic.  Full tiles are guard-free (per-vector guards make the compiler
+// wait for each load in turn); the last, partial tile and the n % W scalar tail belong to the last workgroup.
+constexpr int kTileBlock = 256;
+template <typename T, typename Op, int KIND, int U>
+__global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
+                                                                T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
     ctx.init();
     const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
     V *ov = reinterpret_cast<V *>(out);
-    const size_t stride = (size_t)gridDim.x * kHeavyBlock;
-    size_t i = (size_t)blockIdx.x * kHeavyBlock + threadIdx.x;
-    if (i == 0) {  // the n % W scalar tail rides with the first lane
+    const size_t base = (size_t)blockIdx.x * (kTileBlock * U) + threadIdx.x;
+    auto eval = [&](const V &xa, const V &xb) {
+        if constexpr (KIND == 0) return apply_vec<Op, T>(ctx, xa, xb);
+        else return apply_vec_scalar<Op, T, KIND == 2>(ctx, xa, s);
+    };
+    if ((size_t)(blockIdx.x + 1) * (kTileBlock * U) <= n_vec) {
+        V va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            va[u] = load_stream_if(T, av + base + (size_t)u * kTileBlock, nt);
+            if constexpr (KIND == 0) vb[u] = load_stream_if(T, bv + base + (size_t)u * kTileBlock, nt);
+            else vb[u] = va[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) store_stream(ov + base + (size_t)u * kTileBlock, eval(va[u], vb[u]));
+        return;
+    }
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * kTileBlock;
+        if (i < n_vec) {
+            const V va = load_stream(av + i);
+            const V vb = KIND == 0 ? load_stream(bv + i) : va;
+            store_stream(ov + i, eval(va, vb));
+        }
+    }
+    if (threadIdx.x == 0) {
         for (int k = 0; k < tail; ++k) {
             const T x = a[n_vec * W + k];
             const T y = KIND == 0 ? b[n_vec * W + k] : s;
             out[n_vec * W + k] = KIND == 2 ? Op::apply(y, x) : Op::apply(x, y);
         }
-    }
-    if (i >= n_vec) return;
-    V ca = load_stream(av + i), cb;
-    if constexpr (KIND == 0) cb = load_stream(bv + i);
-    for (;;) {
-        const size_t nx = i + stride;
-        const bool more = nx < n_vec;
-        V na, nb;
-        if (more) {
-            na = load_stream(av + nx);
-            if constexpr (KIND == 0) nb = load_stream(bv + nx);
-        }
-        V r;
-        if constexpr (KIND == 0) r = apply_vec<Op, T>(ctx, ca, cb);
-        else r = apply_vec_scalar<Op, T, KIND == 2>(ctx, ca, s);
-        store_stream(ov + i, r);
-        if (!more) break;
-        ca = na;
-        if constexpr (KIND == 0) cb = nb;
-        i = nx;
     }
 }
 
@@ -150,11 +157,23 @@ template <typename Op> struct IsHeavy : std::false_type {};
 // it for every exponent distribution tried (tools/ipow_exp.py: 80 % vs 64 % of peak for exponents < 32, 42 % vs 40 % for
 // 20-bit exponents)
 template <typename T> struct IsHeavy<PowOp<T>> : std::integral_constant<bool, std::is_floating_point<T>::value> {};
+// Vectors per lane of the one-shot tile form.  double pow (profiles/r02_op_matrix.txt): two 68-81 %, one 51-72 %.
+#ifndef SMHIP_HEAVY_F64_TILE
+#define SMHIP_HEAVY_F64_TILE 2
+#endif
+template <typename T> struct HeavyTile { static constexpr int value = 2; };
+template <> struct HeavyTile<double> { static constexpr int value = SMHIP_HEAVY_F64_TILE; };
 
-inline unsigned heavy_grid(size_t n_vec) {
-    const size_t want = (n_vec + kHeavyBlock - 1) / kHeavyBlock;
-    const size_t cap = (size_t)compute_units() * kHeavyGridPerCU;
-    return (unsigned)(want < cap ? (want ? want : 1) : cap);
+// Launches the heavy form of `Op` (KIND 0: a op b, 1: a op s, 2: s op a).
+template <typename T, typename Op, int KIND>
+void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s);
+
+template <typename T, typename Op, int KIND>
+void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
+    constexpr int U = HeavyTile<T>::value;
+    const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
+    const int nt = stream_reads((KIND == 0 ? 2 : 1) * n_vec * 16);
+    hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
 }
 
 inline int grid_for(size_t threads, int block, unsigned *grid) {
@@ -174,13 +193,14 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     const int tail = (int)(n % W);
     const size_t threads = n_vec + (tail ? 1 : 0);
     if constexpr (IsHeavy<Op>::value) {
-        hipLaunchKernelGGL((heavy_vec_kernel<T, Op, 0>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa, pb, T{}, po, n_vec, tail);
+        if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
+        launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
     } else if (n_vec >= kBigThreshold) {
         if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail);
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, stream_reads(2 * n * sizeof(T)));
     } else {
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail);
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_reads(2 * n * sizeof(T)));
     }
     SMHIP_LAUNCH_CHECK("contiguous");
     return SMHIP_OK;
@@ -215,23 +235,23 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         if (value == T(2) || value == T(1) || value == T(-1) || value == T(0.5)) {
             if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
             const dim3 g(grid), b(kBlockSmall);
-            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail);
-            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail);
-            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail);
-            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail);
+            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
+            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
+            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
+            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
             SMHIP_LAUNCH_CHECK("array_scalar pow (exact form)");
             return SMHIP_OK;
         }
     }
     constexpr bool kHeavy = IsHeavy<Op>::value;
     if constexpr (kHeavy) {
-        hipLaunchKernelGGL((heavy_vec_kernel<T, Op, SWAPPED ? 2 : 1>), dim3(heavy_grid(n_vec)), dim3(kHeavyBlock), 0, s, pa,
-                           static_cast<const T *>(nullptr), value, po, n_vec, tail);
+        if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
+        launch_heavy<T, Op, SWAPPED ? 2 : 1>(pa, static_cast<const T *>(nullptr), value, po, n_vec, tail, s);
     } else {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail);
+        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
     }
     SMHIP_LAUNCH_CHECK("array_scalar");
     return SMHIP_OK;
@@ -247,7 +267,7 @@ int run_devscalar(const void *a, const void *sp, size_t n, void *out, hipStream_
     const size_t n_vec = n / W;
     const int tail = (int)(n % W);
     if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
-    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail);
+    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail, stream_reads(n * sizeof(T)));
     SMHIP_LAUNCH_CHECK("array_devscalar");
     return SMHIP_OK;
 }

@@ -69,6 +69,10 @@ constexpr int kReduceFoldSpan = 1024;  // = reduce.hip's kFoldSpan: partial buff
             return ::smhip::fail(SMHIP_ERR_HIP, "launch %s: %s", what, hipGetErrorString(smhip_e_)); \
     } while (0)
 
+// Read streams of a launch get the non-temporal hint when together they exceed the Infinity Cache (ops.hip.h: load_stream_if).
+constexpr size_t kInfinityCacheBytes = (size_t)256 << 20;
+inline int stream_reads(size_t bytes_read) { return bytes_read > kInfinityCacheBytes ? 1 : 0; }
+
 inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }
 inline bool valid_dtype(int dtype) { return dtype >= SMHIP_F32 && dtype <= SMHIP_I64; }
 inline bool valid_op(int op) { return op >= SMHIP_OP_ADD && op <= SMHIP_OP_LEFT; }

@@ -181,10 +181,17 @@ typedef __SIZE_TYPE__ size_t;
 #define SMHIP_MAX_NDIM 6
 template <typename T> struct VecTraits;
 #define SMHIP_VEC(T, N) template <> struct VecTraits<T> { typedef T full_t __attribute__((ext_vector_type(N))); \
-    typedef full_t vec_t __attribute__((aligned(sizeof(T)))); static constexpr int width = N; };
+    typedef full_t vec_t __attribute__((aligned(sizeof(T)))); typedef T half_full_t __attribute__((ext_vector_type(N / 2))); \
+    typedef half_full_t half_t __attribute__((aligned(sizeof(T)))); static constexpr int width = N; \
+    static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } };
+#define SMHIP_JOIN_4 0, 1, 2, 3
+#define SMHIP_JOIN_2 0, 1
 SMHIP_VEC(float, 4) SMHIP_VEC(int32_t, 4) SMHIP_VEC(double, 2) SMHIP_VEC(int64_t, 2)
 #define load_stream(ptr) __builtin_nontemporal_load(ptr)
 #define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
+#define load_stream_if(T, ptr, nt) ({ typedef VecTraits<T> smhip_tr_; const typename smhip_tr_::vec_t *smhip_p_ = (ptr); typename smhip_tr_::full_t smhip_v_; \
+    if (nt) { smhip_v_ = __builtin_nontemporal_load(smhip_p_); } else { const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
+    const typename smhip_tr_::half_full_t smhip_lo_ = smhip_h_[0], smhip_hi_ = smhip_h_[1]; smhip_v_ = smhip_tr_::join(smhip_lo_, smhip_hi_); } smhip_v_; })
 struct FastDiv {
     uint32_t d, mul, shr;
     __device__ FastDiv() : d(1), mul(0), shr(0) {}

@@ -33,8 +33,13 @@ template <typename T> struct VecTraits;
     template <> struct VecTraits<T> {                                         \
         typedef T full_t __attribute__((ext_vector_type(N)));                \
         typedef full_t vec_t __attribute__((aligned(sizeof(T))));            \
+        typedef T half_full_t __attribute__((ext_vector_type(N / 2)));       \
+        typedef half_full_t half_t __attribute__((aligned(sizeof(T))));      \
         static constexpr int width = N;                                       \
+        static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } \
     };
+#define SMHIP_JOIN_4 0, 1, 2, 3
+#define SMHIP_JOIN_2 0, 1
 SMHIP_VEC(float, 4)
 SMHIP_VEC(int32_t, 4)
 SMHIP_VEC(double, 2)
@@ -52,6 +57,29 @@ SMHIP_VEC(int64_t, 2)
 #define load_stream(ptr) __builtin_nontemporal_load(ptr)
 #define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
 #endif
+// The READ side's policy as a launch-time (wave-uniform) choice.  Whether a read stream wants `nt` depends on its size
+// (tools/sweep_scalar2.hip, profiles/r02_sweep_scalar2.txt): operands that together fit the 256 MiB Infinity Cache are
+// served faster through plain loads -- 1R+1W at 256 MiB: 92.9 % of HBM peak against 83.5 % with nt, 2R+1W at 2 x 64 MiB:
+// 88 % against 79.5 % -- and larger ones faster with nt (1 GiB: 79.3 % plain, 82.0 % nt; 2R+1W at 2 x 256 MiB: 74 %
+// against 82 %).  The host passes nt = (bytes the launch reads > kInfinityCacheBytes).
+// The plain arm is written as two half-width loads on purpose: as `if (nt) nt_load(p) else *p` the two arms are one load
+// with different metadata to the optimiser, which merges them and drops the hint; two halves are a different
+// instruction sequence until the load/store vectoriser (which runs after the CFG clean-ups) joins them back into one
+// global_load_dwordx4 -- so the ISA has exactly `global_load_dwordx4 ... nt` in one arm and `global_load_dwordx4` in the other.
+#define load_stream_if(T, ptr, nt)                                                                 \
+    ({                                                                                             \
+        typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
+        const typename smhip_tr_::vec_t *smhip_p_ = (ptr);                                         \
+        typename smhip_tr_::full_t smhip_v_;                                                       \
+        if (nt) {                                                                                  \
+            smhip_v_ = __builtin_nontemporal_load(smhip_p_);                                       \
+        } else {                                                                                   \
+            const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
+            const typename smhip_tr_::half_full_t smhip_lo_ = smhip_h_[0], smhip_hi_ = smhip_h_[1]; \
+            smhip_v_ = smhip_tr_::join(smhip_lo_, smhip_hi_);                                      \
+        }                                                                                          \
+        smhip_v_;                                                                                  \
+    })
 
 // -------------------------------------------------------------- Op policies
 // f32/f64: one correctly rounded IEEE operation each (add.h:18-59 etc.);

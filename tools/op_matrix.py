@@ -4,7 +4,8 @@ import sys, ctypes as C
 sys.path.insert(0, "/root/repo")
 import numpy as np
 import simplemath_amd as sma
-lib = sma.load()
+lib = sma.load(sys.argv[1]) if len(sys.argv) > 1 else sma.load()
+ONLY = sys.argv[2].split(',') if len(sys.argv) > 2 else None  # e.g. f64
 def timeit(fn, args, steps=30):
     for _ in range(5): fn(*args)
     e0, e1 = lib.event(), lib.event()
@@ -19,6 +20,7 @@ for _ in range(300): lib.c.smhip_array_scalar(C.c_int(4), C.c_int(0), C.c_void_p
 lib.synchronize()
 print("%-5s %-4s %-14s %10s %9s %7s" % ("dtype", "op", "form", "ms", "GB/s", "% peak"))
 for dtn, dt, code in (("f32", np.float32, 0), ("f64", np.float64, 1), ("i32", np.int32, 2), ("i64", np.int64, 3)):
+    if ONLY and dtn not in ONLY: continue
     n = GiB // np.dtype(dt).itemsize
     # inputs: positive floats in (0.5, 2) / ints in [1, 1000]: fine for every op incl. div and pow
     if dt in (np.float32, np.float64):
