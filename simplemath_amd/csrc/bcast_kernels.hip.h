@@ -198,6 +198,7 @@ struct LdsParams {
     int ndim;
     uint32_t n, n_vec;                // outputs, and whole vectors among them
     uint32_t y_span;                  // elements of the small operand to stage
+    uint32_t nt;                      // read the dense operand non-temporally (it exceeds the Infinity Cache)
 };
 
 // x: the operand that is dense in output order (streams as vectors); y: the small one, gathered
@@ -264,7 +265,7 @@ __device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t v = base + u * 256u + threadIdx.x;
-            if (v < p.n_vec) xv[u] = load_stream(reinterpret_cast<const V *>(x) + v);
+            if (v < p.n_vec) xv[u] = load_stream_if(T, reinterpret_cast<const V *>(x) + v, p.nt);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

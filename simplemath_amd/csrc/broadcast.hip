@@ -202,6 +202,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             lp.n = (uint32_t)pl.n;
             lp.n_vec = (uint32_t)(pl.n / W);
             lp.y_span = (uint32_t)(pick == 0 ? span_b : span_a);
+            lp.nt = (uint32_t)stream_reads(pl.n * (size_t)esz);
             for (int d = 0; d < nd; ++d) {
                 const int src = nd - 1 - d;
                 lp.shape[d] = FastDiv((uint32_t)pl.shape[src]);

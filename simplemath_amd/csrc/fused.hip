@@ -21,15 +21,15 @@ constexpr int kBlock = 1024;
 template <typename T, typename Op1, typename Op2, bool SCALAR_C>
 __global__ __launch_bounds__(kBlock) void fused_vec_kernel(const T *__restrict__ a, const T *__restrict__ b,
                                                            const T *__restrict__ c, T cs, T *__restrict__ out, size_t n_vec,
-                                                           int tail) {
+                                                           int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n_vec) {
-        const V va = load_stream(reinterpret_cast<const V *>(a) + i);
-        const V vb = load_stream(reinterpret_cast<const V *>(b) + i);
+        const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
+        const V vb = load_stream_if(T, reinterpret_cast<const V *>(b) + i, nt);
         V vc;
-        if constexpr (!SCALAR_C) vc = load_stream(reinterpret_cast<const V *>(c) + i);
+        if constexpr (!SCALAR_C) vc = load_stream_if(T, reinterpret_cast<const V *>(c) + i, nt);
         V r;
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = Op2::apply(Op1::apply(va[k], vb[k]), SCALAR_C ? cs : vc[k]);
@@ -52,8 +52,8 @@ int run(const void *a_, const void *b_, const void *c_, const void *cs_host, voi
     const size_t n_vec = n / W, threads = n_vec + (n % W ? 1 : 0);
     const size_t g = (threads + kBlock - 1) / kBlock;
     if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused: array too large for one launch");
-    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W));
-    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W));
+    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_reads(2 * n * sizeof(T)));
+    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_reads(3 * n * sizeof(T)));
     SMHIP_LAUNCH_CHECK("fused");
     return SMHIP_OK;
 }

@@ -14,7 +14,10 @@
 // fixed order: results are deterministic run to run.
 // Roofline: HBM-bound; sizeof(T) B/elem (sum), 2*sizeof(T) (dot),
 // 3*sizeof(T) (fused op+sum: the sum adds no traffic).
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "internal.h"
 #include "ops.hip.h"
@@ -130,6 +133,20 @@ __device__ __forceinline__ void write_result(typename AccOf<T>::type acc, void *
     }
 }
 
+// Arrival counters for finish_kernel: a few zeroed uint32 per (device, stream), made on that pair's first
+// reduction and never freed.  Reductions queued on one stream run one after the other and every launch leaves its
+// counters at zero, so a stream's buffer is always ready for the next launch; two streams never share one.  (A caller
+// stream that is destroyed leaves its 4 KiB behind; a later stream that gets the same handle finds them zeroed.)
+int reduce_counters(hipStream_t s, uint32_t **out);
+
+// What the finishing launch of a multi-workgroup reduction needs (finish_kernel).
+template <typename A> struct Finish {
+    A *level2;           // one total per group
+    uint32_t *counters;  // the arrival counter, zero between launches
+    uint32_t gsize, groups;
+};
+constexpr uint32_t kMaxGroups = 1024, kGroupTarget = 1024;
+
 // Each workgroup owns one tile of kBlock * kVecPerThread vectors.  Full tiles (all
 // but possibly the last) take a guard-free path: every load of the tile is issued
 // before the first use, so kVecPerThread (x2 operands) 16-byte loads are in flight
@@ -138,7 +155,7 @@ __device__ __forceinline__ void write_result(typename AccOf<T>::type acc, void *
 template <typename T, typename Op, int MODE>
 __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                            size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials,
-                                                           void *__restrict__ out8, T *__restrict__ out_native) {
+                                                           void *__restrict__ out8, T *__restrict__ out_native, int nt) {
     typedef typename AccOf<T>::type A;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
@@ -154,8 +171,8 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
         V va[kVecPerThread], vb[kVecPerThread];
 #pragma unroll
         for (int u = 0; u < kVecPerThread; ++u) {
-            va[u] = load_stream(av + tile0 + (size_t)u * kBlock);
-            if constexpr (MODE != kSum) vb[u] = load_stream(bv + tile0 + (size_t)u * kBlock);
+            va[u] = load_stream_if(T, av + tile0 + (size_t)u * kBlock, nt);
+            if constexpr (MODE != kSum) vb[u] = load_stream_if(T, bv + tile0 + (size_t)u * kBlock, nt);
             else vb[u] = va[u];
         }
 #pragma unroll
@@ -185,6 +202,48 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
     if (threadIdx.x == 0) {
         if (gridDim.x == 1) write_result<T, MODE != kDot>(acc, out8, out_native);  // a small array: no second launch
         else partials[blockIdx.x] = acc;
+    }
+}
+
+// The second (and last) launch of a multi-workgroup reduction.  Workgroup g adds `gsize` partials IN INDEX ORDER into
+// level2[g]; the last workgroup to finish -- whichever it is -- adds the level2 values in index order and writes the
+// result, so the bits are the same on every run.  Round 1 ran this as two launches (fold, then finalize: 4.7 us each
+// behind a 502 us main kernel, profiles/r01_add_sum_kernel_stats.csv).  Doing it inside the main kernel instead was
+// measured and dropped: a device-scope release per workgroup writes back the whole L2, 262 144 times (11.4 ms).
+// The arrival counter resets itself.
+template <typename T, bool AS_DOUBLE>
+__global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>::type *__restrict__ partials, uint32_t count,
+                                                        Finish<typename AccOf<T>::type> fin, void *__restrict__ out8,
+                                                        T *__restrict__ out_native) {
+    typedef typename AccOf<T>::type A;
+    const uint32_t first = blockIdx.x * fin.gsize;
+    const uint32_t members = first + fin.gsize <= count ? fin.gsize : count - first;
+    A acc = A(0);
+    for (uint32_t i = threadIdx.x; i < members; i += kBlock) acc += partials[first + i];
+    acc = block_reduce<A, kBlock>(acc);
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) write_result<T, AS_DOUBLE>(acc, out8, out_native);
+        return;
+    }
+    // The hand-over uses device-scope RELAXED atomics only: they are performed at the memory side (write-through, past
+    // the per-XCD L2s), so no fence is needed -- a device-scope release fence writes back the whole L2, which right behind
+    // a kernel that streamed a gigabyte of results costs more than the launch it saves.  Order between the total and the
+    // ticket comes from waiting for the store's acknowledgement (vmcnt) before the ticket is taken.
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&fin.level2[blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    acc = A(0);
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += kBlock) acc += __hip_atomic_load(&fin.level2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // block_reduce's LDS slots are reused
+    acc = block_reduce<A, kBlock>(acc);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(fin.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        write_result<T, AS_DOUBLE>(acc, out8, out_native);
     }
 }
 
@@ -261,6 +320,23 @@ __global__ __launch_bounds__(64) void cdot_finalize_kernel(const double *__restr
     if (threadIdx.x == 0) { out2[0] = re; out2[1] = im; }
 }
 
+// Queues finish_kernel over `blocks` partials (blocks >= 1); `partials` has room for the group totals behind them
+// (blocks / kGroupTarget + 2 more accumulators are enough).
+template <typename T, bool AS_DOUBLE>
+int launch_finish(typename AccOf<T>::type *partials, size_t blocks, void *out8, T *out_native, hipStream_t s) {
+    typedef typename AccOf<T>::type A;
+    uint32_t groups = (uint32_t)((blocks + kGroupTarget - 1) / kGroupTarget);
+    if (groups > kMaxGroups) groups = kMaxGroups;
+    const uint32_t gsize = (uint32_t)((blocks + groups - 1) / groups);
+    groups = (uint32_t)((blocks + gsize - 1) / gsize);
+    Finish<A> fin{partials + blocks, nullptr, gsize, groups};
+    if (groups > 1)
+        if (int rc = reduce_counters(s, &fin.counters)) return rc;
+    hipLaunchKernelGGL((finish_kernel<T, AS_DOUBLE>), dim3(groups), dim3(kBlock), 0, s, partials, (uint32_t)blocks, fin, out8, out_native);
+    SMHIP_LAUNCH_CHECK("reduce finish");
+    return SMHIP_OK;
+}
+
 template <typename T, typename Op, int MODE>
 int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8, void *out_native, hipStream_t s) {
     typedef typename AccOf<T>::type A;
@@ -272,23 +348,33 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     size_t blocks;
     blocks = n_vec / tile + 1;  // the last workgroup takes the partial tile and the n % W tail (maybe empty)
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);
-    const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
-    double *scratch;
+    double *scratch = nullptr;
     ScratchLease lease;
-    if (int rc = lease.take(blocks + folded, &scratch)) return rc;
+    if (blocks > 1)
+        if (int rc = lease.take(blocks + blocks / kGroupTarget + 2, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
     hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
-                       static_cast<T *>(out_native));
+                       static_cast<T *>(out_native), stream_reads((MODE == kSum ? 1 : 2) * n * sizeof(T)));
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
-    if (blocks > (size_t)kFoldSpan) {
-        hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)folded), dim3(kBlock), 0, s, partials, blocks, partials + blocks);
-        SMHIP_LAUNCH_CHECK("reduce fold");
-        partials += blocks;
-        blocks = folded;
+    return launch_finish<T, MODE != kDot>(partials, blocks, out8, static_cast<T *>(out_native), s);
+}
+
+int reduce_counters(hipStream_t s, uint32_t **out) {
+    static std::mutex mutex;
+    static std::map<std::pair<int, hipStream_t>, uint32_t *> buffers;
+    const std::pair<int, hipStream_t> key(current_device(), s);
+    std::lock_guard<std::mutex> lock(mutex);
+    auto it = buffers.find(key);
+    if (it == buffers.end()) {
+        void *p = nullptr;
+        const size_t bytes = 64;  // one counter, on a cache line of its own
+        SMHIP_TRY(hipMalloc(&p, bytes));
+        SMHIP_TRY(hipMemset(p, 0, bytes));
+        SMHIP_TRY(hipDeviceSynchronize());
+        it = buffers.emplace(key, static_cast<uint32_t *>(p)).first;
     }
-    hipLaunchKernelGGL((finalize_kernel<T, MODE != kDot>), dim3(1), dim3(kFinalBlock), 0, s, partials, blocks, out8, static_cast<T *>(out_native));
-    SMHIP_LAUNCH_CHECK("reduce finalize");
+    *out = it->second;
     return SMHIP_OK;
 }
 
@@ -361,29 +447,15 @@ int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void 
 // For reductions whose first pass is compiled at run time (jit.hip: fused expression + sum): `partials` holds one
 // accumulator per workgroup of that pass (double for float types, uint64 for integer types, as AccOf<T>), with room
 // for blocks / kFoldSpan + 1 more behind them; this runs the fixed-order fold and the final pass into *out8 (fp64).
-int reduce_finish(int dtype, void *partials_, size_t blocks, double *out8, hipStream_t s) {
-    const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
-    auto go = [&](auto tag) {
-        typedef decltype(tag) T;
-        typedef typename AccOf<T>::type A;
-        A *partials = static_cast<A *>(partials_);
-        size_t count = blocks;
-        if (blocks > (size_t)kFoldSpan) {
-            hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)folded), dim3(kBlock), 0, s, partials, blocks, partials + blocks);
-            partials += blocks;
-            count = folded;
-        }
-        hipLaunchKernelGGL((finalize_kernel<T, true>), dim3(1), dim3(kFinalBlock), 0, s, partials, count, out8, static_cast<T *>(nullptr));
-    };
+int reduce_finish(int dtype, void *partials, size_t blocks, double *out8, hipStream_t s) {
+    if (blocks < 1) return fail(SMHIP_ERR_INVALID, "reduce_finish: no partials");
     switch (dtype) {
-        case SMHIP_F32: go(float{}); break;
-        case SMHIP_F64: go(double{}); break;
-        case SMHIP_I32: go(int32_t{}); break;
-        case SMHIP_I64: go(int64_t{}); break;
-        default: return fail(SMHIP_ERR_INVALID, "reduce_finish: bad dtype %d", dtype);
+        case SMHIP_F32: return launch_finish<float, true>(static_cast<double *>(partials), blocks, out8, static_cast<float *>(nullptr), s);
+        case SMHIP_F64: return launch_finish<double, true>(static_cast<double *>(partials), blocks, out8, static_cast<double *>(nullptr), s);
+        case SMHIP_I32: return launch_finish<int32_t, true>(static_cast<uint64_t *>(partials), blocks, out8, static_cast<int32_t *>(nullptr), s);
+        case SMHIP_I64: return launch_finish<int64_t, true>(static_cast<uint64_t *>(partials), blocks, out8, static_cast<int64_t *>(nullptr), s);
     }
-    SMHIP_LAUNCH_CHECK("reduce finish");
-    return SMHIP_OK;
+    return fail(SMHIP_ERR_INVALID, "reduce_finish: bad dtype %d", dtype);
 }
 
 }  // namespace smhip
