@@ -348,10 +348,25 @@ public:
     // (the README's "add the operator in SMArray.h" step, without editing the class).
     template <typename Op>
     SMArray apply(const SMArray &rhs) const {
-        auto br = sm::broadcast(_shape, _strides, rhs._shape, rhs._strides);
+        // equal shapes need no resolving (and none of sm::broadcast's vectors): the common case, and the one that
+        // matters for tiny arrays, where the operator's host work is a visible part of its few microseconds
+        auto br = _shape == rhs._shape ? BroadCastResult{_shape, {}, _strides, {}, rhs._strides, totalSize}
+                                       : sm::broadcast(_shape, _strides, rhs._shape, rhs._strides);
         if (br.resultShape.size() > MAX_NDIM) throw std::runtime_error("rank exceeds MAX_NDIM");
         if constexpr (hip::on_device_v<T, Op>) {
             SMArray out = device_empty(std::move(br.resultShape));
+            if (!out._shape.empty() && out.totalSize <= SMHIP_INLINE_MAX_OUTPUTS && (host_only_small() || rhs.host_only_small()) &&
+                hip::device_op<Op>::id() <= SMHIP_OP_POW) {
+                // a tiny operand that exists only on the host rides in the kernel's argument block: one packet instead
+                // of an upload packet plus a kernel packet (smhip_elementwise_inline)
+                const std::size_t ia = host_only_small(), ib = rhs.host_only_small();
+                const auto sa = hip::to_i64(br.newStrides1), sb = hip::to_i64(br.newStrides2), sh = hip::to_i64(out._shape);
+                hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id,
+                                                    ia ? static_cast<const void *>(data.read()) : device_data(), ia, sa.data(),
+                                                    ib ? static_cast<const void *>(rhs.data.read()) : rhs.device_data(), ib, sb.data(),
+                                                    sh.data(), static_cast<int>(sh.size()), out.device_data_mut()));
+                return out;
+            }
             hip::element_wise_op_device<T, Op>(device_data(), br.newStrides1, rhs.device_data(), br.newStrides2,
                                                out.device_data_mut(), out._shape);
             return out;
@@ -373,6 +388,15 @@ public:
     SMArray apply_scalar(T value) const {
         if constexpr (hip::on_device_v<T, Op>) {
             SMArray out = device_empty(std::vector<std::size_t>(_shape));
+            if (!_shape.empty() && totalSize <= SMHIP_INLINE_MAX_OUTPUTS && host_only_small() && hip::device_op<Op>::id() <= SMHIP_OP_POW) {
+                // host-built tiny array op scalar: both ride in the launch packet
+                const auto sa = hip::to_i64(_strides), sh = hip::to_i64(_shape);
+                const std::vector<std::int64_t> zeros(sh.size(), 0);
+                hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id, data.read(), host_only_small(), sa.data(),
+                                                    &value, sizeof(T), zeros.data(), sh.data(), static_cast<int>(sh.size()),
+                                                    out.device_data_mut()));
+                return out;
+            }
             if (is_dense()) {
                 hip::array_scalar_op_device<T, Op>(device_data(), value, totalSize, out.device_data_mut());
             } else {  // a view: honour its strides (the reference reads views as flat here)
@@ -531,6 +555,15 @@ private:
         hip::check(smhip_elementwise(SMHIP_OP_LEFT, hip::dtype_of<T>::id, src, st.data(), src, zeros.data(), sh.data(),
                                      static_cast<int>(sh.size()), out.device_data_mut()));
         return out;
+    }
+
+    // Bytes from this array's first element to the end of its storage when the elements exist ONLY in host memory and
+    // that is at most SMHIP_INLINE_MAX_BYTES (such an operand can ride in a kernel's argument block); 0 otherwise.
+    std::size_t host_only_small() const {
+        const auto &st = data.storage();
+        if (!st || st->dev_valid || !st->host_valid || st->count <= data.offset()) return 0;
+        const std::size_t bytes = (st->count - data.offset()) * sizeof(T);
+        return bytes <= SMHIP_INLINE_MAX_BYTES ? bytes : 0;
     }
 
     // Device pointer to a dense version of this array (itself when already dense).

@@ -121,6 +121,18 @@ int smhip_is_contiguous(int ndim, const int64_t *shape, const int64_t *strides);
 int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
                       const void *b, const int64_t *stride_b,
                       const int64_t *shape, int ndim, void *out);
+/* element_wise_op for TINY operands that exist only in host memory (the reference's simple_check / BM_SMArrayPow_1D/2D
+ * build 10-25 element arrays on the host and apply one operator, benchmark/add.cpp:4-19, benchmark/pow.cpp:5-28).
+ * `a_host_bytes` > 0 says `a` is a HOST pointer to that many bytes (the operand's whole span, <= SMHIP_INLINE_MAX_BYTES),
+ * which are copied into the kernel's argument block -- the launch packet carries the operand, so there is no upload
+ * packet (~2.7 us each on this stack) and no device buffer for it; 0 says `a` is a device pointer as in
+ * smhip_elementwise.  Likewise b; a scalar is an inline operand of one element with all strides 0.  At most
+ * SMHIP_INLINE_MAX_OUTPUTS results, built-in Ops only (SMHIP_ERR_UNSUPPORTED otherwise: use smhip_elementwise). */
+#define SMHIP_INLINE_MAX_BYTES 1024
+#define SMHIP_INLINE_MAX_OUTPUTS 4096
+int smhip_elementwise_inline(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *stride_a,
+                             const void *b, size_t b_host_bytes, const int64_t *stride_b,
+                             const int64_t *shape, int ndim, void *out);
 /* A whole expression in one pass: out[i] = EXPR(a0[i], ..., a{k-1}[i]) over k <= 8 dense operands of n elements each,
  * EXPR a HIP expression in a0..a7 and the scalars s0..s3 (n_scalars <= 4 values of the element type in host memory, passed
  * at launch: changing them does not recompile), e.g. "(a0 + a1) * a2 - s0 * a3".  (k + 1) * sizeof(T) bytes per

@@ -233,6 +233,28 @@ class Smhip:
         self.elementwise_raw(op, a.dtype, a.ptr, sa, b.ptr, sb, shape, out.ptr)
         return out
 
+    def binary_inline(self, op, a, b):
+        """a op b where a host numpy array (<= 1 KiB) rides in the kernel's argument block instead of being uploaded
+        (smhip_elementwise_inline); a, b: numpy arrays (inline) or DeviceArrays; a numpy scalar is an inline operand of one element."""
+        def side(x):
+            if isinstance(x, DeviceArray):
+                return x.shape, x.strides, C.c_void_p(x.ptr), 0, x.dtype, None
+            h = np.ascontiguousarray(x)
+            if h.ndim == 0:
+                h = h.reshape(1)
+            return h.shape, [st // h.itemsize for st in h.strides], h.ctypes.data_as(C.c_void_p), h.nbytes, h.dtype, h
+        sha, sta, pa, na, dta, keep_a = side(a)
+        shb, stb, pb, nb, dtb, keep_b = side(b)
+        assert dta == dtb
+        res = self.broadcast(sha, sta, shb, stb)
+        if res is None:
+            raise RuntimeError("Cannot broadcast shapes: incompatible dimensions")
+        shape, sa, sb, _ = res
+        out = self.empty(shape, dta)
+        self._ck(self.c.smhip_elementwise_inline(C.c_int(op), C.c_int(DTYPES[np.dtype(dta)]), pa, C.c_size_t(na), _i64(sa), pb, C.c_size_t(nb),
+                                                 _i64(sb), _i64(shape), C.c_int(len(shape)), C.c_void_p(out.ptr)))
+        return out
+
     def assign(self, dst: DeviceArray, src: DeviceArray):
         """dst[...] = src, element by element (src broadcast to dst's shape): SMArray::operator=(SMArray&&), SMArray.h:89-97."""
         assert dst.dtype == src.dtype

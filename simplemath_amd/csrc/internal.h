@@ -86,6 +86,8 @@ int launch_array_devscalar(int op, int dtype, const void *a, const void *value_d
                            bool swapped, hipStream_t s);
 int launch_broadcast(int op, int dtype, const void *a, const int64_t *sa, const void *b, const int64_t *sb,
                      const int64_t *shape, int ndim, void *out, hipStream_t s);
+int launch_inline(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *sa, const void *b, size_t b_host_bytes,
+                  const int64_t *sb, const int64_t *shape, int ndim, void *out, hipStream_t s);
 int launch_copy_strided(int dtype, const void *src, const int64_t *src_strides, void *dst, const int64_t *dst_strides,
                         const int64_t *shape, int ndim, hipStream_t s);
 // run-time compiled user Ops (jit.hip)

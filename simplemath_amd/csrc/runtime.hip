@@ -255,7 +255,10 @@ int acquire(hipStream_t *stream) {
     }
     if (tls.device < 0) tls.device = 0;
     if (tls.device >= g_device_count) return fail(SMHIP_ERR_INVALID, "device %d out of range (%d devices)", tls.device, g_device_count);
-    SMHIP_TRY(hipSetDevice(tls.device));
+    {   // a thread that stays on one device (the usual case) pays a thread-local read here, not a hipSetDevice
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != tls.device) SMHIP_TRY(hipSetDevice(tls.device));
+    }
     if (!tls.checked[tls.device]) {
         hipDeviceProp_t prop;
         SMHIP_TRY(hipGetDeviceProperties(&prop, tls.device));
@@ -672,6 +675,30 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
     SMHIP_ACQUIRE(s);
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
+}
+
+int smhip_elementwise_inline(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *stride_a, const void *b,
+                             size_t b_host_bytes, const int64_t *stride_b, const int64_t *shape, int ndim, void *out) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "elementwise_inline: bad dtype %d", dtype);
+    if (!valid_op(op)) return fail(user_op(op) ? SMHIP_ERR_UNSUPPORTED : SMHIP_ERR_INVALID, "elementwise_inline: op %d (built-in Ops only)", op);
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "elementwise_inline: ndim %d outside 1..%d", ndim, SMHIP_MAX_NDIM);
+    if (!stride_a || !stride_b || !shape) return fail(SMHIP_ERR_INVALID, "elementwise_inline: null shape/stride");
+    if (a_host_bytes > SMHIP_INLINE_MAX_BYTES || b_host_bytes > SMHIP_INLINE_MAX_BYTES)
+        return fail(SMHIP_ERR_UNSUPPORTED, "elementwise_inline: an inline operand is limited to %d bytes", SMHIP_INLINE_MAX_BYTES);
+    int64_t n = 1, span_a = 0, span_b = 0;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0 || stride_a[i] < 0 || stride_b[i] < 0) return fail(SMHIP_ERR_INVALID, "elementwise_inline: negative extent or stride at dim %d", i);
+        n *= shape[i];
+        if (shape[i] > 0) { span_a += (shape[i] - 1) * stride_a[i]; span_b += (shape[i] - 1) * stride_b[i]; }
+        if (n > SMHIP_INLINE_MAX_OUTPUTS) return fail(SMHIP_ERR_UNSUPPORTED, "elementwise_inline: more than %d results", SMHIP_INLINE_MAX_OUTPUTS);
+    }
+    if (n == 0) return SMHIP_OK;
+    if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise_inline: null buffer");
+    const int64_t esz = (int64_t)dtype_size(dtype);
+    if ((a_host_bytes && (span_a + 1) * esz > (int64_t)a_host_bytes) || (b_host_bytes && (span_b + 1) * esz > (int64_t)b_host_bytes))
+        return fail(SMHIP_ERR_INVALID, "elementwise_inline: the strides reach past the inline operand's bytes");
+    SMHIP_ACQUIRE(s);
+    return launch_inline(op, dtype, a, a_host_bytes, stride_a, b, b_host_bytes, stride_b, shape, ndim, out, s);
 }
 
 int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, const void *scalars_host,

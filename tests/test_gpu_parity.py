@@ -1071,3 +1071,39 @@ def test_pool_reuses_buffers(smhip):
     q = smhip.alloc(1 << 20)
     assert p == q  # the per-operator `new T[n]` of SMArray.h:219 became a pointer pop
     smhip.free(q)
+
+
+def test_inline_operands_vs_oracle(smhip, oracle):
+    """smhip_elementwise_inline: tiny host-built operands carried by the launch packet (no upload).  Same values as the
+    uploaded path / the oracle for every Op and element type, dense and broadcast shapes, array and scalar operands."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(11)
+    ops = {"add": (sma.OP_ADD, orc.ADD), "sub": (sma.OP_SUB, orc.SUB), "mul": (sma.OP_MUL, orc.MUL), "div": (sma.OP_DIV, orc.DIV)}
+    shapes = [((5, 5), (5, 5)), ((25,), (25,)), ((2, 3), (1, 3)), ((4, 1), (1, 7)), ((3, 1, 5), (2, 1)), ((1,), (13,)), ((2, 3, 2, 2), (3, 1, 2))]
+    for dt in (np.float32, np.float64, np.int32, np.int64):
+        for sha, shb in shapes:
+            if np.issubdtype(dt, np.floating):
+                a, b = rng.uniform(-4, 4, sha).astype(dt), rng.uniform(0.5, 4, shb).astype(dt)
+            else:
+                a, b = rng.integers(-50, 50, sha).astype(dt), rng.integers(1, 9, shb).astype(dt)
+            for name, (op, oop) in ops.items():
+                want = oracle.binary(oop, a, b)
+                got = smhip.binary_inline(op, a, b).numpy()
+                assert np.array_equal(got, want), (dt, sha, shb, name)
+                da = smhip.to_device(a)                      # one side resident, the other inline
+                assert np.array_equal(smhip.binary_inline(op, da, b).numpy(), want), (dt, sha, shb, name, "a resident")
+                db = smhip.to_device(b)
+                assert np.array_equal(smhip.binary_inline(op, a, db).numpy(), want), (dt, sha, shb, name, "b resident")
+            s = dt(3)
+            assert np.array_equal(smhip.binary_inline(sma.OP_MUL, a, s).numpy(), (a * s).astype(dt)), (dt, sha, "scalar")
+    # int pow: the reference's square-and-multiply (crafted_pow.h:54-103), as the array kernels compute it
+    base = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10], dtype=np.int32)
+    assert np.array_equal(smhip.binary_inline(sma.OP_POW, base, np.int32(3)).numpy(), base ** 3)
+    x = rng.uniform(0.01, 100, 200).astype(np.float32)
+    got = smhip.binary_inline(sma.OP_POW, x, np.float32(2.5)).numpy()
+    assert orc.ulp_diff_f32(got, np.power(x.astype(np.float64), 2.5).astype(np.float32)).max() <= 4
+    # limits are refusals, not truncations
+    with pytest.raises(sma.SmhipError):
+        smhip.binary_inline(sma.OP_ADD, np.zeros(257, np.float32), np.zeros(257, np.float32))  # 1028 bytes
+    with pytest.raises(sma.SmhipError):
+        smhip.binary_inline(sma.OP_ADD, np.zeros((100, 1), np.float32), np.zeros((1, 100), np.float32))  # 10 000 results
