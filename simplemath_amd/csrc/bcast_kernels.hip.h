@@ -10,6 +10,7 @@
 
 constexpr int kMaxOuter = SMHIP_MAX_NDIM - 1;
 template <bool B> struct BoolTag { static constexpr bool value = B; };
+template <int I> struct IntTag { static constexpr int value = I; };
 
 struct RowParams {
     int64_t sa[kMaxOuter], sb[kMaxOuter];  // outer strides, elements, innermost-outer first
@@ -187,6 +188,81 @@ __device__ __forceinline__ void gather_body(const T *__restrict__ a, const T *__
         store_stream(reinterpret_cast<V *>(out + first), v);
     } else {
         for (int k = 0; k < count; ++k) out[first + k] = res[k];
+    }
+}
+
+// ------------------------------------------------------------------- inner-strided rows
+// An operand that takes every 2nd / 3rd / 4th element of the inner axis (a[:, ::2]; one channel of interleaved data).  The
+// gather above reads such an operand with one 4-byte load per lane (W load instructions per 16 bytes of output); here a
+// lane owns W consecutive outputs of a row and loads the S consecutive 16-byte vectors that hold its W inputs, keeping
+// every S-th element -- S full-width loads per operand, every fetched line requested once, the store one vector.  (Half,
+// two thirds or three quarters of every line it fetches is not used whatever the kernel does: the roofline of such a
+// view is lines fetched, not bytes used.)  SA / SB: the operand's inner stride -- 0 one value per row, 1 dense, 2-4
+// strided.  The outer axes are unravelled once per lane like the row kernel's.
+struct StridedParams {
+    int64_t sa[kMaxOuter], sb[kMaxOuter];  // outer strides, elements, innermost-outer first
+    FastDiv shape[kMaxOuter];
+    int n_outer;
+    uint32_t inner;   // outputs per row
+    FastDiv vpr;      // vector slots per row = ceil(inner / W)
+    uint32_t slots;   // rows * vpr
+};
+
+template <typename T, typename Op, int SA, int SB>
+__device__ __forceinline__ void strided_row_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, StridedParams p) {
+    constexpr int W = VecTraits<T>::width;
+    typedef typename VecTraits<T>::vec_t V;
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= p.slots) return;
+    uint32_t row, col;
+    p.vpr.divmod(slot, row, col);
+    int64_t offA = 0, offB = 0;
+    {
+        uint32_t rem = row;
+        for (int k = 0; k < p.n_outer - 1; ++k) {
+            uint32_t q, idx;
+            p.shape[k].divmod(rem, q, idx);
+            rem = q;
+            offA += (int64_t)idx * p.sa[k];
+            offB += (int64_t)idx * p.sb[k];
+        }
+        if (p.n_outer > 0) {
+            offA += (int64_t)rem * p.sa[p.n_outer - 1];
+            offB += (int64_t)rem * p.sb[p.n_outer - 1];
+        }
+    }
+    const uint32_t e0 = col * W;
+    T *dst = out + (size_t)row * p.inner + e0;
+    // strictly inside the row: the S vectors read up to S - 1 elements past the lane's last input, which then still
+    // belongs to the row (the row's own last slot is done element by element)
+    if (e0 + W < p.inner) {
+        T xa[W], xb[W], res[W];
+        auto fetch = [&](const T *base, auto stride_tag, T (&dst_regs)[W]) {
+            constexpr int S = decltype(stride_tag)::value;
+            if constexpr (S == 0) {
+                const T v = *base;
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst_regs[k] = v;
+            } else {
+                V v[S];
+#pragma unroll
+                for (int i = 0; i < S; ++i) v[i] = load_stream(reinterpret_cast<const V *>(base + (int64_t)e0 * S) + i);
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst_regs[k] = v[(k * S) / W][(k * S) % W];
+            }
+        };
+        fetch(a + offA, IntTag<SA>{}, xa);
+        fetch(b + offB, IntTag<SB>{}, xb);
+        apply_n<Op, T, W>(ctx, xa, xb, res);
+        V r;
+#pragma unroll
+        for (int k = 0; k < W; ++k) r[k] = res[k];
+        store_stream(reinterpret_cast<V *>(dst), r);
+    } else {
+        for (uint32_t k = 0; e0 + k < p.inner; ++k)
+            dst[k] = Op::apply(a[offA + (int64_t)(e0 + k) * SA], b[offB + (int64_t)(e0 + k) * SB]);
     }
 }
 

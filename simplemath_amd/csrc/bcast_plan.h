@@ -24,13 +24,14 @@ Plan normalise(const int64_t *shape, const int64_t *sa, const int64_t *sb, int n
 
 // One kernel launch: the body, its compile-time variant, the grid and the parameter block.
 struct Launch {
-    enum Kind { kRow, kLds, kTile, kGather } kind;
+    enum Kind { kRow, kLds, kTile, kGather, kStrided } kind;
     int ia, ib, tx, rows;   // row: INNER_A / INNER_B, lanes per row, rows per lane
     bool ca, cb;            // row: CONST_A / CONST_B
     bool swapped;           // lds: the streamed operand is the Op's right one
     bool vec;               // tile: 16-byte form
     int ma, mb;             // tile: LDS-mode operands (compile-time in the 16-byte form)
     int w;                  // gather: outputs per lane
+                            // strided rows: ia / ib are the inner strides (0..4)
     unsigned grid;
     size_t lds_bytes;
     union Params {
@@ -38,6 +39,7 @@ struct Launch {
         LdsParams lds;
         TileParams tile;
         GatherParams gather;
+        StridedParams strided;
         Params() {}
     } p;
 };

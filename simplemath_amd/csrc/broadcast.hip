@@ -62,6 +62,10 @@ template <typename T, typename Op, int W>
 __global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, GatherParams p) {
     gather_body<T, Op, W>(a, b, out, p);
 }
+template <typename T, typename Op, int SA, int SB>
+__global__ __launch_bounds__(256) void strided_row_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, StridedParams p) {
+    strided_row_body<T, Op, SA, SB>(a, b, out, p);
+}
 template <typename T, typename Op, bool SWAPPED, int U>
 __global__ __launch_bounds__(256) void dense_lds_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out, LdsParams p) {
     dense_lds_body<T, Op, SWAPPED, U>(x, y, out, p);
@@ -276,6 +280,33 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
         }
     }
 
+    // An operand that steps over the inner axis by 2-4 elements, the other side dense, one value per row, or stepping
+    // by the same amount: rows of wide loads + select (strided_row_body).
+    {
+        const int64_t big = ia > ib ? ia : ib, small = ia > ib ? ib : ia;
+        const size_t vpr = ((size_t)inner + W - 1) / W;
+        if (big >= 2 && big <= 4 && (small == big || small == 0 || small == 1) && inner >= 64 && rows * vpr < 0x7fffffffull &&
+            inner < 0x7fffffffll / 4) {
+            StridedParams &p = L->p.strided;
+            p = StridedParams{};
+            p.n_outer = nd - 1;
+            p.inner = (uint32_t)inner;
+            for (int k = 0; k < nd - 1; ++k) {  // innermost-outer first
+                const int src = nd - 2 - k;
+                p.shape[k] = FastDiv((uint32_t)pl.shape[src]);
+                p.sa[k] = pl.sa[src];
+                p.sb[k] = pl.sb[src];
+            }
+            p.vpr = FastDiv((uint32_t)vpr);
+            p.slots = (uint32_t)(rows * vpr);
+            L->kind = Launch::kStrided;
+            L->ia = (int)ia;
+            L->ib = (int)ib;
+            L->grid = (unsigned)((rows * vpr + 255) / 256);
+            return SMHIP_OK;
+        }
+    }
+
     if (pl.n >= 0x7fffffffull)
         return fail(SMHIP_ERR_UNSUPPORTED, "gather path limited to < 2^31 elements (got %zu)", pl.n);
     GatherParams &g = L->p.gather;
@@ -357,6 +388,27 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
             else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, 0, s, a, b, out, L.p.tile);
             SMHIP_LAUNCH_CHECK("tile_kernel");
             return SMHIP_OK;
+        case Launch::kStrided: {
+            bool launched = false;
+            auto go = [&](auto sa_t, auto sb_t) {
+                constexpr int SA = decltype(sa_t)::value, SB = decltype(sb_t)::value;
+                if (L.ia == SA && L.ib == SB) {
+                    hipLaunchKernelGGL((strided_row_kernel<T, Op, SA, SB>), grid, block, 0, s, a, b, out, L.p.strided);
+                    launched = true;
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            using I4 = std::integral_constant<int, 4>;
+            go(I2{}, I2{}); go(I2{}, I1{}); go(I1{}, I2{}); go(I2{}, I0{}); go(I0{}, I2{});
+            go(I3{}, I3{}); go(I3{}, I1{}); go(I1{}, I3{}); go(I3{}, I0{}); go(I0{}, I3{});
+            go(I4{}, I4{}); go(I4{}, I1{}); go(I1{}, I4{}); go(I4{}, I0{}); go(I0{}, I4{});
+            if (!launched) return fail(SMHIP_ERR_INVALID, "strided rows: no kernel for inner strides %d / %d", L.ia, L.ib);
+            SMHIP_LAUNCH_CHECK("strided_row_kernel");
+            return SMHIP_OK;
+        }
         case Launch::kGather:
             if (L.w == 1) hipLaunchKernelGGL((gather_kernel<T, Op, 1>), grid, block, 0, s, a, b, out, L.p.gather);
             else hipLaunchKernelGGL((gather_kernel<T, Op, W>), grid, block, 0, s, a, b, out, L.p.gather);

@@ -434,6 +434,10 @@ int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void
             snprintf(body, sizeof body, "gather_body<T,UserOp,%d>", L.w);
             params = "GatherParams";
             break;
+        case Launch::kStrided:
+            snprintf(body, sizeof body, "strided_row_body<T,UserOp,%d,%d>", L.ia, L.ib);
+            params = "StridedParams";
+            break;
     }
     std::string expr;
     if (int rc = user_expr(op, &expr)) return rc;

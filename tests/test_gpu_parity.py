@@ -1107,3 +1107,39 @@ def test_inline_operands_vs_oracle(smhip, oracle):
         smhip.binary_inline(sma.OP_ADD, np.zeros(257, np.float32), np.zeros(257, np.float32))  # 1028 bytes
     with pytest.raises(sma.SmhipError):
         smhip.binary_inline(sma.OP_ADD, np.zeros((100, 1), np.float32), np.zeros((1, 100), np.float32))  # 10 000 results
+
+
+def test_inner_strided_operands_take_wide_loads(smhip, oracle):
+    """a[:, ::S] op b[...] for S = 2, 3, 4 against a dense / per-row / equally strided partner (strided_row_kernel: S wide loads
+    + select instead of one 4-byte load per lane): every element type, ragged row lengths, views that end at the very
+    last element of their allocation, 1-D and 3-D forms; bit-exact against the oracle's element_wise_op walk."""
+    from oracle import oracle as orc
+    for dtn in ("f32", "f64", "i32", "i64"):
+        dt = DT[dtn]
+        a = gen.gen(dt, 23 * 1030, 7, "uniform").reshape(23, 1030)
+        b = gen.gen(dt, 23 * 1030, 8, "positive" if dtn[0] == "f" else "uniform").reshape(23, 1030)
+        if dtn[0] == "i":
+            b = np.where(b == 0, 1, b).astype(dt)
+        da, db = smhip.to_device(a), smhip.to_device(b)
+        fa, fb = a.reshape(-1), b.reshape(-1)
+        pairs = [(a[:, ::2], b[:, ::2]), (a[:, 1::2], b[:, ::2]), (a[:, ::3], b[:, 1::3]), (a[:, ::4], b[:, 2::4]),
+                 (a[:, ::2], b[:, :515]), (a[:, :343], b[:, 1::3]),                     # strided against dense
+                 (a[:, ::4], b[:, 5:6]), (a[:, 3:4], b[:, ::2]),                        # strided against one value per row
+                 (a[3:, 6:1030:2], b[3:, 7:1030:2]), (a[22:, ::2], b[22:, 1::2]),        # ends at the allocation's last element
+                 (fa[::2], fb[1::2]), (fa[23 * 1030 - 4 * 900::4], fb[:900]),           # 1-D
+                 (a.reshape(23, 10, 103)[:, :, ::2][:, :, :40], b.reshape(23, 10, 103)[:, :, 1::2][:, :, :40])]  # short rows: gather
+        for k, (va, vb) in enumerate(pairs):
+            if va.shape[-1] != vb.shape[-1] and 1 not in (va.shape[-1], vb.shape[-1]):  # stepped slices differ by one column
+                w = min(va.shape[-1], vb.shape[-1])
+                va, vb = va[..., :w], vb[..., :w]
+            for opn in ("add", "div"):
+                want = oracle.binary(getattr(orc, opn.upper()), va, vb)
+                got = smhip.binary(sma.OPS[opn], da.view_like(va, a), db.view_like(vb, b)).numpy()
+                assert np.array_equal(got, want), (dtn, k, opn, va.shape, va.strides, vb.strides)
+    # a user-defined Op takes the same kernel through hipRTC
+    op = smhip.register_op("a * b + a")
+    a = gen.gen(np.float32, 64 * 512, 9, "uniform").reshape(64, 512)
+    b = gen.gen(np.float32, 64 * 512, 10, "uniform").reshape(64, 512)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    got = smhip.binary(op, da.view_like(a[:, ::2], a), db.view_like(b[:, 1::2], b)).numpy()
+    assert np.array_equal(got, a[:, ::2] * b[:, 1::2] + a[:, ::2])
