@@ -53,7 +53,7 @@ private:
     void *p_ = nullptr;
 };
 int reduce_finish(int dtype, void *partials, size_t blocks, double *out8, hipStream_t s);
-constexpr int kReduceFoldSpan = 1024;  // = reduce.hip's kFoldSpan: partial buffers need blocks + blocks / span + 1 slots
+constexpr int kReduceFoldSpan = 1024;  // = reduce.hip's kGroupTarget: partial buffers need blocks + blocks / span + 2 slots
 
 #define SMHIP_TRY(expr)                                                                        \
     do {                                                                                       \

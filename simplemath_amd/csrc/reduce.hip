@@ -43,7 +43,6 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kSumVectors = SMHIP_SUM_VECTORS, kDotVectors = SMHIP_DOT_VECTORS;
 constexpr int vec_per_thread(int mode) { return mode == 0 /* kSum */ ? kSumVectors : mode == 1 /* kDot */ ? kDotVectors : SMHIP_FUSED_VECTORS; }
-constexpr int kFinalBlock = 1024;
 
 template <typename T> struct AccOf { typedef double type; };
 template <> struct AccOf<int32_t> { typedef uint64_t type; };
@@ -247,30 +246,6 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     }
 }
 
-// Intermediate pass when there are many partials (one vector per lane means one partial per 4 KiB
-// of each operand): every workgroup folds kFoldSpan of them into one, in a fixed order.
-constexpr int kFoldSpan = 1024;  // 2^18 partials (2^28 f32) -> 256 workgroups here, 256 values for the last pass
-template <typename A>
-__global__ __launch_bounds__(kBlock) void fold_kernel(const A *__restrict__ in, size_t count, A *__restrict__ out) {
-    const size_t base = (size_t)blockIdx.x * kFoldSpan;
-    A acc = A(0);
-    for (int k = threadIdx.x; k < kFoldSpan; k += kBlock)
-        if (base + k < count) acc += in[base + k];
-    acc = block_reduce<A, kBlock>(acc);
-    if (threadIdx.x == 0) out[blockIdx.x] = acc;
-}
-
-// Last pass: fixed-order sum of the partials (write_result above says what is handed back).
-template <typename T, bool AS_DOUBLE>
-__global__ __launch_bounds__(kFinalBlock) void finalize_kernel(const typename AccOf<T>::type *__restrict__ partials, size_t count,
-                                                               void *__restrict__ out8, T *__restrict__ out_native) {
-    typedef typename AccOf<T>::type A;
-    A acc = A(0);
-    for (size_t i = threadIdx.x; i < count; i += kFinalBlock) acc += partials[i];
-    acc = block_reduce<A, kFinalBlock>(acc);
-    if (threadIdx.x == 0) write_result<T, AS_DOUBLE>(acc, out8, out_native);
-}
-
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // std::complex<double> dot (reference product.h:168-224): sum a[i] * b[i], unconjugated, as the
@@ -282,7 +257,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a, const dbl2 *__restrict__ b, size_t n,
                                                       double *__restrict__ partials, size_t blocks) {
     // one-shot like reduce_kernel: a workgroup owns kBlock * 2 consecutive elements, two per lane and operand in flight;
-    // its partial sums go to partials[block] (real) and partials[blocks + block] (imaginary)
+    // its partial sums go to partials[block] (real) and partials[blocks + block] (imaginary; `blocks` = the arrays' pitch)
     double re = 0.0, im = 0.0;
     auto acc = [&](dbl2 x, dbl2 y) {
         re = __builtin_fma(x[0], y[0], re);
@@ -311,15 +286,6 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
         partials[blocks + blockIdx.x] = m;
     }
 }
-__global__ __launch_bounds__(64) void cdot_finalize_kernel(const double *__restrict__ re_parts, const double *__restrict__ im_parts,
-                                                           size_t count, double *__restrict__ out2) {
-    double re = 0.0, im = 0.0;
-    for (size_t i = threadIdx.x; i < count; i += 64) { re += re_parts[i]; im += im_parts[i]; }
-    re = wave_reduce(re);
-    im = wave_reduce(im);
-    if (threadIdx.x == 0) { out2[0] = re; out2[1] = im; }
-}
-
 // Queues finish_kernel over `blocks` partials (blocks >= 1); `partials` has room for the group totals behind them
 // (blocks / kGroupTarget + 2 more accumulators are enough).
 template <typename T, bool AS_DOUBLE>
@@ -403,24 +369,15 @@ int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out8_d
 int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s) {
     const size_t blocks = n / (kBlock * 2) + 1;
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "complex dot too large (%zu workgroups)", blocks);
-    const size_t folded = (blocks + kFoldSpan - 1) / kFoldSpan;
+    // two partial arrays (real, imaginary), each with room for its group totals behind it
+    const size_t span = blocks + blocks / kGroupTarget + 2;
     double *scratch;
     ScratchLease lease;
-    if (int rc = lease.take(2 * blocks + 2 * folded, &scratch)) return rc;
-    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, blocks);
+    if (int rc = lease.take(2 * span, &scratch)) return rc;
+    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, span);
     SMHIP_LAUNCH_CHECK("cdot");
-    const double *re = scratch, *im = scratch + blocks;
-    size_t count = blocks;
-    if (blocks > (size_t)kFoldSpan) {  // fixed-order fold of the two partial arrays, as in run_reduce
-        double *fre = scratch + 2 * blocks, *fim = fre + folded;
-        hipLaunchKernelGGL(fold_kernel<double>, dim3((unsigned)folded), dim3(kBlock), 0, s, re, blocks, fre);
-        hipLaunchKernelGGL(fold_kernel<double>, dim3((unsigned)folded), dim3(kBlock), 0, s, im, blocks, fim);
-        SMHIP_LAUNCH_CHECK("cdot fold");
-        re = fre; im = fim; count = folded;
-    }
-    hipLaunchKernelGGL(cdot_finalize_kernel, dim3(1), dim3(64), 0, s, re, im, count, out2_dev);
-    SMHIP_LAUNCH_CHECK("cdot finalize");
-    return SMHIP_OK;
+    if (int rc = launch_finish<double, true>(scratch, blocks, out2_dev, static_cast<double *>(nullptr), s)) return rc;
+    return launch_finish<double, true>(scratch + span, blocks, out2_dev + 1, static_cast<double *>(nullptr), s);
 }
 
 int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev, hipStream_t s) {
@@ -446,7 +403,7 @@ int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void 
 
 // For reductions whose first pass is compiled at run time (jit.hip: fused expression + sum): `partials` holds one
 // accumulator per workgroup of that pass (double for float types, uint64 for integer types, as AccOf<T>), with room
-// for blocks / kFoldSpan + 1 more behind them; this runs the fixed-order fold and the final pass into *out8 (fp64).
+// for blocks / kGroupTarget + 2 more behind them; this queues the finishing launch into *out8 (fp64).
 int reduce_finish(int dtype, void *partials, size_t blocks, double *out8, hipStream_t s) {
     if (blocks < 1) return fail(SMHIP_ERR_INVALID, "reduce_finish: no partials");
     switch (dtype) {
