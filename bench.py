@@ -231,6 +231,21 @@ def cpu_baseline(wl, log2n):
 
 # ----------------------------------------------------------------------------------------------- launching
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when a communicator is first created; the contract is ONE JSON line there.
+    While a communicator is being set up, file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as children.  This process
     has not imported torch or touched HIP, and it never becomes a rank itself."""
@@ -355,10 +370,12 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank %= max(torch.cuda.device_count(), 1)  # identity on a full node; lets a rehearsal share one GPU
         torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        with _StdoutToStderr():
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()  # torch creates the communicator lazily: do it now, while stdout is parked
+            else:
+                dist.init_process_group("gloo")
 
     import ctypes as C
     import numpy as np
@@ -370,9 +387,10 @@ def run_rank(args):
     use_lib_comm = world > 1 and args.dist_backend == "nccl"
     if use_lib_comm:
         # libsmhip's own communicator for config 5's all-reduce: the unique id travels over torch.distributed
-        box = [lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        lib.comm_init_rank(world, rank, box[0])
+        with _StdoutToStderr():
+            box = [lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            lib.comm_init_rank(world, rank, box[0])
 
     def barrier():
         lib.synchronize()
@@ -516,7 +534,8 @@ def run_single(args):
         raise SystemExit("--mode single runs the headline `add` workload (and its config-5 leg)")
     lib = sma.load()
     G = args.gpus
-    lib.set_devices(G)
+    with _StdoutToStderr():
+        lib.set_devices(G)
     log2n = args.log2n or 28
     n = 1 << log2n
     F32 = np.float32

@@ -67,6 +67,7 @@ struct Storage {
     bool dev_valid = false;   // device buffer holds the current values
 
     int device = 0;           // the GPU the device buffer lives on (the creating thread's current device)
+    unsigned inline_uses = 0; // times the host-only elements rode in a kernel's argument block instead of being uploaded
 
     explicit Storage(std::size_t n) : count(n) { smhip_get_device(&device); }
     Storage(T *adopted, std::size_t n) : host(adopted), count(n), host_valid(true) { smhip_get_device(&device); }  // takes ownership of new T[]
@@ -365,6 +366,8 @@ public:
                                                     ia ? static_cast<const void *>(data.read()) : device_data(), ia, sa.data(),
                                                     ib ? static_cast<const void *>(rhs.data.read()) : rhs.device_data(), ib, sb.data(),
                                                     sh.data(), static_cast<int>(sh.size()), out.device_data_mut()));
+                if (ia) ++data.storage()->inline_uses;
+                if (ib) ++rhs.data.storage()->inline_uses;
                 return out;
             }
             hip::element_wise_op_device<T, Op>(device_data(), br.newStrides1, rhs.device_data(), br.newStrides2,
@@ -395,6 +398,7 @@ public:
                 hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id, data.read(), host_only_small(), sa.data(),
                                                     &value, sizeof(T), zeros.data(), sh.data(), static_cast<int>(sh.size()),
                                                     out.device_data_mut()));
+                ++data.storage()->inline_uses;
                 return out;
             }
             if (is_dense()) {
@@ -562,6 +566,11 @@ private:
     std::size_t host_only_small() const {
         const auto &st = data.storage();
         if (!st || st->dev_valid || !st->host_valid || st->count <= data.offset()) return 0;
+        // Once only: an array that is used AGAIN is worth its upload -- reading the argument block costs the kernel a
+        // trip over the fabric (a launch with an inline operand takes ~4.0 us against ~2.8 us with resident ones), so
+        // the second use uploads it and every later one runs resident.  simple_check builds its array anew each time
+        // and never gets that far; BM_SMArrayPow_1D / _2D reuse theirs and do.
+        if (st->inline_uses != 0) return 0;
         const std::size_t bytes = (st->count - data.offset()) * sizeof(T);
         return bytes <= SMHIP_INLINE_MAX_BYTES ? bytes : 0;
     }

@@ -388,6 +388,7 @@ struct TileParams {
     FastDiv rest[SMHIP_MAX_NDIM - 2];
     int64_t a_r[SMHIP_MAX_NDIM - 2], b_r[SMHIP_MAX_NDIM - 2], o_r[SMHIP_MAX_NDIM - 2];
     uint32_t tiles_p, tiles_q;
+    uint32_t nt;                // streamed reads carry the non-temporal hint (the launch reads more than the Infinity Cache holds)
 };
 
 // One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
@@ -439,7 +440,9 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
         const T *g = src0 + ig * W + (int64_t)jl * s_q;
         if constexpr (VEC) {
             // two turned streams and no reuse: nt is worth 8 % there; with one it costs (tools/sweep_transpose.hip)
-            const V val = both ? load_stream(reinterpret_cast<const V *>(g)) : *reinterpret_cast<const V *>(g);
+            V val;
+            if constexpr (MA == 1 && MB == 1) val = load_stream_if(T, reinterpret_cast<const V *>(g), p.nt);  // = `both` in the vector form
+            else val = *reinterpret_cast<const V *>(g);
 #pragma unroll
             for (int k = 0; k < W; ++k) dst[k] = val[k];
         } else {
@@ -471,7 +474,7 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     auto along_q = [&](const T *src0, int64_t s_p, int64_t s_q, uint32_t il, uint32_t jg, T (&dst)[W]) {
         const T *g = src0 + (int64_t)il * s_p + (int64_t)(jg * W) * s_q;
         if (VEC && s_q == 1) {
-            const V val = load_stream(reinterpret_cast<const V *>(g));
+            const V val = load_stream_if(T, reinterpret_cast<const V *>(g), p.nt);
 #pragma unroll
             for (int k = 0; k < W; ++k) dst[k] = val[k];
         } else {

@@ -265,6 +265,14 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                 ++t.n_rest;
                 slices *= (size_t)pl.shape[d];
             }
+            {
+                size_t da = 1, db = 1;
+                for (int d = 0; d < nd; ++d) {
+                    if (pl.sa[d] != 0) da *= (size_t)pl.shape[d];
+                    if (pl.sb[d] != 0) db *= (size_t)pl.shape[d];
+                }
+                t.nt = (uint32_t)stream_reads((da + db) * (size_t)esz);
+            }
             t.tiles_p = (t.np + kTileP - 1) / kTileP;
             t.tiles_q = (t.nq + tq - 1) / tq;
             const size_t blocks = slices * t.tiles_p * t.tiles_q;

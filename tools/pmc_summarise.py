@@ -44,6 +44,9 @@ def main():
         res[wl] = {"kernel": k, "launches": len(f), "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
                    "read_bytes": read_b, "write_bytes": write_b, "hbm_bytes_per_launch": read_b + write_b,
                    "algorithmic_bytes": ALGORITHMIC[wl], "ratio_to_algorithmic": (read_b + write_b) / ALGORITHMIC[wl]}
+    import datetime
+    res["_meta"] = {"date": datetime.date.today().isoformat(), "commit": os.environ.get("SMHIP_COMMIT", "unknown"),
+                    "how": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, of `bench.py --workload W --steps 10`"}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
