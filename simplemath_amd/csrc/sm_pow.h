@@ -333,10 +333,13 @@ SM_POW_FN bool any_lane(bool v) {
 #endif
 }
 
+template <int W>
+SM_POW_FN void pow_special_n(const float (&x)[W], const float (&y)[W], float (&out)[W], const double *tab);
+
 // x^y for W independent (x, y) pairs.
 template <int W>
 SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W], const double *tab) {
-    const uint32_t ONE = 0x3f800000u, INF = 0x7f800000u, QNAN = 0x7fc00000u;
+    const uint32_t INF = 0x7f800000u;
     // Ordinary operands -- x positive, finite, non-zero; y finite, non-zero -- need none of
     // the special-case lattice.  The test is wave-uniform (one ballot), so the usual case
     // (e.g. BASELINE config 4: a in (0.01, 100), y = 2.5) runs the bare exp2/log2 chain and
@@ -357,6 +360,29 @@ SM_POW_FN void pow_n(const float (&x)[W], const float (&y)[W], float (&out)[W], 
         pow_core_n<W, false>(x, y, out, tab, eadj);
         return;
     }
+    // From here on the operands are opaque to the optimiser.  Without this, a kernel that evaluates several vectors
+    // against the SAME exponents (the row kernel: two rows, one row-constant operand) sees the exponent-only part of
+    // the lattice below as common to both evaluations and hoists it ABOVE the branch -- ~70 VALU instructions per wave
+    // executed on the ordinary path for nothing (row pow: 393 instructions per wave instead of 315,
+    // profiles/r02_pmc_sq_pow_shapes.txt).
+    float xs[W], ys[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        xs[k] = x[k];
+        ys[k] = y[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(xs[k]), "+v"(ys[k]));
+#endif
+    }
+    pow_special_n<W>(xs, ys, out, tab);
+}
+
+// The special path of pow_n: at least one lane of the wavefront holds a zero, subnormal, negative, infinite or NaN base,
+// or a zero, infinite or NaN exponent.
+template <int W>
+SM_POW_FN void pow_special_n(const float (&x)[W], const float (&y)[W], float (&out)[W], const double *tab) {
+    const uint32_t ONE = 0x3f800000u, INF = 0x7f800000u, QNAN = 0x7fc00000u, MINNORM = 0x00800000u;
+    int eadj[W];
     float axc[W], yc_f[W], core[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {

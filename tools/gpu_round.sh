@@ -28,5 +28,7 @@ timeout -k 10 200 python tools/bcast_matrix.py > $out/bcast_matrix.txt 2>&1
 timeout -k 10 200 python tools/reduce_rates.py > $out/reduce_rates.txt 2>&1
 timeout -k 10 200 python tools/misc_rates.py > $out/misc_rates.txt 2>&1
 timeout -k 10 100 python tools/pow_shapes.py > $out/pow_shapes.txt 2>&1
+bash tools/pmc_sq_pow_shapes.sh $tag > $out/pmc_sq_pow_shapes.txt 2>&1
+timeout -k 10 100 tools/bin/small_breakdown > $out/small_breakdown.txt 2>&1
 for y in 2.5 1.5 3.25; do timeout -k 10 120 simplemath_amd/bin/pow_exhaustive $y; done > $out/pow_exhaustive.txt 2>&1
 echo done
