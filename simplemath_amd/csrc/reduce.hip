@@ -208,8 +208,9 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
 // level2[g]; the last workgroup to finish -- whichever it is -- adds the level2 values in index order and writes the
 // result, so the bits are the same on every run.  Round 1 ran this as two launches (fold, then finalize: 4.7 us each
 // behind a 502 us main kernel, profiles/r01_add_sum_kernel_stats.csv).  Doing it inside the main kernel instead was
-// measured and dropped: a device-scope release per workgroup writes back the whole L2, 262 144 times (11.4 ms).
-// The arrival counter resets itself.
+// measured and dropped twice: with a device-scope release per workgroup (each writes back the whole L2: 11.4 ms), and with
+// the fence-free hand-over below per workgroup (131 072 returning atomics on ~130 counters serialise at the memory side:
+// the 157 us sum took 1079 us).  The arrival counter resets itself.
 template <typename T, bool AS_DOUBLE>
 __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>::type *__restrict__ partials, uint32_t count,
                                                         Finish<typename AccOf<T>::type> fin, void *__restrict__ out8,
