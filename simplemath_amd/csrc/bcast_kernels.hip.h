@@ -206,6 +206,7 @@ struct StridedParams {
     uint32_t inner;   // outputs per row
     FastDiv vpr;      // vector slots per row = ceil(inner / W)
     uint32_t slots;   // rows * vpr
+    uint32_t nt;      // non-temporal reads: the launch fetches more lines than the Infinity Cache holds
 };
 
 template <typename T, typename Op, int SA, int SB>
@@ -239,7 +240,7 @@ __device__ __forceinline__ void strided_row_body(const T *__restrict__ a, const 
     // belongs to the row (the row's own last slot is done element by element)
     if (e0 + W < p.inner) {
         T xa[W], xb[W], res[W];
-        auto fetch = [&](const T *base, auto stride_tag, T (&dst_regs)[W]) {
+        auto fetch = [&](const T *base, auto stride_tag, auto nt_tag, T (&dst_regs)[W]) {
             constexpr int S = decltype(stride_tag)::value;
             if constexpr (S == 0) {
                 const T v = *base;
@@ -248,13 +249,18 @@ __device__ __forceinline__ void strided_row_body(const T *__restrict__ a, const 
             } else {
                 V v[S];
 #pragma unroll
-                for (int i = 0; i < S; ++i) v[i] = load_stream(reinterpret_cast<const V *>(base + (int64_t)e0 * S) + i);
+                for (int i = 0; i < S; ++i) v[i] = load_stream_as(T, reinterpret_cast<const V *>(base + (int64_t)e0 * S) + i, decltype(nt_tag)::value);
 #pragma unroll
                 for (int k = 0; k < W; ++k) dst_regs[k] = v[(k * S) / W][(k * S) % W];
             }
         };
-        fetch(a + offA, IntTag<SA>{}, xa);
-        fetch(b + offB, IntTag<SB>{}, xb);
+        if (p.nt) {  // ONE branch around all the loads of the lane (see load_stream_as)
+            fetch(a + offA, IntTag<SA>{}, BoolTag<true>{}, xa);
+            fetch(b + offB, IntTag<SB>{}, BoolTag<true>{}, xb);
+        } else {
+            fetch(a + offA, IntTag<SA>{}, BoolTag<false>{}, xa);
+            fetch(b + offB, IntTag<SB>{}, BoolTag<false>{}, xb);
+        }
         apply_n<Op, T, W>(ctx, xa, xb, res);
         V r;
 #pragma unroll
@@ -374,6 +380,9 @@ __device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T 
 // consecutive workgroups walking q -- matched the plain add's rate; 64 x 64 was 8 % behind, p-fastest ordering
 // 15-25 %.  8-byte elements take 64 x 64: the same 512-byte output segments and the same 33 KiB of LDS per tile,
 // so four workgroups still fit a CU (64 x 128 doubles left room for two: 57 % of peak instead of 80 %).
+#ifndef SMHIP_TILE_BOTH_CHUNK
+#define SMHIP_TILE_BOTH_CHUNK 1
+#endif
 constexpr int kTileP = 64;
 template <typename T> constexpr int tile_q() { return 512 / (int)sizeof(T); }
 
@@ -435,14 +444,98 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     const T *b0 = b + offB + (int64_t)i0 * p.b_p + (int64_t)j0 * p.b_q;
     T *o0 = out + offO + (int64_t)i0 * p.o_p + j0;
 
+    constexpr int S1 = TQ * VP / 256, S2 = kTileP * VQ / 256;
+    // ---- whole patches in the vector form: every load of the lane is issued before anything is used -----------------
+    // Written slot by slot (load, use, next slot) each load sat in a basic block of its own with an s_waitcnt vmcnt(0)
+    // behind it: up to sixteen round trips to memory in a row per lane.  Here the S1 turned loads (x2 when both operands
+    // are turned) and the S2 loads of the direct operand all go out first; then LDS writes, barrier, LDS reads, Op, stores.
+    if constexpr (VEC) {
+        constexpr bool kBoth = MA == 1 && MB == 1;
+        const int64_t direct_q = MA == 1 ? p.b_q : p.a_q;
+        if (full && (kBoth || direct_q == 1)) {
+            const T *d0 = MA == 1 ? b0 : a0;  // the direct operand (unused when both are turned)
+            const int64_t d_p = MA == 1 ? p.b_p : p.a_p;
+            // Slots whose loads go out together.  One turned operand: all of them (and all of the direct operand's).  Two
+            // turned operands: SMHIP_TILE_BOTH_CHUNK slots at a time -- with all sixteen 256-byte-segment loads of a lane
+            // outstanding the two scattered streams got slower, not faster (a.T + b.T at 8192^2: 139 us with one slot at a
+            // time, 147 with two, 153 with four, 151 with all eight).
+            constexpr int CH = kBoth ? (SMHIP_TILE_BOTH_CHUNK < S1 ? SMHIP_TILE_BOTH_CHUNK : S1) : S1;
+            V va[CH], vb[kBoth ? CH : 1], vd[kBoth ? 1 : S2];
+#pragma unroll
+            for (int c = 0; c < S1; c += CH) {
+                auto issue = [&](auto nt_tag) {
+                    constexpr bool NT = decltype(nt_tag)::value;
+#pragma unroll
+                    for (int s = 0; s < CH; ++s) {
+                        const uint32_t v = threadIdx.x + 256 * (c + s), jl = v / VP, ig = v % VP;
+                        if constexpr (kBoth) {  // two turned streams and no reuse: the footprint decides the policy
+                            va[s] = load_stream_as(T, reinterpret_cast<const V *>(a0 + ig * W + (int64_t)jl * p.a_q), NT);
+                            vb[s] = load_stream_as(T, reinterpret_cast<const V *>(b0 + ig * W + (int64_t)jl * p.b_q), NT);
+                        } else if constexpr (MA == 1) {  // one turned stream: cached reads win (tools/sweep_transpose.hip)
+                            va[s] = *reinterpret_cast<const V *>(a0 + ig * W + (int64_t)jl * p.a_q);
+                        } else {
+                            va[s] = *reinterpret_cast<const V *>(b0 + ig * W + (int64_t)jl * p.b_q);
+                        }
+                    }
+                    if constexpr (!kBoth) {
+#pragma unroll
+                        for (int s = 0; s < S2; ++s) {
+                            const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
+                            vd[s] = load_stream_as(T, reinterpret_cast<const V *>(d0 + (int64_t)il * d_p + jg * W), NT);
+                        }
+                    }
+                };
+                if (p.nt) issue(BoolTag<true>{});  // ONE branch around the loads of a chunk (see load_stream_as)
+                else issue(BoolTag<false>{});
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const uint32_t v = threadIdx.x + 256 * (c + s), jl = v / VP, ig = v % VP;
+                    T x[W];
+                    if constexpr (kBoth) {
+                        T xa[W], xb[W];
+#pragma unroll
+                        for (int k = 0; k < W; ++k) { xa[k] = va[s][k]; xb[k] = vb[s][k]; }
+                        apply_n<Op, T, W>(ctx, xa, xb, x);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) x[k] = va[s][k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < W; ++k) tile[at(ig * W + k, jl)] = x[k];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < S2; ++s) {
+                const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
+                T xt[W], xr[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) xt[k] = tile[at(il, jg * W + k)];
+                if constexpr (kBoth) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) xr[k] = xt[k];
+                } else {
+                    T xd[W];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) xd[k] = vd[s][k];
+                    if constexpr (MA == 1) apply_n<Op, T, W>(ctx, xt, xd, xr);
+                    else apply_n<Op, T, W>(ctx, xd, xt, xr);
+                }
+                V val;
+#pragma unroll
+                for (int k = 0; k < W; ++k) val[k] = xr[k];
+                store_stream(reinterpret_cast<V *>(o0 + (int64_t)il * p.o_p + jg * W), val);
+            }
+            return;
+        }
+    }
+
+    // ---- edge patches, a direct operand that is not dense along q, and the element form: slot by slot, guarded -------
     // phase 1: LDS-mode operands, coalesced along p (slot ig covers i = ig*W .. +W-1 of row jl)
     auto along_p = [&](const T *src0, int64_t s_q, uint32_t jl, uint32_t ig, T (&dst)[W]) {
         const T *g = src0 + ig * W + (int64_t)jl * s_q;
         if constexpr (VEC) {
-            // two turned streams and no reuse: nt is worth 8 % there; with one it costs (tools/sweep_transpose.hip)
-            V val;
-            if constexpr (MA == 1 && MB == 1) val = load_stream_if(T, reinterpret_cast<const V *>(g), p.nt);  // = `both` in the vector form
-            else val = *reinterpret_cast<const V *>(g);
+            const V val = *reinterpret_cast<const V *>(g);
 #pragma unroll
             for (int k = 0; k < W; ++k) dst[k] = val[k];
         } else {
@@ -450,7 +543,7 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
         }
     };
 #pragma unroll
-    for (int s = 0; s < TQ * VP / 256; ++s) {
+    for (int s = 0; s < S1; ++s) {
         const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
         if (full || (i0 + ig * W < p.np && j0 + jl < p.nq)) {
             T x[W];
@@ -483,7 +576,7 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
         }
     };
 #pragma unroll
-    for (int s = 0; s < kTileP * VQ / 256; ++s) {
+    for (int s = 0; s < S2; ++s) {
         const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
         if (full || (i0 + il < p.np && j0 + jg * W < p.nq)) {
             T xt[W], xr[W];

@@ -46,6 +46,10 @@
 
 #include "bcast_plan.h"
 
+#ifndef SMHIP_HEAVY_ROWS
+#define SMHIP_HEAVY_ROWS 2
+#endif
+
 namespace smhip {
 namespace {
 
@@ -167,8 +171,8 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
         // no streamed read at all (a per-row scalar against a row-constant: an outer product) is a pure write stream: one
         // row per lane, like the fill kernel (83 % of peak against 78 % with two)
         const bool write_only = (ia == 0 && L->cb) || (ib == 0 && L->ca);
-        (void)heavy;  // float pow took one row per lane in round 1; with the lighter core two loads in flight per lane win there too
-        L->rows = (three_streams || write_only) ? 1 : 2;
+        // float / double pow: SMHIP_HEAVY_ROWS rows per lane (round 1: one; two loads in flight per lane win there too)
+        L->rows = (three_streams || write_only) ? 1 : (heavy ? SMHIP_HEAVY_ROWS : 2);
         const int ty = 256 / L->tx;
         const size_t gx = (p.vpr + L->tx - 1) / L->tx;
         const size_t gy = ((size_t)p.rows + ty * L->rows - 1) / (ty * L->rows);
@@ -307,6 +311,16 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             }
             p.vpr = FastDiv((uint32_t)vpr);
             p.slots = (uint32_t)(rows * vpr);
+            {   // lines fetched: a strided operand touches `stride` times its elements
+                size_t da = 1, db = 1;
+                for (int d = 0; d < nd - 1; ++d) {
+                    if (pl.sa[d] != 0) da *= (size_t)pl.shape[d];
+                    if (pl.sb[d] != 0) db *= (size_t)pl.shape[d];
+                }
+                da *= ia == 0 ? 1 : (size_t)inner * (size_t)ia;
+                db *= ib == 0 ? 1 : (size_t)inner * (size_t)ib;
+                p.nt = (uint32_t)stream_reads((da + db) * (size_t)esz);
+            }
             L->kind = Launch::kStrided;
             L->ia = (int)ia;
             L->ib = (int)ib;
@@ -349,7 +363,7 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
     const dim3 grid(L.grid), block(256);
     switch (L.kind) {
         case Launch::kRow: {
-            constexpr int kRows = 2;  // what plan_launch gives non-three-stream forms
+            constexpr int kRows = (std::is_same<Op, PowOp<T>>::value && std::is_floating_point<T>::value) ? SMHIP_HEAVY_ROWS : 2;  // what plan_launch gives non-three-stream forms
             bool launched = false;
             auto go_tx = [&](auto ia_t, auto ib_t, auto ca_t, auto cb_t, auto rows_t) {
                 constexpr int IA = decltype(ia_t)::value, IB = decltype(ib_t)::value, ROWS = decltype(rows_t)::value;
@@ -477,7 +491,7 @@ int run_repeat(const void *src, void *out, size_t n_src, uint32_t r, hipStream_t
 // read up to S - 1 elements past the last one the view owns).
 template <typename T, int S>
 __global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__ src, T *__restrict__ out, int64_t pitch, uint32_t inner,
-                                                           FastDiv vpr, uint32_t slots) {
+                                                           FastDiv vpr, uint32_t slots, int nt) {
     constexpr int W = VecTraits<T>::width;
     typedef typename VecTraits<T>::vec_t V;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
@@ -489,8 +503,13 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__
     T *d = out + (size_t)row * inner + e0;
     if (e0 + W < inner) {  // strictly inside the row: the over-read stays inside it too
         V v[S];
+        if (nt) {  // one branch around the S loads (see load_stream_as)
 #pragma unroll
-        for (int i = 0; i < S; ++i) v[i] = load_stream(reinterpret_cast<const V *>(s) + i);
+            for (int i = 0; i < S; ++i) v[i] = load_stream_as(T, reinterpret_cast<const V *>(s) + i, true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; ++i) v[i] = load_stream_as(T, reinterpret_cast<const V *>(s) + i, false);
+        }
         V r;
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = v[(k * S) / W][(k * S) % W];
@@ -508,10 +527,11 @@ int run_deinterleave(const void *src, void *out, size_t rows, uint32_t inner, in
     const T *a = static_cast<const T *>(src);
     T *o = static_cast<T *>(out);
     const FastDiv vpr((uint32_t)per_row);
+    const int nt = stream_reads(rows * (size_t)inner * (size_t)stride * sizeof(T));  // the lines it fetches
     switch (stride) {
-        case 2: hipLaunchKernelGGL((deinterleave_kernel<T, 2>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots); break;
-        case 3: hipLaunchKernelGGL((deinterleave_kernel<T, 3>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots); break;
-        default: hipLaunchKernelGGL((deinterleave_kernel<T, 4>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots); break;
+        case 2: hipLaunchKernelGGL((deinterleave_kernel<T, 2>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots, nt); break;
+        case 3: hipLaunchKernelGGL((deinterleave_kernel<T, 3>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots, nt); break;
+        default: hipLaunchKernelGGL((deinterleave_kernel<T, 4>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots, nt); break;
     }
     SMHIP_LAUNCH_CHECK("deinterleave_kernel");
     return SMHIP_OK;
@@ -524,7 +544,7 @@ int run_deinterleave(const void *src, void *out, size_t rows, uint32_t inner, in
 // the generic gather and a first version of this kernel read y with per-lane scalar loads and sat at 67 % of peak.
 template <typename T, typename Op, bool SWAPPED>
 __global__ __launch_bounds__(256) void short_rows_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out, FastDiv r,
-                                                         uint32_t n_vec, uint32_t n) {
+                                                         uint32_t n_vec, uint32_t n, int nt) {
     constexpr int W = VecTraits<T>::width;
     typedef typename VecTraits<T>::vec_t V;
     __shared__ T ylds[256 * W / 2 + 2];
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(256) void short_rows_kernel(const T *__restrict__ x
     if (last >= n) last = n - 1;
     const uint32_t q_last = r.div(last) + 1;
     V xv;
-    if (v < n_vec) xv = load_stream(reinterpret_cast<const V *>(x + (size_t)v * W));
+    if (v < n_vec) xv = load_stream_if(T, reinterpret_cast<const V *>(x + (size_t)v * W), nt);
     for (uint32_t i = threadIdx.x; q0 + i < q_last; i += 256) ylds[i] = y[q0 + i];
     __syncthreads();
     if (v > n_vec) return;
@@ -568,8 +588,9 @@ int run_short_rows(const void *x, const void *y, void *out, size_t rows, uint32_
     const size_t n = rows * r;
     const uint32_t n_vec = (uint32_t)(n / W);
     const dim3 grid((unsigned)(((size_t)n_vec + 1 + 255) / 256)), block(256);
-    if (swapped) hipLaunchKernelGGL((short_rows_kernel<T, Op, true>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n);
-    else hipLaunchKernelGGL((short_rows_kernel<T, Op, false>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n);
+    const int nt = stream_reads((n + rows) * sizeof(T));
+    if (swapped) hipLaunchKernelGGL((short_rows_kernel<T, Op, true>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n, nt);
+    else hipLaunchKernelGGL((short_rows_kernel<T, Op, false>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n, nt);
     SMHIP_LAUNCH_CHECK("short_rows_kernel");
     return SMHIP_OK;
 }
@@ -587,6 +608,7 @@ struct CopyParams {
     uint32_t inner;
     FastDiv slots_per_row;
     uint32_t slots;  // rows * slots_per_row
+    uint32_t nt;     // non-temporal reads: the copy reads more than the Infinity Cache holds
 };
 
 template <typename T, bool VEC>
@@ -613,7 +635,7 @@ __global__ __launch_bounds__(256) void strided_copy_kernel(const T *__restrict__
     const uint32_t e0 = col * W;
     if constexpr (VEC) {
         if (e0 + W <= p.inner) {
-            *reinterpret_cast<V *>(dst + offD + e0) = load_stream(reinterpret_cast<const V *>(src + offS + e0));
+            *reinterpret_cast<V *>(dst + offD + e0) = load_stream_if(T, reinterpret_cast<const V *>(src + offS + e0), p.nt);
         } else {
             for (uint32_t e = e0; e < p.inner; ++e) dst[offD + e] = src[offS + e];
         }
@@ -644,6 +666,7 @@ int run_copy_strided(const void *src_, void *dst_, const Plan &pl, hipStream_t s
     const size_t slots = pl.n / (size_t)p.inner * per_row;
     p.slots_per_row = FastDiv((uint32_t)per_row);
     p.slots = (uint32_t)slots;
+    p.nt = (uint32_t)stream_reads(2 * pl.n * sizeof(T));  // its stores are plain (partial lines want the L2's write combining): they occupy the cache too
     const unsigned grid = (unsigned)((slots + 255) / 256);
     if (vec) hipLaunchKernelGGL((strided_copy_kernel<T, true>), dim3(grid), dim3(256), 0, s, src, dst, p);
     else hipLaunchKernelGGL((strided_copy_kernel<T, false>), dim3(grid), dim3(256), 0, s, src, dst, p);

@@ -189,6 +189,9 @@ template <typename T> struct VecTraits;
 SMHIP_VEC(float, 4) SMHIP_VEC(int32_t, 4) SMHIP_VEC(double, 2) SMHIP_VEC(int64_t, 2)
 #define load_stream(ptr) __builtin_nontemporal_load(ptr)
 #define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
+#define load_stream_as(T, ptr, NT) ({ typedef VecTraits<T> smhip_tr_; const typename smhip_tr_::vec_t *smhip_p_ = (ptr); typename smhip_tr_::full_t smhip_v_; \
+    if constexpr (NT) { smhip_v_ = __builtin_nontemporal_load(smhip_p_); } else { const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
+    const typename smhip_tr_::half_full_t smhip_lo_ = smhip_h_[0], smhip_hi_ = smhip_h_[1]; smhip_v_ = smhip_tr_::join(smhip_lo_, smhip_hi_); } smhip_v_; })
 #define load_stream_if(T, ptr, nt) ({ typedef VecTraits<T> smhip_tr_; const typename smhip_tr_::vec_t *smhip_p_ = (ptr); typename smhip_tr_::full_t smhip_v_; \
     if (nt) { smhip_v_ = __builtin_nontemporal_load(smhip_p_); } else { const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
     const typename smhip_tr_::half_full_t smhip_lo_ = smhip_h_[0], smhip_hi_ = smhip_h_[1]; smhip_v_ = smhip_tr_::join(smhip_lo_, smhip_hi_); } smhip_v_; })

@@ -66,6 +66,23 @@ SMHIP_VEC(int64_t, 2)
 // with different metadata to the optimiser, which merges them and drops the hint; two halves are a different
 // instruction sequence until the load/store vectoriser (which runs after the CFG clean-ups) joins them back into one
 // global_load_dwordx4 -- so the ISA has exactly `global_load_dwordx4 ... nt` in one arm and `global_load_dwordx4` in the other.
+// load_stream_as(T, ptr, NT): the same two forms with a COMPILE-TIME choice -- for a lane that issues several loads, branch
+// once around the whole group (`if (nt) { ...as(.., true) } else { ...as(.., false) }`): with one branch per load the
+// compiler parks an s_waitcnt vmcnt(0) at every join and the loads go out one at a time (strided rows: 111 -> 134 us).
+#define load_stream_as(T, ptr, NT)                                                                 \
+    ({                                                                                             \
+        typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
+        const typename smhip_tr_::vec_t *smhip_p_ = (ptr);                                         \
+        typename smhip_tr_::full_t smhip_v_;                                                       \
+        if constexpr (NT) {                                                                        \
+            smhip_v_ = __builtin_nontemporal_load(smhip_p_);                                       \
+        } else {                                                                                   \
+            const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
+            const typename smhip_tr_::half_full_t smhip_lo_ = smhip_h_[0], smhip_hi_ = smhip_h_[1]; \
+            smhip_v_ = smhip_tr_::join(smhip_lo_, smhip_hi_);                                      \
+        }                                                                                          \
+        smhip_v_;                                                                                  \
+    })
 #define load_stream_if(T, ptr, nt)                                                                 \
     ({                                                                                             \
         typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
