@@ -24,7 +24,8 @@
 // Subnormal x (no implicit bit to strip) and everything else out of the ordinary go through the special path, which
 // pre-scales by 2^24 and carries -24 into e.
 // Cost per element on gfx950: 12 fp64-rate VALU ops (2 cvt in, fma, add, 4 fma, mul, rint, sub, cvt out), 1 cvt_i32,
-// 6 integer ops, 1 ds_read_b128, 3 packed-f32 + 1 ldexp (+ a clamp) -- 27 against round 1's 45 (profiles/r02_pmc_sq_pow.txt).
+// 6 integer ops, 1 ds_read_b128, 3 packed-f32 + 1 ldexp (+ a clamp) -- 27, 30 with addressing and the special-case test, against round 1's 45
+// (profiles/r02_pmc_sq_cycles.txt: 3.19e7 VALU wave-instructions per 2^26-element launch, r01: 4.76e7).
 // No MFMA: there is no contraction.  W elements are evaluated side by side (pow_n<W>), polynomial constants come
 // from constant memory into SGPRs, and the special-case lattice is skipped wave-uniformly when no lane needs it.  The
 // lattice is C99 F.9.4.4 / IEEE 754-2008 9.2.1 as glibc implements it (x^0 = 1 and 1^y = 1 even for quiet NaN, not
