@@ -362,8 +362,11 @@ def run_rank(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # SMHIP_BENCH_FORCE_DIST=1: take the multi-rank code path (torch.distributed, libsmhip's communicator, the config-5
+    # leg) even with ONE rank -- how the one-GPU test box exercises it through the real RCCL calls.
+    dist_on = world > 1 or os.environ.get("SMHIP_BENCH_FORCE_DIST") == "1"
     dist = torch = None
-    if world > 1:
+    if dist_on:
         # torch first: libsmhip then binds to the HIP runtime and the RCCL torch already loaded (same sonames)
         import torch
         import torch.distributed as dist
@@ -384,13 +387,30 @@ def run_rank(args):
     lib = sma.load()  # raises if the HIP library is missing: no CPU fallback
     lib.set_device(local_rank)
 
-    use_lib_comm = world > 1 and args.dist_backend == "nccl"
+    use_lib_comm = dist_on and args.dist_backend == "nccl"
+    comm_error = None
     if use_lib_comm:
-        # libsmhip's own communicator for config 5's all-reduce: the unique id travels over torch.distributed
+        # libsmhip's own communicator for config 5's all-reduce: the unique id travels over torch.distributed.  A failure
+        # here must not cost the headline measurement: every rank learns whether ALL ranks have a communicator, and if
+        # not the config-5 leg says so and exchanges its scalar through torch.distributed instead.
         with _StdoutToStderr():
-            box = [lib.comm_unique_id() if rank == 0 else None]
+            try:
+                box = [lib.comm_unique_id() if rank == 0 else None]
+            except sma.SmhipError as e:
+                box, comm_error = [None], str(e)
             dist.broadcast_object_list(box, src=0)
-            lib.comm_init_rank(world, rank, box[0])
+            if box[0] is None:
+                comm_error = comm_error or "rank 0 could not create a communicator id"
+            else:
+                try:
+                    lib.comm_init_rank(world, rank, box[0])
+                except sma.SmhipError as e:
+                    comm_error = str(e)
+        flag = torch.tensor([1 if comm_error else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag[0]):
+            use_lib_comm = False
+            comm_error = comm_error or "another rank could not create its communicator"
 
     def barrier():
         lib.synchronize()
@@ -456,7 +476,7 @@ def run_rank(args):
 
     # config 5's exchange step: fused add+sum per shard, then ONE all-reduce of the fp64 scalar
     c5 = None
-    if wl == "add" and world > 1:
+    if wl == "add" and dist_on:
         n, log2n = info["n"], info["log2n"]
         del keep, step  # the headline operands go back to the pool; config 5 has its own (seeds 6/7 in [0,1))
         a5 = lib.uniform_f32(n, 6, 0.0, 1.0, first=rank * n)
@@ -469,7 +489,8 @@ def run_rank(args):
             if use_lib_comm:
                 lib.allreduce_sum_async(np.float64, part, 1)  # RCCL from libsmhip, same stream: 8 bytes per rank
                 return None
-            host = torch.tensor([lib.read_f64(part)], dtype=torch.float64)  # gloo rehearsal: the exchange runs on the host
+            # no libsmhip communicator (gloo rehearsal, or its creation failed): the scalar goes through torch.distributed
+            host = torch.tensor([lib.read_f64(part)], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(host)
             return float(host[0])
 
@@ -486,7 +507,12 @@ def run_rank(args):
             total = lib.read_f64(part)
         tt = torch.tensor([tc], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        backend = "libsmhip -> ncclAllReduce (RCCL over xGMI), on the kernel's stream" if use_lib_comm else "gloo on the host (rehearsal, not RCCL)"
+        if use_lib_comm:
+            backend = "libsmhip -> ncclAllReduce (RCCL over xGMI), on the kernel's stream"
+        elif args.dist_backend == "gloo":
+            backend = "gloo on the host (rehearsal, not RCCL)"
+        else:
+            backend = f"torch.distributed nccl after a host read-back -- libsmhip's communicator was not available: {comm_error}"
         c5 = {"workload": f"fused add+sum over {world} x 2^{log2n} f32 (uniform[0,1), seeds 6/7) + one all-reduce of 1 x fp64",
               "allreduce": backend, "ms_per_step": float(tt[0]) * 1e3, "value": world * n / float(tt[0]) / 1e9, "unit": "Gelem/s",
               "global_sum": total, "expected_sum_approx": float(world) * n}

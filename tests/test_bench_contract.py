@@ -110,3 +110,21 @@ def test_single_process_mode_through_rccl():
     n = 1 << 24
     c5 = d["c5"]
     assert abs(c5["global_sum"] - n) < 6 * (n / 6.0) ** 0.5 and "ncclAllReduce" in c5["allreduce"]
+
+
+@pytest.mark.gpu
+def test_rank_mode_through_rccl_with_one_rank():
+    """The code path the driver's N > 1 runs take -- torch.distributed (nccl) for the barrier, libsmhip's own communicator
+    (ncclGetUniqueId / ncclCommInitRank) and ncclAllReduce for config 5's scalar -- with ONE rank under the launcher."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SMHIP_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--log2n", "24", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # ONE JSON line on stdout (RCCL's banner goes to stderr)
+    d = json.loads(lines[0])
+    n = 1 << 24
+    c5 = d["c5"]
+    assert "libsmhip -> ncclAllReduce" in c5["allreduce"], c5
+    assert abs(c5["global_sum"] - n) < 6 * (n / 6.0) ** 0.5 and c5["value"] > 0
