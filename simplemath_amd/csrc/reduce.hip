@@ -27,7 +27,8 @@ namespace {
 
 using namespace dev;
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;  // also for the fused op+sum, although it is a 2R+1W stream like the add (whose kernel takes 1024): 507 us with
+                             // 256-thread workgroups, 510 with 512, 514 with 1024 (round 2)
 // 16-byte vectors per lane and operand (tools/reduce_rates.py, profiles/r01_reduce_rates.txt).  Read-only streams want
 // more loads in flight than the 2R+1W streams do: a plain sum runs at 86 % of peak with two vectors per lane (65-69 %
 // with one, 82-84 % with four or eight), a dot at 84 % with two per operand (79 % with one).  The fused op+sum writes as
