@@ -81,8 +81,12 @@ def test_no_cpu_fallback(lib):
     """Without a HIP device the product fails loudly (never routes to the oracle)."""
     if _has_gpu(lib):
         pytest.skip("a GPU is present")
+    host = np.ones(4, dtype=np.float32)
     for call in (lambda: lib.alloc(1024),
                  lambda: lib.elementwise_raw(sma.OP_ADD, np.float32, 16, [1], 16, [1], [4], 16),
+                 lambda: lib.binary_inline(sma.OP_ADD, host, host),   # operands in HOST memory: still no host arithmetic
+                 lambda: lib.set_devices(1),
+                 lambda: lib.comm_init_rank(1, 0, bytes(128)),
                  lambda: lib.synchronize()):
         with pytest.raises(sma.SmhipError) as e:
             call()
