@@ -314,7 +314,7 @@ using namespace smhip;
 
 extern "C" {
 
-const char *smhip_version(void) { return "smhip 0.1 (gfx950)"; }
+const char *smhip_version(void) { return "smhip 0.2 (gfx950)"; }
 const char *smhip_last_error(void) { return tls.error.c_str(); }
 
 int smhip_device_count(int *count) {

@@ -1143,3 +1143,39 @@ def test_inner_strided_operands_take_wide_loads(smhip, oracle):
     da, db = smhip.to_device(a), smhip.to_device(b)
     got = smhip.binary(op, da.view_like(a[:, ::2], a), db.view_like(b[:, 1::2], b)).numpy()
     assert np.array_equal(got, a[:, ::2] * b[:, 1::2] + a[:, ::2])
+
+
+def test_large_view_shapes_vs_numpy(smhip):
+    """Views big enough for whole 64 x 128 LDS patches, long strided rows and multi-row lanes (tests/fuzz_views.py keeps its
+    extents under 140): random 2-D / 3-D bases with extents up to ~1500, transposed / permuted / stepped / offset views of
+    them, + and * in f32, f64 and i32, bit-exact against numpy (one correctly rounded operation per element)."""
+    rng = np.random.default_rng(2024)
+    for t in range(48):
+        dtn = ("f32", "f64", "i32")[t % 3]
+        dt = DT[dtn]
+        nd = 2 if t % 4 else 3
+        dims = [int(rng.integers(130, 1500)), int(rng.integers(130, 1500))] if nd == 2 else [int(rng.integers(2, 9)), int(rng.integers(70, 400)), int(rng.integers(130, 700))]
+        a = gen.gen(dt, int(np.prod(dims)), 300 + t, "uniform").reshape(dims)
+        b = gen.gen(dt, int(np.prod(dims)), 400 + t, "uniform").reshape(dims)
+
+        step = int(rng.integers(2, 5))
+
+        def view(x, kind):
+            if kind == 0:
+                return x
+            if kind == 1:
+                return np.transpose(x, list(range(x.ndim - 2)) + [x.ndim - 1, x.ndim - 2])
+            if kind == 2:
+                return x[..., ::step]
+            if kind == 3:
+                return x[..., 1:-1, 3:-2]
+            return np.transpose(x)  # full reversal of the axes
+
+        ka, kb = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        va, vb = view(a, ka), view(b, kb)
+        if va.shape != vb.shape:  # make them broadcast-compatible: bring b to a's shape through a's own kind on b
+            vb = view(b, ka)
+        da, db = smhip.to_device(a), smhip.to_device(b)
+        for opn, f in (("add", np.add), ("mul", np.multiply)):
+            got = smhip.binary(sma.OPS[opn], da.view_like(va, a), db.view_like(vb, b)).numpy()
+            assert np.array_equal(got, f(va, vb)), (t, dtn, opn, dims, ka, kb)
