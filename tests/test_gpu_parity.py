@@ -1179,3 +1179,35 @@ def test_large_view_shapes_vs_numpy(smhip):
         for opn, f in (("add", np.add), ("mul", np.multiply)):
             got = smhip.binary(sma.OPS[opn], da.view_like(va, a), db.view_like(vb, b)).numpy()
             assert np.array_equal(got, f(va, vb)), (t, dtn, opn, dims, ka, kb)
+
+
+def test_user_ops_first_used_from_many_threads(smhip, tmp_path, monkeypatch):
+    """hipRTC builds run with the cache mutex released: threads that need the SAME new kernel wait for one build, threads
+    that need different ones compile side by side -- and every thread gets the right kernel."""
+    import threading
+    exprs = ["a * b + (T)%d" % k for k in range(101, 104)]   # fresh expressions: nothing cached in this process
+    ids = [smhip.register_op(e) for e in exprs]
+    n = 100003
+    a = gen.gen(np.float32, n, 1, "uniform"); b = gen.gen(np.float32, n, 2, "uniform")
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                got = smhip.contiguous(ids[k % 3], da, db).numpy()
+                want = a * b + np.float32(101 + k % 3)
+                if not np.array_equal(got, want):
+                    errors.append((k, rep, "values"))
+                v = smhip.binary(ids[k % 3], da.view_like(a[: n - 3].reshape(-1, 100)[:, ::2], a), db.view_like(b[: n - 3].reshape(-1, 100)[:, 1::2], b)).numpy()
+                if not np.array_equal(v, a[: n - 3].reshape(-1, 100)[:, ::2] * b[: n - 3].reshape(-1, 100)[:, 1::2] + np.float32(101 + k % 3)):
+                    errors.append((k, rep, "broadcast values"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(9)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
