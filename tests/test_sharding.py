@@ -61,9 +61,15 @@ def _worker(rank, world, port, tmpdir):
         r = gen.gen(np.float32, cols, 2, "uniform").reshape(1, cols)
         shape, sa, sb, _ = o.broadcast(A.shape, [cols, 1], r.shape, [cols, 1])
         sh = sharding.shard_outer(shape, sa, sb, world, rank)
-        a_sh = A.reshape(-1)[sh.offset_a:]
-        b_sh = r.reshape(-1)[sh.offset_b:]
-        part = o.elementwise(orc.MUL, a_sh, sa, b_sh, sb, list(sh.shape)) if sh.size else np.empty(0, np.float32)
+        # the planner the product uses (libsmhip's smhip_shard_outer: host-only code, so it runs here without a GPU) must
+        # cut the same block; the shard below is taken from ITS answer
+        import simplemath_amd as sma
+        c_shape, c_off_a, c_off_b, c_off_out, c_rep_a, c_rep_b = sma.load().shard_outer(shape, sa, sb, world, rank)
+        if (c_shape, c_off_a, c_off_b, c_off_out, c_rep_a, c_rep_b) != (sh.shape, sh.offset_a, sh.offset_b, sh.offset_out, sh.replicated_a, sh.replicated_b):
+            fails.append("C planner and Python planner disagree")
+        a_sh = A.reshape(-1)[c_off_a:]
+        b_sh = r.reshape(-1)[c_off_b:]
+        part = o.elementwise(orc.MUL, a_sh, sa, b_sh, sb, list(c_shape)) if sh.size else np.empty(0, np.float32)
         np.save(os.path.join(tmpdir, f"part{rank}.npy"), part)
         dist.barrier()
         if rank == 0:
@@ -73,7 +79,9 @@ def _worker(rank, world, port, tmpdir):
 
         # (2) config 5 in miniature: fused add + sum per shard, ONE all-reduce of the fp64 scalar
         n = 100003
-        first, count = sharding.split_range(n, world, rank)
+        first, count = sma.load().split_range(n, world, rank)  # smhip_split_range
+        if (first, count) != sharding.split_range(n, world, rank):
+            fails.append("C and Python split_range disagree")
         a = o.uniform_f32(count, 6, 0.0, 1.0, first=first)   # each rank generates ITS slice of the global stream
         b = o.uniform_f32(count, 7, 0.0, 1.0, first=first)
         _, partial = o.contiguous_sum(orc.ADD, a, b)
