@@ -171,6 +171,8 @@ int smhip_sum(int dtype, const void *a, size_t n, double *out_host);
  * caller can all-reduce it (RCCL) without a host round trip. */
 int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev);
 int smhip_dot_async(int dtype, const void *a, const void *b, size_t n, double *out_dev);
+/* smhip_dot_c64 leaving {re, im} in device memory (out2_dev: 2 doubles). */
+int smhip_dot_c64_async(const void *a, const void *b, size_t n, double *out2_dev);
 /* Fused out = a op b and *sum_dev = sum(out) in one pass (config 5: 12 B/elem). */
 int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, void *out, size_t n,
                                double *sum_dev);

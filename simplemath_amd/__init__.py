@@ -347,6 +347,9 @@ class Smhip:
         self._ck(self.c.smhip_dot_async(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),
                                         C.c_void_p(out_ptr)))
 
+    def dot_c64_async(self, a_ptr, b_ptr, n, out2_ptr):
+        self._ck(self.c.smhip_dot_c64_async(C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_size_t(n), C.c_void_p(out2_ptr)))
+
     def contiguous_sum_async(self, op, a: DeviceArray, b: DeviceArray, out: DeviceArray, sum_ptr):
         self._ck(self.c.smhip_contiguous_sum_async(C.c_int(op), C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
                                                    C.c_void_p(out.ptr), C.c_size_t(a.size), C.c_void_p(sum_ptr)))

@@ -142,8 +142,10 @@ int reduce_counters(hipStream_t s, uint32_t **out);
 // What the finishing launch of a multi-workgroup reduction needs (finish_kernel).
 template <typename A> struct Finish {
     A *level2;           // one total per group
-    uint32_t *counters;  // the arrival counter, zero between launches
+    uint32_t *counters;  // the arrival counter(s), zero between launches
     uint32_t gsize, groups;
+    uint32_t pitch;      // blockIdx.y = plane (complex dot: real, imaginary): plane y's partials, group totals and result
+                         // slot lie y * pitch accumulators / y counters / y doubles behind plane 0's
 };
 constexpr uint32_t kMaxGroups = 1024, kGroupTarget = 1024;
 
@@ -217,6 +219,10 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
                                                         Finish<typename AccOf<T>::type> fin, void *__restrict__ out8,
                                                         T *__restrict__ out_native) {
     typedef typename AccOf<T>::type A;
+    partials += (size_t)blockIdx.y * fin.pitch;
+    fin.level2 += (size_t)blockIdx.y * fin.pitch;
+    fin.counters += blockIdx.y;
+    if (out8) out8 = static_cast<double *>(out8) + blockIdx.y;
     const uint32_t first = blockIdx.x * fin.gsize;
     const uint32_t members = first + fin.gsize <= count ? fin.gsize : count - first;
     A acc = A(0);
@@ -257,7 +263,7 @@ inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<
 // the real and imaginary sums, grid-stride, then the same wave / LDS / partials tree.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a, const dbl2 *__restrict__ b, size_t n,
-                                                      double *__restrict__ partials, size_t blocks) {
+                                                      double *__restrict__ partials, size_t blocks, int nt) {
     // one-shot like reduce_kernel: a workgroup owns kBlock * 2 consecutive elements, two per lane and operand in flight;
     // its partial sums go to partials[block] (real) and partials[blocks + block] (imaginary; `blocks` = the arrays' pitch)
     double re = 0.0, im = 0.0;
@@ -269,7 +275,15 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
     };
     const size_t i0 = (size_t)blockIdx.x * (kBlock * 2) + threadIdx.x, i1 = i0 + kBlock;
     if (i1 < n) {
-        const dbl2 x0 = load_stream(a + i0), y0 = load_stream(b + i0), x1 = load_stream(a + i1), y1 = load_stream(b + i1);
+        typedef const VecTraits<double>::vec_t *vp;
+        dbl2 x0, y0, x1, y1;
+        if (nt) {  // one branch around the group (ops.hip.h)
+            x0 = load_stream_as(double, (vp)(a + i0), true), y0 = load_stream_as(double, (vp)(b + i0), true);
+            x1 = load_stream_as(double, (vp)(a + i1), true), y1 = load_stream_as(double, (vp)(b + i1), true);
+        } else {
+            x0 = load_stream_as(double, (vp)(a + i0), false), y0 = load_stream_as(double, (vp)(b + i0), false);
+            x1 = load_stream_as(double, (vp)(a + i1), false), y1 = load_stream_as(double, (vp)(b + i1), false);
+        }
         acc(x0, y0);
         acc(x1, y1);
     } else if (i0 < n) {
@@ -291,16 +305,17 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
 // Queues finish_kernel over `blocks` partials (blocks >= 1); `partials` has room for the group totals behind them
 // (blocks / kGroupTarget + 2 more accumulators are enough).
 template <typename T, bool AS_DOUBLE>
-int launch_finish(typename AccOf<T>::type *partials, size_t blocks, void *out8, T *out_native, hipStream_t s) {
+int launch_finish(typename AccOf<T>::type *partials, size_t blocks, void *out8, T *out_native, hipStream_t s, uint32_t planes = 1,
+                  size_t pitch = 0) {
     typedef typename AccOf<T>::type A;
     uint32_t groups = (uint32_t)((blocks + kGroupTarget - 1) / kGroupTarget);
     if (groups > kMaxGroups) groups = kMaxGroups;
     const uint32_t gsize = (uint32_t)((blocks + groups - 1) / groups);
     groups = (uint32_t)((blocks + gsize - 1) / gsize);
-    Finish<A> fin{partials + blocks, nullptr, gsize, groups};
+    Finish<A> fin{partials + blocks, nullptr, gsize, groups, (uint32_t)pitch};
     if (groups > 1)
         if (int rc = reduce_counters(s, &fin.counters)) return rc;
-    hipLaunchKernelGGL((finish_kernel<T, AS_DOUBLE>), dim3(groups), dim3(kBlock), 0, s, partials, (uint32_t)blocks, fin, out8, out_native);
+    hipLaunchKernelGGL((finish_kernel<T, AS_DOUBLE>), dim3(groups, planes), dim3(kBlock), 0, s, partials, (uint32_t)blocks, fin, out8, out_native);
     SMHIP_LAUNCH_CHECK("reduce finish");
     return SMHIP_OK;
 }
@@ -376,10 +391,11 @@ int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStr
     double *scratch;
     ScratchLease lease;
     if (int rc = lease.take(2 * span, &scratch)) return rc;
-    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, span);
+    hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, span,
+                       stream_reads(2 * n * sizeof(dbl2)));
     SMHIP_LAUNCH_CHECK("cdot");
-    if (int rc = launch_finish<double, true>(scratch, blocks, out2_dev, static_cast<double *>(nullptr), s)) return rc;
-    return launch_finish<double, true>(scratch + span, blocks, out2_dev + 1, static_cast<double *>(nullptr), s);
+    // one finishing launch for both sums (plane 0: real -> out2_dev[0], plane 1: imaginary -> out2_dev[1])
+    return launch_finish<double, true>(scratch, blocks, out2_dev, static_cast<double *>(nullptr), s, 2, span);
 }
 
 int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev, hipStream_t s) {

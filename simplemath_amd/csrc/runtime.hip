@@ -821,14 +821,18 @@ int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host)
     return rc;
 }
 
-int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host) {
-    if (!out2_host || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot_c64: null buffer");
+int smhip_dot_c64_async(const void *a, const void *b, size_t n, double *out2_dev) {
+    if (!out2_dev || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot_c64: null buffer");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u) return fail(SMHIP_ERR_INVALID, "dot_c64: operands must be 16-byte aligned");
+    SMHIP_ACQUIRE(s);
+    return launch_cdot(a, b, n, out2_dev, s);
+}
+
+int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host) {
+    if (!out2_host) return fail(SMHIP_ERR_INVALID, "dot_c64: null buffer");
     void *d = nullptr;
     if (int rc = smhip_alloc(&d, 16)) return rc;
-    hipStream_t s;
-    int rc = acquire(&s);
-    if (!rc) rc = launch_cdot(a, b, n, static_cast<double *>(d), s);
+    int rc = smhip_dot_c64_async(a, b, n, static_cast<double *>(d));
     if (!rc) rc = smhip_download(out2_host, d, 16);
     smhip_free(d);
     return rc;

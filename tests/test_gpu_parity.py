@@ -418,7 +418,7 @@ def test_fused_equals_two_passes(smhip, oracle):
 
 def test_complex_dot(smhip):
     """dot_product<std::complex<double>> (product.h:168-224): unconjugated sum a[i]*b[i]."""
-    for n in (1, 2, 3, 511, 512, 513, 1000, 100003, 1024 * 512 + 77):  # tile edges; the last needs the fold pass
+    for n in (1, 2, 3, 511, 512, 513, 1000, 100003, 1024 * 512 + 77, 3_000_001):  # tile edges; the last two finish in several groups
         ar, ai = gen.gen(np.float64, n, 61, "uniform"), gen.gen(np.float64, n, 62, "uniform")
         br, bi = gen.gen(np.float64, n, 63, "uniform"), gen.gen(np.float64, n, 64, "uniform")
         a, b = ar + 1j * ai, br + 1j * bi

@@ -24,15 +24,24 @@ for dt in (np.float32, np.float64, np.int32, np.int64):
         t = timeit(fn)
         print("%-34s %10.1f %9.0f %6.1f%%" % ("%s %s n=2^%d" % (np.dtype(dt).name, name, n.bit_length() - 1), t, byts / t * 1e-3, byts / t * 1e-3 / 80), flush=True)
     lib.free(sp); del a, b, c
-# complex<double> dot (synchronous entry point: includes the 16-byte read-back)
+# complex<double> dot: the kernels alone (async entry point), then the synchronous call with its 16-byte read-back
 import time
 n = 1 << 26
 a = lib.empty((2 * n,), np.float64); b = lib.empty((2 * n,), np.float64)
 one = np.array([1.0], dtype=np.float64)
 lib.c.smhip_fill(C.c_int(1), C.c_void_p(a.ptr), one.ctypes.data_as(C.c_void_p), C.c_size_t(2 * n))
 lib.c.smhip_fill(C.c_int(1), C.c_void_p(b.ptr), one.ctypes.data_as(C.c_void_p), C.c_size_t(2 * n))
+sp = lib.alloc(16)
+t = timeit(lambda: lib.dot_c64_async(a.ptr, b.ptr, n, sp))
+print("%-34s %10.1f %9.0f %6.1f%%" % ("complex128 dot n=2^26", t, 32.0 * n / t * 1e-3, 32.0 * n / t * 1e-3 / 80))
 for _ in range(3): lib.dot_c64(a.ptr, b.ptr, n)
 t0 = time.perf_counter()
 for _ in range(20): r = lib.dot_c64(a.ptr, b.ptr, n)
 t = (time.perf_counter() - t0) / 20 * 1e6
-print("%-34s %10.1f %9.0f %6.1f%%   (value %s)" % ("complex128 dot n=2^26", t, 32.0 * n / t * 1e-3, 32.0 * n / t * 1e-3 / 80, r))
+print("%-34s %10.1f %9.0f %6.1f%%   (value %s)" % ("  with the read-back (host clock)", t, 32.0 * n / t * 1e-3, 32.0 * n / t * 1e-3 / 80, r))
+# the same at sizes the Infinity Cache holds (plain-load policy)
+for lg in (20, 22):
+    m = 1 << lg
+    t = timeit(lambda: lib.dot_c64_async(a.ptr, b.ptr, m, sp), steps=200)
+    print("%-34s %10.1f %9.0f %6.1f%%" % ("complex128 dot n=2^%d" % lg, t, 32.0 * m / t * 1e-3, 32.0 * m / t * 1e-3 / 80))
+lib.free(sp)
