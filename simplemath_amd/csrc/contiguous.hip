@@ -115,7 +115,6 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
-    ctx.init();
     const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
     V *ov = reinterpret_cast<V *>(out);
     const size_t base = (size_t)blockIdx.x * (kTileBlock * U) + threadIdx.x;
@@ -123,18 +122,37 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
         if constexpr (KIND == 0) return apply_vec<Op, T>(ctx, xa, xb);
         else return apply_vec_scalar<Op, T, KIND == 2>(ctx, xa, s);
     };
-    if ((size_t)(blockIdx.x + 1) * (kTileBlock * U) <= n_vec) {
-        V va[U], vb[U];
+    // The Op's tables (a round trip to the L2, LDS writes and a barrier: OpCtx) are fetched first and committed after a
+    // full tile's own loads have gone out, so the two latencies overlap instead of adding up -- this one-shot form
+    // would otherwise pay the staging once per 256 x U vectors.
+    typename OpCtx<Op>::template Stage<kTileBlock> staged;
+    ctx.template fetch<kTileBlock>(staged);
+    const bool full = (size_t)(blockIdx.x + 1) * (kTileBlock * U) <= n_vec;  // uniform over the workgroup
+    V va[U], vb[U];
+    if (full) {
+        // the commit sits inside each arm of the read-policy branch, in straight-line code behind the tile's loads, so
+        // that the wait in front of its LDS writes is a counted one (vmcnt = the tile's loads still in flight); past a
+        // join the compiler falls back to vmcnt(0) and the staging would wait for the tile as well
+        if (nt) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            va[u] = load_stream_if(T, av + base + (size_t)u * kTileBlock, nt);
-            if constexpr (KIND == 0) vb[u] = load_stream_if(T, bv + base + (size_t)u * kTileBlock, nt);
-            else vb[u] = va[u];
+            for (int u = 0; u < U; ++u) {
+                va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, true);
+                if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * kTileBlock, true);
+            }
+            ctx.template commit<kTileBlock>(staged);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, false);
+                if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * kTileBlock, false);
+            }
+            ctx.template commit<kTileBlock>(staged);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) store_stream(ov + base + (size_t)u * kTileBlock, eval(va[u], vb[u]));
+        for (int u = 0; u < U; ++u) store_stream(ov + base + (size_t)u * kTileBlock, eval(va[u], KIND == 0 ? vb[u] : va[u]));
         return;
     }
+    ctx.template commit<kTileBlock>(staged);
     for (int u = 0; u < U; ++u) {
         const size_t i = base + (size_t)u * kTileBlock;
         if (i < n_vec) {
@@ -157,12 +175,23 @@ template <typename Op> struct IsHeavy : std::false_type {};
 // it for every exponent distribution tried (tools/ipow_exp.py: 80 % vs 64 % of peak for exponents < 32, 42 % vs 40 % for
 // 20-bit exponents)
 template <typename T> struct IsHeavy<PowOp<T>> : std::integral_constant<bool, std::is_floating_point<T>::value> {};
-// Vectors per lane of the one-shot tile form.  double pow (profiles/r02_op_matrix.txt): two 68-81 %, one 51-72 %.
-#ifndef SMHIP_HEAVY_F64_TILE
-#define SMHIP_HEAVY_F64_TILE 2
+// Vectors per lane of the one-shot tile form, by element type and by whether the second operand is an array (KIND 0) or
+// a scalar.  double pow, N = 2^26 with random bases (tools/pow64_rate.py, profiles/r02_pow64_rate.txt): scalar exponent
+// 207 us with two, 195 with three, 197 with four; array exponents 249 / 249 / 251.
+#ifndef SMHIP_HEAVY_F32_TILE_ARRAY
+#define SMHIP_HEAVY_F32_TILE_ARRAY 2
 #endif
-template <typename T> struct HeavyTile { static constexpr int value = 2; };
-template <> struct HeavyTile<double> { static constexpr int value = SMHIP_HEAVY_F64_TILE; };
+#ifndef SMHIP_HEAVY_F32_TILE_SCALAR
+#define SMHIP_HEAVY_F32_TILE_SCALAR 2
+#endif
+#ifndef SMHIP_HEAVY_F64_TILE_ARRAY
+#define SMHIP_HEAVY_F64_TILE_ARRAY 2
+#endif
+#ifndef SMHIP_HEAVY_F64_TILE_SCALAR
+#define SMHIP_HEAVY_F64_TILE_SCALAR 3
+#endif
+template <typename T, int KIND> struct HeavyTile { static constexpr int value = KIND == 0 ? SMHIP_HEAVY_F32_TILE_ARRAY : SMHIP_HEAVY_F32_TILE_SCALAR; };
+template <int KIND> struct HeavyTile<double, KIND> { static constexpr int value = KIND == 0 ? SMHIP_HEAVY_F64_TILE_ARRAY : SMHIP_HEAVY_F64_TILE_SCALAR; };
 
 // Launches the heavy form of `Op` (KIND 0: a op b, 1: a op s, 2: s op a).
 template <typename T, typename Op, int KIND>
@@ -170,7 +199,7 @@ void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int ta
 
 template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
-    constexpr int U = HeavyTile<T>::value;
+    constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
     const int nt = stream_reads((KIND == 0 ? 2 : 1) * n_vec * 16);
     hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);

@@ -201,7 +201,12 @@ struct FastDiv {
     __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : (__umulhi(n, mul) >> shr); }
     __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const { q = div(n); r = n - q * d; }
 };
-template <typename Op> struct OpCtx { __device__ __forceinline__ void init() {} };
+template <typename Op> struct OpCtx {
+    template <int BLOCK> struct Stage {};
+    __device__ __forceinline__ void init() {}
+    template <int BLOCK> __device__ __forceinline__ void fetch(Stage<BLOCK> &) const {}
+    template <int BLOCK> __device__ __forceinline__ void commit(const Stage<BLOCK> &) {}
+};
 template <typename Op, typename T, int W>
 __device__ __forceinline__ void apply_n(const OpCtx<Op> &, const T (&a)[W], const T (&b)[W], T (&r)[W]) {
 #pragma unroll

@@ -180,24 +180,71 @@ template <> struct PowOp<double> {
 // constant memory into LDS once per workgroup so the per-lane lookups are
 // ds_read_b128s instead of divergent global loads.
 template <typename Op> struct OpCtx {
+    template <int BLOCK> struct Stage {};
     __device__ __forceinline__ void init() {}
+    template <int BLOCK> __device__ __forceinline__ void fetch(Stage<BLOCK> &) const {}
+    template <int BLOCK> __device__ __forceinline__ void commit(const Stage<BLOCK> &) {}
 };
+// init() in two halves for a kernel that has loads of its own to issue: fetch() reads this lane's share of the tables
+// into registers (issue it FIRST), commit() writes them to LDS and synchronises.  The kernel's own loads go in
+// between: the wait before the LDS writes then covers only the table reads (vmcnt counts in issue order), and both
+// round trips are in flight together.  BLOCK = the workgroup size.
 template <> struct OpCtx<PowOp<float>> {
+    static constexpr int kDoubles = 2 * smpow::kTabN;
     const double *tab;
+    template <int BLOCK> struct Stage { double v[(kDoubles + BLOCK - 1) / BLOCK]; };
     __device__ __forceinline__ void init() {
-        __shared__ __attribute__((aligned(16))) double lds_tab[2 * smpow::kTabN];
-        for (int i = threadIdx.x; i < 2 * smpow::kTabN; i += blockDim.x) lds_tab[i] = smpow::kLogTab[i];
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+        for (int i = threadIdx.x; i < kDoubles; i += blockDim.x) lds_tab[i] = smpow::kLogTab[i];
+        __syncthreads();
+        tab = lds_tab;
+    }
+    template <int BLOCK> __device__ __forceinline__ void fetch(Stage<BLOCK> &st) const {
+#pragma unroll
+        for (int k = 0; k < (kDoubles + BLOCK - 1) / BLOCK; ++k) {
+            const int i = threadIdx.x + k * BLOCK;
+            st.v[k] = smpow::kLogTab[i < kDoubles ? i : kDoubles - 1];  // unconditional: no branch between the loads
+        }
+    }
+    template <int BLOCK> __device__ __forceinline__ void commit(const Stage<BLOCK> &st) {
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+#pragma unroll
+        for (int k = 0; k < (kDoubles + BLOCK - 1) / BLOCK; ++k) {
+            const int i = threadIdx.x + k * BLOCK;
+            if (i < kDoubles) lds_tab[i] = st.v[k];
+        }
         __syncthreads();
         tab = lds_tab;
     }
 };
 
 template <> struct OpCtx<PowOp<double>> {
+    static constexpr int kDoubles = smpow64::kLogTabDoubles + smpow64::kExpTabDoubles;
     const double *logtab, *exptab;
+    template <int BLOCK> struct Stage { double v[(kDoubles + BLOCK - 1) / BLOCK]; };
     __device__ __forceinline__ void init() {
-        __shared__ __attribute__((aligned(16))) double lds_tab[smpow64::kLogTabDoubles + smpow64::kExpTabDoubles];
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
         for (int i = threadIdx.x; i < smpow64::kLogTabDoubles; i += blockDim.x) lds_tab[i] = smpow64::kLogTab[i];
         for (int i = threadIdx.x; i < smpow64::kExpTabDoubles; i += blockDim.x) lds_tab[smpow64::kLogTabDoubles + i] = smpow64::kExpTab[i];
+        __syncthreads();
+        logtab = lds_tab;
+        exptab = lds_tab + smpow64::kLogTabDoubles;
+    }
+    template <int BLOCK> __device__ __forceinline__ void fetch(Stage<BLOCK> &st) const {
+#pragma unroll
+        for (int k = 0; k < (kDoubles + BLOCK - 1) / BLOCK; ++k) {
+            const int i = threadIdx.x + k * BLOCK < kDoubles ? threadIdx.x + k * BLOCK : kDoubles - 1;  // unconditional loads
+            const double *src = i < smpow64::kLogTabDoubles ? smpow64::kLogTab + i : smpow64::kExpTab + (i - smpow64::kLogTabDoubles);
+            st.v[k] = *src;
+        }
+    }
+    template <int BLOCK> __device__ __forceinline__ void commit(const Stage<BLOCK> &st) {
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+#pragma unroll
+        for (int k = 0; k < (kDoubles + BLOCK - 1) / BLOCK; ++k) {
+            const int i = threadIdx.x + k * BLOCK;
+            if (i < kDoubles) lds_tab[i] = st.v[k];
+        }
         __syncthreads();
         logtab = lds_tab;
         exptab = lds_tab + smpow64::kLogTabDoubles;
@@ -212,8 +259,7 @@ __device__ __forceinline__ void apply_n(const OpCtx<Op> &ctx, const T (&a)[W], c
     if constexpr (std::is_same<Op, PowOp<float>>::value) {
         smpow::pow_n<W>(a, b, r, ctx.tab);
     } else if constexpr (std::is_same<Op, PowOp<double>>::value) {
-#pragma unroll
-        for (int i = 0; i < W; ++i) r[i] = smpow64::pow(a[i], b[i], ctx.logtab, ctx.exptab);
+        smpow64::pow_n<W>(a, b, r, ctx.logtab, ctx.exptab);
     } else {
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);

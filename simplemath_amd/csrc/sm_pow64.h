@@ -15,7 +15,9 @@
 //   e^E = 2^k' * T[j] * (1 + tail[j] + r' + r'^2/2 + ... + r'^5/120);  v_ldexp_f64 applies 2^k' with
 //   correct subnormal / overflow behaviour.
 // Tables (3 KiB + 2 KiB) are staged in LDS by the kernels (OpCtx<PowOp<double>>); tools/gen_pow64_tables.py
-// generates them.  ~45 fp64 VALU ops per element.  Special cases: C99 F.9.4.4 as for the float form.
+// generates them.  ~54 fp64 + ~11 integer / conversion vector instructions per element on the ordinary path (pow_core_t<false>;
+operands that are not ordinary -- anything but a positive normal base and an exponent of normal magnitude -- take
+pow_general).  Special cases: C99 F.9.4.4 as for the float form.
 #pragma once
 
 #include <stdint.h>
@@ -318,18 +320,55 @@ SM_POW_FN int int_class(uint64_t iy) {
     return e < 1023 ? 0 : (e > 1075 ? 2 : whole);
 }
 
+// p * r + c for a compile-time constant c.  On the device the constant rides in an SGPR pair: left to itself the
+// compiler forms a two-address v_fmac_f64 and first copies each constant into the VGPR pair it overwrites -- two
+// v_mov_b32 per polynomial step, 14 of the ~95 vector instructions of one evaluation.
+SM_POW_FN double fma_c(double p, double r, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+    return d;
+#else
+    return SM_POW_FMA(p, r, c);
+#endif
+}
+// 4 r + c (4.0 is an inline operand)
+SM_POW_FN double fma4_c(double r, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, 4.0, %1, %2" : "=v"(d) : "v"(r), "s"(c));
+    return d;
+#else
+    return SM_POW_FMA(4.0, r, c);
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SM_POW_FMAX(a, b) __builtin_fmax((a), (b))
+#define SM_POW_FMIN(a, b) __builtin_fmin((a), (b))
+#else
+#define SM_POW_FMAX(a, b) fmax((a), (b))
+#define SM_POW_FMIN(a, b) fmin((a), (b))
+#endif
+
 // ax finite > 0, y finite.  logtab / exptab: kLogTab / kExpTab layout (LDS copies on the device).
-SM_POW_FN double pow_core(double ax, double y, const double *logtab, const double *exptab) {
-    uint64_t ix = f64_bits(ax);
+// SUB = false: ax is known to be normal (the callers route subnormal bases through the general path).
+template <bool SUB>
+SM_POW_FN double pow_core_t(double ax, double y, const double *logtab, const double *exptab) {
+    uint32_t hi = (uint32_t)(f64_bits(ax) >> 32), lw = (uint32_t)f64_bits(ax);
     int sub = 0;
-    if (ix < 0x0010000000000000ULL) {  // subnormal: normalise
-        ix = f64_bits(ax * 0x1p52);
-        sub = 52;
+    if constexpr (SUB) {
+        if (hi < 0x00100000u) {  // subnormal: normalise
+            const uint64_t nx = f64_bits(ax * 0x1p52);
+            hi = (uint32_t)(nx >> 32);
+            lw = (uint32_t)nx;
+            sub = 52;
+        }
     }
-    const uint64_t tmp = ix - kOff;
-    const int i = (int)((tmp >> (52 - 7)) & (kN - 1));
-    const int k = (int)((int64_t)tmp >> 52) - sub;
-    const double z = bits_f64(ix - (tmp & 0xfff0000000000000ULL));
+    static_assert((kOff & 0xffffffffULL) == 0, "the interval arithmetic below works on the high word alone");
+    const uint32_t tmp = hi - (uint32_t)(kOff >> 32);
+    const int i = (int)((tmp >> (20 - 7)) & (kN - 1));
+    const int k = ((int32_t)tmp >> 20) - sub;
+    const double z = smpow::make_f64(hi - (tmp & 0xfff00000u), lw);
     const double invc = logtab[3 * i], logc = logtab[3 * i + 1], logctail = logtab[3 * i + 2];
     const double kd = (double)k;
     const double Ln2hi = 0x1.62e42f8000000p-1, Ln2lo = 0x1.be8e7bcd5e4f2p-27;
@@ -342,26 +381,27 @@ SM_POW_FN double pow_core(double ax, double y, const double *logtab, const doubl
     const double lo1 = SM_POW_FMA(kd, Ln2lo, logctail);
     const double lo2 = (t1 - t2) + r;
     const double ar = -0.5 * r, ar2 = r * ar;
-    const double hi = t2 + ar2;
+    const double hi2 = t2 + ar2;
     const double lo3 = SM_POW_FMA(ar, r, -ar2);
-    const double lo4 = (t2 - hi) + ar2;
-    double p = -0.125;                                         // -1/8
-    p = SM_POW_FMA(p, r, 0x1.2492492492492p-3);                //  1/7
-    p = SM_POW_FMA(p, r, -0x1.5555555555555p-3);               // -1/6
-    p = SM_POW_FMA(p, r, 0x1.999999999999ap-3);                //  1/5
-    p = SM_POW_FMA(p, r, -0.25);
-    p = SM_POW_FMA(p, r, 0x1.5555555555555p-2);                //  1/3
-    p *= r * (r * r);
-    const double lo = lo1 + lo2 + lo3 + lo4 + p + rlo;         // d ln(1+r)/dr ~ 1: rlo enters at first order
-    const double lhi = hi + lo, ltail = (hi - lhi) + lo;       // ln(ax) = lhi + ltail
+    const double lo4 = (t2 - hi2) + ar2;
+    // cubic and higher terms, r^3 (1/3 - r/4 + r^2/5 - r^3/6 + r^4/7 - r^5/8), as a polynomial in s = -r/2 (= ar):
+    // r^3 (1/3 + s/2 + 4 s^2/5 + 4 s^3/3 + 16 s^4/7 + 4 s^5) -- the leading step then multiplies by an inline constant
+    double p = fma4_c(ar, 0x1.2492492492492p+1);               // 16/7
+    p = fma_c(p, ar, 0x1.5555555555555p+0);                    //  4/3
+    p = fma_c(p, ar, 0x1.999999999999ap-1);                    //  4/5
+    p = SM_POW_FMA(p, ar, 0.5);
+    p = fma_c(p, ar, 0x1.5555555555555p-2);                    //  1/3
+    const double r3 = (r * r) * r;
+    const double lo = SM_POW_FMA(p, r3, (((lo1 + lo2) + lo3) + lo4) + rlo);  // d ln(1+r)/dr ~ 1: rlo enters at first order
+    const double lhi = hi2 + lo, ltail = (hi2 - lhi) + lo;     // ln(ax) = lhi + ltail
 
     const double ehi = y * lhi;
-    // beyond +-1500 the result is 0 / inf whatever the fraction (and ehi itself may have overflowed):
-    // saturate, and drop the low part, which is only meaningful for a finite in-range ehi
-    const bool saturated = !(ehi <= 1500.0 && ehi >= -1500.0);
-    const double elo = saturated ? 0.0 : SM_POW_FMA(y, ltail, SM_POW_FMA(y, lhi, -ehi));
+    // beyond +-1500 the result is 0 / inf whatever the fraction (and ehi itself may have overflowed): clamp.  The low
+    // part is below 2^-40 for any in-range ehi; out of range it is garbage (up to NaN: inf - inf), and confining it to
+    // [-1, 1] (fmax / fmin return the other operand for a NaN) keeps 1 + q positive, which is all 2^+-2164 needs.
+    const double elo = SM_POW_FMIN(SM_POW_FMAX(SM_POW_FMA(y, ltail, SM_POW_FMA(y, lhi, -ehi)), -1.0), 1.0);
     const double InvLn2N = 0x1.71547652b82fep+7, Ln2hiN = 0x1.62e42f8000000p-8, Ln2loN = 0x1.be8e7bcd5e4f2p-34;
-    const double ec = ehi > 1500.0 ? 1500.0 : (ehi < -1500.0 ? -1500.0 : ehi);  // keeps kd * Ln2hiN exact
+    const double ec = SM_POW_FMIN(SM_POW_FMAX(ehi, -1500.0), 1500.0);  // keeps kd2 * Ln2hiN exact
     const double kd2 = SM_POW_RINT(ec * InvLn2N);
     const int ki = smpow::sat_i32(kd2);
     double rr = SM_POW_FMA(-kd2, Ln2hiN, ec);
@@ -370,20 +410,22 @@ SM_POW_FN double pow_core(double ax, double y, const double *logtab, const doubl
     const int j = ki & (kN - 1), e = ki >> 7;  // arithmetic shift: floor
     const double th = exptab[2 * j], trel = exptab[2 * j + 1];
     const double r2 = rr * rr;
-    const double q = trel + rr + r2 * SM_POW_FMA(rr, 0x1.5555555555555p-3, 0.5) +
-                     (r2 * r2) * SM_POW_FMA(rr, 0x1.1111111111111p-7, 0x1.5555555555555p-5);
+    // trel + rr + rr^2 (1/2 + rr (1/6 + rr (1/24 + rr/120))); the innermost step as (rr + 5)/120: one constant per instruction
+    double u = (rr + 5.0) * 0x1.1111111111111p-7;
+    u = fma_c(u, rr, 0x1.5555555555555p-3);
+    u = SM_POW_FMA(u, rr, 0.5);
+    const double q = SM_POW_FMA(u, r2, trel + rr);
     return SM_POW_LDEXP(SM_POW_FMA(th, q, th), e);
 }
 
-SM_POW_FN double pow(double x, double y, const double *logtab, const double *exptab) {
+// Every operand class: the core on stand-in operands, then the C99 F.9.4.4 lattice.
+SM_POW_FN double pow_general(double x, double y, const double *logtab, const double *exptab) {
     const uint64_t ONE = 0x3ff0000000000000ULL, INF = 0x7ff0000000000000ULL, QNAN = 0x7ff8000000000000ULL;
     const uint64_t ix = f64_bits(x), iy = f64_bits(y);
     const uint64_t ax = ix & 0x7fffffffffffffffULL, ay = iy & 0x7fffffffffffffffULL;
-    const bool special = (ix - 1ULL >= INF - 1ULL) || (ay - 1ULL >= INF - 1ULL);
-    if (!smpow::any_lane(special)) return pow_core(x, y, logtab, exptab);
     const double axc = bits_f64((ax == 0 || ax >= INF) ? ONE : ax);
     const double yc_d = ay >= INF ? 1.0 : y;
-    const double core = pow_core(axc, yc_d, logtab, exptab);
+    const double core = pow_core_t<true>(axc, yc_d, logtab, exptab);
     const bool x_neg = (ix >> 63) != 0, y_neg = (iy >> 63) != 0;
     const bool x_nan = ax > INF, y_nan = ay > INF;
     const bool x_one = ix == ONE, y_zero = ay == 0;
@@ -399,6 +441,46 @@ SM_POW_FN double pow(double x, double y, const double *logtab, const double *exp
     const uint64_t nan_r = snan ? QNAN : ((x_one || y_zero) ? ONE : QNAN);
     r = (x_nan || y_nan) ? nan_r : r;
     return bits_f64(r);
+}
+
+// How far an operand's high word is from "ordinary": x positive and normal, y finite and of normal magnitude.  Both
+// classes are visible in the high 32 bits; anything else (zeros, subnormals, negatives, infinities, NaNs) yields a value
+// >= kOrdinarySpan and takes pow_general, which is correct for every operand.
+constexpr uint32_t kMinNormalHi = 0x00100000u, kOrdinarySpan = 0x7ff00000u - kMinNormalHi;
+SM_POW_FN uint32_t oddness(double x, double y) {
+    const uint32_t hx = (uint32_t)(f64_bits(x) >> 32), hy = (uint32_t)(f64_bits(y) >> 32) & 0x7fffffffu;
+    const uint32_t dx = hx - kMinNormalHi, dy = hy - kMinNormalHi;
+    return dx > dy ? dx : dy;
+}
+
+SM_POW_FN double pow(double x, double y, const double *logtab, const double *exptab) {
+    if (!smpow::any_lane(oddness(x, y) >= kOrdinarySpan)) return pow_core_t<false>(x, y, logtab, exptab);
+    return pow_general(x, y, logtab, exptab);
+}
+
+// x^y for W independent pairs held in registers: one test (and one branch) for the group.
+template <int W>
+SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W], const double *logtab, const double *exptab) {
+    uint32_t worst = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const uint32_t o = oddness(x[k], y[k]);
+        worst = o > worst ? o : worst;
+    }
+    if (!smpow::any_lane(worst >= kOrdinarySpan)) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) out[k] = pow_core_t<false>(x[k], y[k], logtab, exptab);
+        return;
+    }
+    // operands opaque from here on, so that nothing of the lattice is hoisted above the branch (sm_pow.h: pow_n)
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        double xs = x[k], ys = y[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(xs), "+v"(ys));
+#endif
+        out[k] = pow_general(xs, ys, logtab, exptab);
+    }
 }
 
 }  // namespace smpow64

@@ -15,7 +15,9 @@ static uint64_t mix(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^=
 
 int main() {
     const double ys[] = {2.5, 2.0, 3.0, 0.5, -1.0, -2.5, 1.5, 7.0, -3.0, 1.0 / 3, 10.25, 100.0, -100.0, 1e-3, 37.75, -0.001, 1e6, -1e6,
-                         4503599627370496.0, 1.0000000000000002, 0.9999999999999999, 123456.7, 700.0, -700.0, 1e-300, 0.1};
+                         4503599627370496.0, 1.0000000000000002, 0.9999999999999999, 123456.7, 700.0, -700.0, 1e-300, 0.1,
+                         // exponents for which y * ln x overflows or the product's low part is garbage; subnormal exponents
+                         1e300, -1e300, 1.7976931348623157e308, -1.7976931348623157e308, 18446744073709551616.0, 5e-324, -1e-310, 1e17, -3e15};
     int64_t worst = 0; uint64_t count = 0; double wx = 0, wy = 0;
     for (double y : ys) {
         for (uint64_t i = 0; i < 150000; ++i) {
