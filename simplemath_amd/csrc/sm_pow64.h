@@ -15,9 +15,9 @@
 //   e^E = 2^k' * T[j] * (1 + tail[j] + r' + r'^2/2 + ... + r'^5/120);  v_ldexp_f64 applies 2^k' with
 //   correct subnormal / overflow behaviour.
 // Tables (3 KiB + 2 KiB) are staged in LDS by the kernels (OpCtx<PowOp<double>>); tools/gen_pow64_tables.py
-// generates them.  ~54 fp64 + ~11 integer / conversion vector instructions per element on the ordinary path (pow_core_t<false>;
-operands that are not ordinary -- anything but a positive normal base and an exponent of normal magnitude -- take
-pow_general).  Special cases: C99 F.9.4.4 as for the float form.
+// generates them.  ~54 fp64 + ~11 integer / conversion vector instructions per element on the ordinary path
+// (pow_core_t<false>; operands that are not ordinary -- anything but a positive normal base and an exponent of normal
+// magnitude -- take pow_general).  Special cases: C99 F.9.4.4 as for the float form.
 #pragma once
 
 #include <stdint.h>
