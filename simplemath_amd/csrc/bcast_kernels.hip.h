@@ -384,11 +384,14 @@ __device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T 
 // 15-25 %.  8-byte elements take 64 x 64: the same 512-byte output segments and the same 33 KiB of LDS per tile,
 // so four workgroups still fit a CU (64 x 128 doubles left room for two: 57 % of peak instead of 80 %).
 #ifndef SMHIP_TILE_BOTH_CHUNK
-#define SMHIP_TILE_BOTH_CHUNK 1
+#define SMHIP_TILE_BOTH_CHUNK 8
 #endif
 constexpr int kTileP = 64;
 template <typename T> constexpr int tile_q() { return 512 / (int)sizeof(T); }
 
+#ifndef SMHIP_TILE_ORDER
+#define SMHIP_TILE_ORDER 1  // 0: row-major walk of the patches (round 1), 1: diagonal
+#endif
 struct TileParams {
     // plane axes: p (operand-contiguous axis), q (output inner axis)
     uint32_t np, nq;            // extents
@@ -429,8 +432,18 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     OpCtx<Op> ctx;
     ctx.init();
     uint32_t bid = blockIdx.x;
-    const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;  // consecutive workgroups walk q; walking p instead was 15-25 % slower with one
-    const uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;  // turned operand (r01) and 35 % slower with two (r02: 139 -> 188 us)
+    // Consecutive workgroups walk q (walking p instead was 15-25 % slower with one turned operand, r01, and 35 % slower
+    // with two, r02: 139 -> 188 us) -- along a DIAGONAL: workgroup (tp, tq) takes patch ((tp + tq) mod tiles_p, tq), so
+    // the workgroups in flight together read different column offsets of the turned operand(s) as well as different rows,
+    // instead of 64 of them reading the same 256-byte column of 8192 rows at a power-of-two pitch.  (8192, 8192) f32,
+    // tools/tile_modes.py -> profiles/r02_tile_order.txt: a.T + b.T 138.0 -> 130.5 us, and 169.9 -> 129.2 us when the
+    // operands' pitch is 8256 elements; a.T + b at that pitch 119.6 -> 113.6 us.  Skewing q instead, walking p along the
+    // diagonal, and a skew of three were all slower.
+    const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;
+    uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;
+#if SMHIP_TILE_ORDER == 1
+    tp = (tp + tq) % p.tiles_p;
+#endif
     int64_t offA = 0, offB = 0, offO = 0;
     for (int k = 0; k < p.n_rest; ++k) {
         uint32_t qd, idx;
@@ -459,9 +472,11 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
             const T *d0 = MA == 1 ? b0 : a0;  // the direct operand (unused when both are turned)
             const int64_t d_p = MA == 1 ? p.b_p : p.a_p;
             // Slots whose loads go out together.  One turned operand: all of them (and all of the direct operand's).  Two
-            // turned operands: SMHIP_TILE_BOTH_CHUNK slots at a time -- with all sixteen 256-byte-segment loads of a lane
-            // outstanding the two scattered streams got slower, not faster (a.T + b.T at 8192^2: 139 us with one slot at a
-            // time, 147 with two, 153 with four, 151 with all eight).
+            // turned operands: SMHIP_TILE_BOTH_CHUNK slots at a time, by default all eight.  (Under the row-major walk of
+            // the patches more loads in flight made the two scattered streams slower -- a.T + b.T at 8192^2: 139 us with
+            // one slot at a time, 147 / 153 / 151 with two / four / eight -- which was the column camping the diagonal
+            // walk removes; with it one, two and eight slots give 131.6 / 130.1 / 130.5 us, and at a pitch of 8256
+            // elements 144.6 / 140.8 / 129.2.)
             constexpr int CH = kBoth ? (SMHIP_TILE_BOTH_CHUNK < S1 ? SMHIP_TILE_BOTH_CHUNK : S1) : S1;
             V va[CH], vb[kBoth ? CH : 1], vd[kBoth ? 1 : S2];
 #pragma unroll

@@ -20,3 +20,10 @@ def run(sa, sb, steps=60):
 for name, sa, sb in (("A.T + B  ", (1, M), (M, 1)), ("A.T + B.T", (1, M), (1, M)), ("A + B    ", (M, 1), (M, 1))):
     t = run(sa, sb)
     print("%s (8192,8192): %6.1f us  %5.1f%% of 8 TB/s" % (name, t, 12.0 * n / t * 1e-3 / 80), flush=True)
+# the same two turned operands out of arrays whose row pitch is not a power of two (8192 + 64 elements)
+P = M + 64
+a = lib.uniform_f32(M * P, 1, -1.0, 1.0); b = lib.uniform_f32(M * P, 2, -1.0, 1.0)
+t = run((1, P), (1, P))
+print("A.T + B.T, operand pitch 8256: %6.1f us  %5.1f%%" % (t, 12.0 * n / t * 1e-3 / 80), flush=True)
+t = run((1, P), (M, 1))
+print("A.T + B,   operand pitch 8256: %6.1f us  %5.1f%%" % (t, 12.0 * n / t * 1e-3 / 80), flush=True)
