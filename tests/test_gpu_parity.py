@@ -428,6 +428,13 @@ def test_complex_dot(smhip):
         want = complex(np.sum(a.astype(np.clongdouble) * b.astype(np.clongdouble)))
         scale = float(np.sum(np.abs(a) * np.abs(b)))
         assert abs(got - want) <= 4 * n * 2.0 ** -53 * scale + 1e-300, n
+        # the asynchronous form leaves {re, im} in device memory: the same bits, run after run
+        res = smhip.empty((2,), np.float64)
+        smhip.dot_c64_async(da.ptr, db.ptr, n, res.ptr)
+        first = res.numpy().copy()
+        assert complex(first[0], first[1]) == got, n
+        smhip.dot_c64_async(da.ptr, db.ptr, n, res.ptr)
+        assert np.array_equal(res.numpy(), first), n
 
 
 def test_user_op_via_hiprtc(smhip):
