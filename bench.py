@@ -326,7 +326,7 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound):
     exponent = C.c_float(2.5)
     step = bound(lib.c.smhip_array_scalar, C.c_int(sma.OP_POW), C.c_int(sma.F32), C.c_void_p(a.ptr), C.byref(exponent),
                  C.c_size_t(n), C.c_void_p(out.ptr))
-    return (step, n, 8 * n, "heavy_tile_kernel<float, PowOp<float>, 1, 2>",
+    return (step, n, 8 * n, "heavy_tile_kernel<float, PowOp<float>, 1, 2, false>",
             f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident", (a, out, exponent), {"log2n": log2n})
 
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__res
             V v;
 #pragma unroll
             for (int k = 0; k < W; ++k) v[k] = res[k];
-            store_stream(reinterpret_cast<V *>(dst), v);
+            store_stream_if(T, reinterpret_cast<V *>(dst), v, p.nt);
         } else {
 #pragma unroll
             for (int k = 0; k < W; ++k)
@@ -257,7 +257,7 @@ __device__ __forceinline__ void strided_row_body(const T *__restrict__ a, const 
                 for (int k = 0; k < W; ++k) dst_regs[k] = v[(k * S) / W][(k * S) % W];
             }
         };
-        if (p.nt) {  // ONE branch around all the loads of the lane (see load_stream_as)
+        if (p.nt & kLoadNt) {  // ONE branch around all the loads of the lane (see load_stream_as)
             fetch(a + offA, IntTag<SA>{}, BoolTag<true>{}, xa);
             fetch(b + offB, IntTag<SB>{}, BoolTag<true>{}, xb);
         } else {
@@ -365,7 +365,7 @@ __device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T 
                 V rv;
 #pragma unroll
                 for (int k = 0; k < W; ++k) rv[k] = r[k];
-                store_stream(reinterpret_cast<V *>(out) + v, rv);
+                store_stream_if(T, reinterpret_cast<V *>(out) + v, rv, p.nt);
             }
         }
     }
@@ -503,7 +503,7 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
                         }
                     }
                 };
-                if (p.nt) issue(BoolTag<true>{});  // ONE branch around the loads of a chunk (see load_stream_as)
+                if (p.nt & kLoadNt) issue(BoolTag<true>{});  // ONE branch around the loads of a chunk (see load_stream_as)
                 else issue(BoolTag<false>{});
 #pragma unroll
                 for (int s = 0; s < CH; ++s) {
@@ -542,7 +542,7 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
                 V val;
 #pragma unroll
                 for (int k = 0; k < W; ++k) val[k] = xr[k];
-                store_stream(reinterpret_cast<V *>(o0 + (int64_t)il * p.o_p + jg * W), val);
+                store_stream_if(T, reinterpret_cast<V *>(o0 + (int64_t)il * p.o_p + jg * W), val, p.nt);
             }
             return;
         }

@@ -147,7 +147,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                 if (pl.sa[d] != 0) da *= (size_t)pl.shape[d];
                 if (pl.sb[d] != 0) db *= (size_t)pl.shape[d];
             }
-            p.nt = (uint32_t)stream_reads((da + db) * (size_t)esz);
+            p.nt = (uint32_t)stream_policy((da + db) * (size_t)esz, pl.n * (size_t)esz);
         }
         L->kind = Launch::kRow;
         L->ia = (int)ia;
@@ -210,7 +210,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             lp.n = (uint32_t)pl.n;
             lp.n_vec = (uint32_t)(pl.n / W);
             lp.y_span = (uint32_t)(pick == 0 ? span_b : span_a);
-            lp.nt = (uint32_t)stream_reads(pl.n * (size_t)esz);
+            lp.nt = (uint32_t)stream_policy(pl.n * (size_t)esz, pl.n * (size_t)esz);
             for (int d = 0; d < nd; ++d) {
                 const int src = nd - 1 - d;
                 lp.shape[d] = FastDiv((uint32_t)pl.shape[src]);
@@ -275,7 +275,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                     if (pl.sa[d] != 0) da *= (size_t)pl.shape[d];
                     if (pl.sb[d] != 0) db *= (size_t)pl.shape[d];
                 }
-                t.nt = (uint32_t)stream_reads((da + db) * (size_t)esz);
+                t.nt = (uint32_t)stream_policy((da + db) * (size_t)esz, pl.n * (size_t)esz);
             }
             t.tiles_p = (t.np + kTileP - 1) / kTileP;
             t.tiles_q = (t.nq + tq - 1) / tq;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__
     T *d = out + (size_t)row * inner + e0;
     if (e0 + W < inner) {  // strictly inside the row: the over-read stays inside it too
         V v[S];
-        if (nt) {  // one branch around the S loads (see load_stream_as)
+        if (nt & kLoadNt) {  // one branch around the S loads (see load_stream_as)
 #pragma unroll
             for (int i = 0; i < S; ++i) v[i] = load_stream_as(T, reinterpret_cast<const V *>(s) + i, true);
         } else {

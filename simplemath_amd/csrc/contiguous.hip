@@ -45,7 +45,7 @@ __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restri
     if (i < n_vec) {
         const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
         const V vb = load_stream_if(T, reinterpret_cast<const V *>(b) + i, nt);
-        store_stream(reinterpret_cast<V *>(out) + i, apply_vec<Op, T>(ctx, va, vb));
+        store_stream_if(T, reinterpret_cast<V *>(out) + i, (apply_vec<Op, T>(ctx, va, vb)), nt);
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) out[n_vec * W + k] = Op::apply(a[n_vec * W + k], b[n_vec * W + k]);
     }
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void scalar_vec_kernel(const T *__restrict__
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
         const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
-        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s));
+        store_stream_if(T, reinterpret_cast<V *>(out) + i, (apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s)), nt);
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
             const T x = a[n_vec * W + k];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_vec) {
         const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
-        store_stream(reinterpret_cast<V *>(out) + i, apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s));
+        store_stream_if(T, reinterpret_cast<V *>(out) + i, (apply_vec_scalar<Op, T, SWAPPED>(ctx, va, s)), nt);
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
             const T x = a[n_vec * W + k];
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
 // second load in flight is what covers the arithmetic.  Full tiles are guard-free (per-vector guards make the compiler
 // wait for each load in turn); the last, partial tile and the n % W scalar tail belong to the last workgroup.
 constexpr int kTileBlock = 256;
-template <typename T, typename Op, int KIND, int U>
+// PLAIN_STORES: the write side's policy (ops.hip.h: store_stream_if) as a template parameter -- as a run-time branch in
+// front of each store it cut the arithmetic of the tile's vectors apart (config 4: 73.2 -> 79.0 us).
+template <typename T, typename Op, int KIND, int U, bool PLAIN_STORES>
 __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
                                                                 T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
         // the commit sits inside each arm of the read-policy branch, in straight-line code behind the tile's loads, so
         // that the wait in front of its LDS writes is a counted one (vmcnt = the tile's loads still in flight); past a
         // join the compiler falls back to vmcnt(0) and the staging would wait for the tile as well
-        if (nt) {
+        if (nt & kLoadNt) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, true);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             ctx.template commit<kTileBlock>(staged);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) store_stream(ov + base + (size_t)u * kTileBlock, eval(va[u], KIND == 0 ? vb[u] : va[u]));
+        for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * kTileBlock, eval(va[u], KIND == 0 ? vb[u] : va[u]), !PLAIN_STORES);
         return;
     }
     ctx.template commit<kTileBlock>(staged);
@@ -201,8 +203,9 @@ template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
-    const int nt = stream_reads((KIND == 0 ? 2 : 1) * n_vec * 16);
-    hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
+    const int nt = stream_policy((KIND == 0 ? 2 : 1) * n_vec * 16, n_vec * 16);
+    if (nt & kStorePlain) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
+    else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
 }
 
 inline int grid_for(size_t threads, int block, unsigned *grid) {
@@ -226,10 +229,10 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
     } else if (n_vec >= kBigThreshold) {
         if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, stream_reads(2 * n * sizeof(T)));
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)));
     } else {
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_reads(2 * n * sizeof(T)));
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)));
     }
     SMHIP_LAUNCH_CHECK("contiguous");
     return SMHIP_OK;
@@ -264,10 +267,10 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         if (value == T(2) || value == T(1) || value == T(-1) || value == T(0.5)) {
             if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
             const dim3 g(grid), b(kBlockSmall);
-            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
-            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
-            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
-            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
+            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
+            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
+            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
+            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
             SMHIP_LAUNCH_CHECK("array_scalar pow (exact form)");
             return SMHIP_OK;
         }
@@ -280,7 +283,7 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, stream_reads(n * sizeof(T)));
+        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
     }
     SMHIP_LAUNCH_CHECK("array_scalar");
     return SMHIP_OK;
@@ -296,7 +299,7 @@ int run_devscalar(const void *a, const void *sp, size_t n, void *out, hipStream_
     const size_t n_vec = n / W;
     const int tail = (int)(n % W);
     if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
-    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail, stream_reads(n * sizeof(T)));
+    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
     SMHIP_LAUNCH_CHECK("array_devscalar");
     return SMHIP_OK;
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void fused_vec_kernel(const T *__restrict__
         V r;
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = Op2::apply(Op1::apply(va[k], vb[k]), SCALAR_C ? cs : vc[k]);
-        store_stream(reinterpret_cast<V *>(out) + i, r);
+        store_stream_if(T, reinterpret_cast<V *>(out) + i, r, nt);
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) {
             const size_t e = n_vec * W + k;
@@ -52,8 +52,8 @@ int run(const void *a_, const void *b_, const void *c_, const void *cs_host, voi
     const size_t n_vec = n / W, threads = n_vec + (n % W ? 1 : 0);
     const size_t g = (threads + kBlock - 1) / kBlock;
     if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused: array too large for one launch");
-    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_reads(2 * n * sizeof(T)));
-    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_reads(3 * n * sizeof(T)));
+    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_policy(2 * n * sizeof(T), n * sizeof(T)));
+    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_policy(3 * n * sizeof(T), n * sizeof(T)));
     SMHIP_LAUNCH_CHECK("fused");
     return SMHIP_OK;
 }

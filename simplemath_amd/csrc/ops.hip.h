@@ -28,6 +28,8 @@ namespace dev {
 // shifted off the 16-byte grid runs within 2 % of an aligned one (tools/sweep_unaligned.hip: 6.1-6.4 vs
 // 6.3 TB/s; one element per lane: 5.3).  So views that start mid-row, odd row pitches and sliced operands all
 // take the same vector kernels -- there is no per-element fallback for alignment.
+// Bits of a launch's stream-policy word (host side: internal.h, stream_policy()).
+constexpr int kLoadNt = 1, kStorePlain = 2;
 template <typename T> struct VecTraits;
 #define SMHIP_VEC(T, N)                                                       \
     template <> struct VecTraits<T> {                                         \
@@ -37,9 +39,15 @@ template <typename T> struct VecTraits;
         typedef half_full_t half_t __attribute__((aligned(sizeof(T))));      \
         static constexpr int width = N;                                       \
         static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } \
+        static __device__ __forceinline__ half_full_t lo(full_t v) { return __builtin_shufflevector(v, v, SMHIP_LO_##N); } \
+        static __device__ __forceinline__ half_full_t hi(full_t v) { return __builtin_shufflevector(v, v, SMHIP_HI_##N); } \
     };
 #define SMHIP_JOIN_4 0, 1, 2, 3
 #define SMHIP_JOIN_2 0, 1
+#define SMHIP_LO_4 0, 1
+#define SMHIP_HI_4 2, 3
+#define SMHIP_LO_2 0
+#define SMHIP_HI_2 1
 SMHIP_VEC(float, 4)
 SMHIP_VEC(int32_t, 4)
 SMHIP_VEC(double, 2)
@@ -88,7 +96,7 @@ SMHIP_VEC(int64_t, 2)
         typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
         const typename smhip_tr_::vec_t *smhip_p_ = (ptr);                                         \
         typename smhip_tr_::full_t smhip_v_;                                                       \
-        if (nt) {                                                                                  \
+        if ((nt) & ::smhip::dev::kLoadNt) {                                                        \
             smhip_v_ = __builtin_nontemporal_load(smhip_p_);                                       \
         } else {                                                                                   \
             const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
@@ -97,6 +105,32 @@ SMHIP_VEC(int64_t, 2)
         }                                                                                          \
         smhip_v_;                                                                                  \
     })
+
+// The WRITE side's policy, the other bit of the same launch-time word (internal.h: stream_policy).  Results are written
+// non-temporally unless the launch's whole footprint -- reads and writes -- fits the Infinity Cache: then a plain store
+// leaves the result where the NEXT operator's plain loads find it.  tools/sweep_chain.hip -> profiles/r02_sweep_chain.txt,
+// 1R+1W ping-pong (each launch reads what the previous one wrote), 64 / 128 MiB per array: plain loads + nt stores 72 / 76 %
+// of HBM peak, plain + plain 86 / 90 % -- the rate bench.py's setting (every launch re-reads the SAME operands) shows
+// with either store.  Above the cache (256 MiB per array) plain stores cost 17 % when the operands repeat.  The plain arm
+// is two half-width stores for the reason given above (one store with different metadata per arm would be merged).
+#define store_stream_as(T, ptr, value, NT)                                                         \
+    do {                                                                                           \
+        typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
+        typename smhip_tr_::vec_t *smhip_q_ = (ptr);                                               \
+        const typename smhip_tr_::full_t smhip_w_ = (value);                                       \
+        if constexpr (NT) {                                                                        \
+            __builtin_nontemporal_store(smhip_w_, smhip_q_);                                       \
+        } else {                                                                                   \
+            typename smhip_tr_::half_t *smhip_g_ = reinterpret_cast<typename smhip_tr_::half_t *>(smhip_q_); \
+            smhip_g_[0] = smhip_tr_::lo(smhip_w_);                                                 \
+            smhip_g_[1] = smhip_tr_::hi(smhip_w_);                                                 \
+        }                                                                                          \
+    } while (0)
+#define store_stream_if(T, ptr, value, pol)                                                        \
+    do {                                                                                           \
+        if ((pol) & ::smhip::dev::kStorePlain) store_stream_as(T, ptr, value, false);              \
+        else store_stream_as(T, ptr, value, true);                                                 \
+    } while (0)
 
 // -------------------------------------------------------------- Op policies
 // f32/f64: one correctly rounded IEEE operation each (add.h:18-59 etc.);

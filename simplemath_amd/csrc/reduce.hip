@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
     if (i1 < n) {
         typedef const VecTraits<double>::vec_t *vp;
         dbl2 x0, y0, x1, y1;
-        if (nt) {  // one branch around the group (ops.hip.h)
+        if (nt & kLoadNt) {  // one branch around the group (ops.hip.h)
             x0 = load_stream_as(double, (vp)(a + i0), true), y0 = load_stream_as(double, (vp)(b + i0), true);
             x1 = load_stream_as(double, (vp)(a + i1), true), y1 = load_stream_as(double, (vp)(b + i1), true);
         } else {

@@ -284,6 +284,14 @@ int compute_units() {
 
 int current_device() { return tls.device < 0 ? 0 : tls.device; }
 
+int stream_policy(size_t bytes_read, size_t bytes_written) {
+    static const bool stores_always_nt = [] { const char *e = getenv("SMHIP_STORE_POLICY"); return e && strcmp(e, "nt") == 0; }();
+    int policy = stream_reads(bytes_read);  // bit 0: dev::kLoadNt
+    const size_t footprint = bytes_read + bytes_written;
+    if (!stores_always_nt && footprint >= kStorePlainFloor && footprint <= kInfinityCacheBytes) policy |= 2;  // dev::kStorePlain
+    return policy;
+}
+
 ThreadDeviceScope::ThreadDeviceScope(int device) : prev_device_(tls.device), prev_use_user_(tls.use_user_stream) {
     tls.device = device;
     tls.use_user_stream = false;

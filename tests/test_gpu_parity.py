@@ -1218,3 +1218,48 @@ def test_user_ops_first_used_from_many_threads(smhip, tmp_path, monkeypatch):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_store_policy_plain_arm(smhip):
+    """Results whose launch footprint (reads + writes) lies between 64 and 256 MiB are stored plainly instead of
+    non-temporally (csrc/internal.h: stream_policy) -- a different store instruction in every streaming kernel.  One case
+    per kernel, sized into that window, against numpy (bit-exact; pow within its bar)."""
+    rng = np.random.default_rng(77)
+    n = 9 << 20                                           # 36 MiB of f32 per array
+    a = rng.uniform(0.5, 2.0, n).astype(np.float32); b = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    tail = 3                                              # vector body + scalar tail
+    sub = lambda d, k: sma.DeviceArray(smhip, d.base_ptr, np.float32, (k,), (1,), 0, d._owner)
+    # contiguous (2R+1W = 96 MiB), array-scalar (64 MiB + tail: one element short of... keep it inside the window)
+    got = smhip.contiguous(sma.OP_ADD, da, db).numpy()
+    assert np.array_equal(got, a + b)
+    got = smhip.array_scalar(sma.OP_MUL, da, np.float32(1.25)).numpy()
+    assert np.array_equal(got, a * np.float32(1.25))
+    got = smhip.contiguous(sma.OP_SUB, sub(da, n - tail), sub(db, n - tail)).numpy()
+    assert np.array_equal(got, (a - b)[: n - tail])
+    # heavy tile kernels (pow): scalar and array exponents
+    got = smhip.array_scalar(sma.OP_POW, da, np.float32(2.5)).numpy()
+    want = np.power(a.astype(np.float64), 2.5).astype(np.float32)
+    assert orc.ulp_diff_f32(got, want).max() <= POW_ULP
+    got = smhip.contiguous(sma.OP_POW, da, db).numpy()
+    want = np.power(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
+    assert orc.ulp_diff_f32(got, want).max() <= POW_ULP
+    # row kernel: (2304, 4096) * (1, 4096), 72 MiB
+    A = a.reshape(2304, 4096); r = b[:4096].reshape(1, 4096)
+    dA = sma.DeviceArray(smhip, da.base_ptr, np.float32, A.shape, (4096, 1), 0, da._owner)
+    dr = sma.DeviceArray(smhip, db.base_ptr, np.float32, r.shape, (4096, 1), 0, db._owner)
+    assert np.array_equal(smhip.binary(sma.OP_MUL, dA, dr).numpy(), A * r)
+    # tile kernel: A.T + B on (2304, 4096) -> output (4096, 2304), 108 MiB
+    dAT = sma.DeviceArray(smhip, da.base_ptr, np.float32, (4096, 2304), (1, 4096), 0, da._owner)
+    dB = sma.DeviceArray(smhip, db.base_ptr, np.float32, (4096, 2304), (2304, 1), 0, db._owner)
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dAT, dB).numpy(), A.T + b.reshape(4096, 2304))
+    # LDS kernel: (56, 224, 224, 3) + (1, 224, 1, 3): 32.2 MiB in, 32.2 MiB out (just above the 64 MiB floor)
+    m = 56 * 224 * 224 * 3
+    X = a[:m].reshape(56, 224, 224, 3); y = b[:224 * 3].reshape(1, 224, 1, 3)
+    dX = sma.DeviceArray(smhip, da.base_ptr, np.float32, X.shape, (224 * 224 * 3, 224 * 3, 3, 1), 0, da._owner)
+    dy = sma.DeviceArray(smhip, db.base_ptr, np.float32, y.shape, (672, 3, 3, 1), 0, db._owner)
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dX, dy).numpy(), X + y)
+    # fused (a + b) * c: 3R+1W of 16 MiB = 64 MiB
+    k = 1 << 22
+    got = smhip.fused(sma.OP_ADD, sma.OP_MUL, sub(da, k), sub(db, k), sub(da, k)).numpy()
+    assert np.array_equal(got, (a[:k] + b[:k]) * a[:k])
