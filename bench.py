@@ -20,7 +20,7 @@ N GPUs   each GPU owns one outer-dimension shard of 2^28 elements of the N * 2^2
          Config 5's exchange step (fused add + sum per shard, then ONE ncclAllReduce of an fp64 scalar over xGMI, issued
          by libsmhip itself: smhip_allreduce_sum_async / smhip_sharded_contiguous_sum) is timed after the headline
          region and reported under "c5" (operands: config 5's seeds 6/7 in [0,1)).
-roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024>; algorithmic bytes 12 B/elem (2 reads +
+roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024, false>; algorithmic bytes 12 B/elem (2 reads +
          1 write) * 2^28 = 3 221 225 472 B per launch; duration = HIP events (smhip_event_*, recorded on the stream the
          kernel runs on) over the timed region / launches; peak = 8000 GB/s (MI355X HBM3E spec).  `traffic` is NOT
          measured by this run: it is the HBM byte count of the last committed rocprofv3 --pmc passes
@@ -294,7 +294,7 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound):
         if wl == "add":
             step = bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
                          C.c_void_p(c.ptr), C.c_size_t(n))
-            kernel = "contiguous_vec_kernel<float, AddOp<float>, 1024>"
+            kernel = "contiguous_vec_kernel<float, AddOp<float>, 1024, false>"
         else:
             step = bound(lib.c.smhip_contiguous_sum_async, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
                          C.c_void_p(c.ptr), C.c_size_t(n), C.c_void_p(sum_ptr))
@@ -660,7 +660,7 @@ def run_single(args):
         if cb is not None:
             extra["cpu_baseline"] = cb
     emit(args, "add", G, "single", G * n / (wall / args.steps) / 1e9, wall / args.steps * 1e3, n, 12 * n, kern_ms, singles,
-         "contiguous_vec_kernel<float, AddOp<float>, 1024>",
+         "contiguous_vec_kernel<float, AddOp<float>, 1024, false>",
          f"1D float32 add, N=2^{log2n} per GPU, contiguous, HBM-resident", c5, extra)
     lib.set_devices(0)
     return 0

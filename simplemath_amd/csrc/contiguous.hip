@@ -34,7 +34,10 @@ constexpr size_t kBigThreshold = (size_t)1 << 20;
 
 // out[i] = a[i] op b[i], vector body + <= width-1 scalar tail elements done
 // by the first thread past the body.
-template <typename T, typename Op, int BLOCK>
+// PLAIN_STORES: the write side's policy (ops.hip.h) at compile time -- a run-time branch in front of this kernel's one
+// store cost the N = 2^28 add 1.6 % (498 -> 507 us, same box, tools/op_matrix.py); the 1R+1W scalar kernels below do not
+// notice theirs.
+template <typename T, typename Op, int BLOCK, bool PLAIN_STORES>
 __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restrict__ a, const T *__restrict__ b,
                                                                T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restri
     if (i < n_vec) {
         const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
         const V vb = load_stream_if(T, reinterpret_cast<const V *>(b) + i, nt);
-        store_stream_if(T, reinterpret_cast<V *>(out) + i, (apply_vec<Op, T>(ctx, va, vb)), nt);
+        store_stream_as(T, reinterpret_cast<V *>(out) + i, (apply_vec<Op, T>(ctx, va, vb)), !PLAIN_STORES);
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) out[n_vec * W + k] = Op::apply(a[n_vec * W + k], b[n_vec * W + k]);
     }
@@ -229,10 +232,13 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
     } else if (n_vec >= kBigThreshold) {
         if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)));
+        const int pol = stream_policy(2 * n * sizeof(T), n * sizeof(T));
+        if (pol & kStorePlain) hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, true>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
+        else hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, false>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
     } else {
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)));
+        // below kBigThreshold vectors (16 MiB per operand) the footprint is under the plain-store floor
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall, false>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)) & ~kStorePlain);
     }
     SMHIP_LAUNCH_CHECK("contiguous");
     return SMHIP_OK;

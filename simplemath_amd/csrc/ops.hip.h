@@ -126,11 +126,15 @@ SMHIP_VEC(int64_t, 2)
             smhip_g_[1] = smhip_tr_::hi(smhip_w_);                                                 \
         }                                                                                          \
     } while (0)
+#ifdef SMHIP_STORES_ALWAYS_NT  // experiment switch: no branch, no plain arm
+#define store_stream_if(T, ptr, value, pol) store_stream_as(T, ptr, value, true)
+#else
 #define store_stream_if(T, ptr, value, pol)                                                        \
     do {                                                                                           \
         if ((pol) & ::smhip::dev::kStorePlain) store_stream_as(T, ptr, value, false);              \
         else store_stream_as(T, ptr, value, true);                                                 \
     } while (0)
+#endif
 
 // -------------------------------------------------------------- Op policies
 // f32/f64: one correctly rounded IEEE operation each (add.h:18-59 etc.);
