@@ -1263,3 +1263,30 @@ def test_store_policy_plain_arm(smhip):
     k = 1 << 22
     got = smhip.fused(sma.OP_ADD, sma.OP_MUL, sub(da, k), sub(db, k), sub(da, k)).numpy()
     assert np.array_equal(got, (a[:k] + b[:k]) * a[:k])
+
+
+@pytest.mark.parametrize("dtn", ["f64", "i32", "i64"])
+def test_store_policy_plain_arm_other_types(smhip, dtn):
+    """The plain-store arm for the other element widths: contiguous, array-scalar, row and tile kernels inside the
+    64-256 MiB window, bit for bit against numpy (integer + and * wrap in both)."""
+    dt = DT[dtn]
+    rng = np.random.default_rng(78)
+    rows, cols = 2304, 2048 if np.dtype(dt).itemsize == 8 else 4096      # 36 MiB per array
+    n = rows * cols
+    if dtn == "f64":
+        a = rng.uniform(-2.0, 2.0, n); b = rng.uniform(-2.0, 2.0, n)
+    else:
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, n, dtype=dt); b = rng.integers(info.min, info.max, n, dtype=dt)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(smhip.contiguous(sma.OP_ADD, da, db).numpy(), a + b)
+        s = dt(3)
+        assert np.array_equal(smhip.array_scalar(sma.OP_MUL, da, s).numpy(), a * s)
+        A = a.reshape(rows, cols); r = b[:cols].reshape(1, cols)
+        dA = sma.DeviceArray(smhip, da.base_ptr, dt, A.shape, (cols, 1), 0, da._owner)
+        dr = sma.DeviceArray(smhip, db.base_ptr, dt, r.shape, (cols, 1), 0, db._owner)
+        assert np.array_equal(smhip.binary(sma.OP_MUL, dA, dr).numpy(), A * r)
+        dAT = sma.DeviceArray(smhip, da.base_ptr, dt, (cols, rows), (1, cols), 0, da._owner)
+        dB = sma.DeviceArray(smhip, db.base_ptr, dt, (cols, rows), (rows, 1), 0, db._owner)
+        assert np.array_equal(smhip.binary(sma.OP_ADD, dAT, dB).numpy(), A.T + b.reshape(cols, rows))
