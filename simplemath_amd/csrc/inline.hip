@@ -19,9 +19,13 @@ using namespace dev;
 
 constexpr size_t kInlineBytes = SMHIP_INLINE_MAX_BYTES;
 
-struct alignas(16) InlineBlock {  // FIRST kernel argument: it sits at offset 0 of the kernarg segment
-    unsigned char a[kInlineBytes], b[kInlineBytes];
+// CAP bytes per operand.  Two capacities: the launch writes the whole argument block into the kernarg ring -- device
+// memory, over the bus -- so a 2 KiB block costs a 100-byte operand about a microsecond it does not need
+// (simple_check 4.3-4.7 us with the 1 KiB slots alone, profiles/r02_cpp_benchmarks.txt).
+template <int CAP> struct alignas(16) InlineBlock {  // FIRST kernel argument: it sits at offset 0 of the kernarg segment
+    unsigned char a[CAP], b[CAP];
 };
+constexpr int kSmallCap = 128;
 struct InlineParams {
     int64_t sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];  // innermost first
     uint32_t shape[SMHIP_MAX_NDIM];                   // innermost first
@@ -30,13 +34,13 @@ struct InlineParams {
     uint32_t a_inline, b_inline;
 };
 
-template <typename T, typename Op>
-__global__ __launch_bounds__(256) void inline_kernel(InlineBlock blk, const T *__restrict__ a_dev, const T *__restrict__ b_dev,
+template <typename T, typename Op, int CAP>
+__global__ __launch_bounds__(256) void inline_kernel(InlineBlock<CAP> blk, const T *__restrict__ a_dev, const T *__restrict__ b_dev,
                                                      T *__restrict__ out, InlineParams p) {
     (void)blk;  // read through the kernarg pointer: indexing the by-value copy per lane would spill it to scratch
     const char *kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
     const T *a = p.a_inline ? reinterpret_cast<const T *>(kernarg) : a_dev;
-    const T *b = p.b_inline ? reinterpret_cast<const T *>(kernarg + kInlineBytes) : b_dev;
+    const T *b = p.b_inline ? reinterpret_cast<const T *>(kernarg + CAP) : b_dev;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= p.n) return;
     uint32_t rem = i;
@@ -55,21 +59,24 @@ __global__ __launch_bounds__(256) void inline_kernel(InlineBlock blk, const T *_
 // loads are issued at once, next to (not behind) the scalar loads of the other arguments.  The kernarg segment is host
 // memory: each dependent access is a trip over the fabric (~1.3 us), and the generic kernel above makes two in a row.
 // A_INL: a rides in the block.  B_MODE: 0 device array, 1 inline array, 2 inline scalar (element 0).
-template <typename T, typename Op, bool A_INL, int B_MODE>
-__global__ __launch_bounds__(256) void inline_dense_kernel(InlineBlock blk, const T *__restrict__ a_dev, const T *__restrict__ b_dev,
+template <typename T, typename Op, bool A_INL, int B_MODE, int CAP>
+__global__ __launch_bounds__(256) void inline_dense_kernel(InlineBlock<CAP> blk, const T *__restrict__ a_dev, const T *__restrict__ b_dev,
                                                            T *__restrict__ out, uint32_t n) {
     (void)blk;
     const char *kernarg = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const T x = A_INL ? reinterpret_cast<const T *>(kernarg)[i] : a_dev[i];
-    const T y = B_MODE == 2 ? reinterpret_cast<const T *>(kernarg + kInlineBytes)[0]
-                            : (B_MODE == 1 ? reinterpret_cast<const T *>(kernarg + kInlineBytes)[i] : b_dev[i]);
+    const T y = B_MODE == 2 ? reinterpret_cast<const T *>(kernarg + CAP)[0]
+                            : (B_MODE == 1 ? reinterpret_cast<const T *>(kernarg + CAP)[i] : b_dev[i]);
     out[i] = Op::apply(x, y);
 }
 
-template <typename T, typename Op>
-int run_inline(const InlineBlock &blk, const void *a, const void *b, void *out, const InlineParams &p, hipStream_t s) {
+template <typename T, typename Op, int CAP>
+int run_inline(const void *a, size_t a_host_bytes, const void *b, size_t b_host_bytes, void *out, const InlineParams &p, hipStream_t s) {
+    InlineBlock<CAP> blk;
+    if (a_host_bytes) memcpy(blk.a, a, a_host_bytes);
+    if (b_host_bytes) memcpy(blk.b, b, b_host_bytes);
     // dense in output order <=> strides are the running products of the extents; a single value <=> all strides 0
     bool a_dense = true, b_dense = true, b_scalar = true;
     int64_t run = 1;
@@ -87,18 +94,18 @@ int run_inline(const InlineBlock &blk, const void *a, const void *b, void *out, 
     if (a_dense && (b_dense || (b_scalar && p.b_inline))) {
         const int mode = (p.a_inline ? 3 : 0) + (b_scalar && p.b_inline ? 2 : (p.b_inline ? 1 : 0));
         switch (mode) {
-            case 1: hipLaunchKernelGGL((inline_dense_kernel<T, Op, false, 1>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
-            case 2: hipLaunchKernelGGL((inline_dense_kernel<T, Op, false, 2>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
-            case 3: hipLaunchKernelGGL((inline_dense_kernel<T, Op, true, 0>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
-            case 4: hipLaunchKernelGGL((inline_dense_kernel<T, Op, true, 1>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
-            case 5: hipLaunchKernelGGL((inline_dense_kernel<T, Op, true, 2>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
+            case 1: hipLaunchKernelGGL((inline_dense_kernel<T, Op, false, 1, CAP>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
+            case 2: hipLaunchKernelGGL((inline_dense_kernel<T, Op, false, 2, CAP>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
+            case 3: hipLaunchKernelGGL((inline_dense_kernel<T, Op, true, 0, CAP>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
+            case 4: hipLaunchKernelGGL((inline_dense_kernel<T, Op, true, 1, CAP>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
+            case 5: hipLaunchKernelGGL((inline_dense_kernel<T, Op, true, 2, CAP>), grid, block, 0, s, blk, ad, bd, od, p.n); break;
             default: goto generic;  // nothing inline: the caller should have used smhip_elementwise, but it still works
         }
         SMHIP_LAUNCH_CHECK("inline (dense)");
         return SMHIP_OK;
     }
 generic:
-    hipLaunchKernelGGL((inline_kernel<T, Op>), dim3((p.n + 255) / 256), dim3(256), 0, s, blk, static_cast<const T *>(a),
+    hipLaunchKernelGGL((inline_kernel<T, Op, CAP>), dim3((p.n + 255) / 256), dim3(256), 0, s, blk, static_cast<const T *>(a),
                        static_cast<const T *>(b), static_cast<T *>(out), p);
     SMHIP_LAUNCH_CHECK("inline");
     return SMHIP_OK;
@@ -108,7 +115,6 @@ generic:
 
 int launch_inline(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *sa, const void *b, size_t b_host_bytes,
                   const int64_t *sb, const int64_t *shape, int ndim, void *out, hipStream_t s) {
-    InlineBlock blk;
     InlineParams p{};
     size_t n = 1;
     for (int d = 0; d < ndim; ++d) {
@@ -122,16 +128,17 @@ int launch_inline(int op, int dtype, const void *a, size_t a_host_bytes, const i
     p.n = (uint32_t)n;
     p.a_inline = a_host_bytes != 0;
     p.b_inline = b_host_bytes != 0;
-    if (a_host_bytes) memcpy(blk.a, a, a_host_bytes);
-    if (b_host_bytes) memcpy(blk.b, b, b_host_bytes);
+    const bool small = a_host_bytes <= (size_t)kSmallCap && b_host_bytes <= (size_t)kSmallCap;
+#define SMHIP_INLINE_OP(T, OP) return small ? run_inline<T, OP<T>, kSmallCap>(a, a_host_bytes, b, b_host_bytes, out, p, s) \
+                                            : run_inline<T, OP<T>, (int)kInlineBytes>(a, a_host_bytes, b, b_host_bytes, out, p, s)
 #define SMHIP_INLINE_OPS(T)                                                              \
     switch (op) {                                                                        \
-        case SMHIP_OP_ADD: return run_inline<T, AddOp<T>>(blk, a, b, out, p, s);        \
-        case SMHIP_OP_SUB: return run_inline<T, SubtractOp<T>>(blk, a, b, out, p, s);   \
-        case SMHIP_OP_MUL: return run_inline<T, MultiplyOp<T>>(blk, a, b, out, p, s);   \
-        case SMHIP_OP_DIV: return run_inline<T, DivideOp<T>>(blk, a, b, out, p, s);     \
-        case SMHIP_OP_POW: return run_inline<T, PowOp<T>>(blk, a, b, out, p, s);        \
-        case SMHIP_OP_LEFT: return run_inline<T, LeftOp<T>>(blk, a, b, out, p, s);      \
+        case SMHIP_OP_ADD: SMHIP_INLINE_OP(T, AddOp);    \
+        case SMHIP_OP_SUB: SMHIP_INLINE_OP(T, SubtractOp);    \
+        case SMHIP_OP_MUL: SMHIP_INLINE_OP(T, MultiplyOp);    \
+        case SMHIP_OP_DIV: SMHIP_INLINE_OP(T, DivideOp);    \
+        case SMHIP_OP_POW: SMHIP_INLINE_OP(T, PowOp);    \
+        case SMHIP_OP_LEFT: SMHIP_INLINE_OP(T, LeftOp);    \
     }                                                                                    \
     break;
     switch (dtype) {
