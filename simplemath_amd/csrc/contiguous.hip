@@ -34,10 +34,10 @@ constexpr size_t kBigThreshold = (size_t)1 << 20;
 
 // out[i] = a[i] op b[i], vector body + <= width-1 scalar tail elements done
 // by the first thread past the body.
-// PLAIN_STORES: the write side's policy (ops.hip.h) at compile time -- a run-time branch in front of this kernel's one
+// KEEP_STORES: the write side's policy (ops.hip.h) at compile time -- a run-time branch in front of this kernel's one
 // store cost the N = 2^28 add 1.6 % (498 -> 507 us, same box, tools/op_matrix.py); the 1R+1W scalar kernels below do not
 // notice theirs.
-template <typename T, typename Op, int BLOCK, bool PLAIN_STORES>
+template <typename T, typename Op, int BLOCK, bool KEEP_STORES>
 __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restrict__ a, const T *__restrict__ b,
                                                                T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(BLOCK) void contiguous_vec_kernel(const T *__restri
     if (i < n_vec) {
         const V va = load_stream_if(T, reinterpret_cast<const V *>(a) + i, nt);
         const V vb = load_stream_if(T, reinterpret_cast<const V *>(b) + i, nt);
-        store_stream_as(T, reinterpret_cast<V *>(out) + i, (apply_vec<Op, T>(ctx, va, vb)), !PLAIN_STORES);
+        store_stream_as(T, reinterpret_cast<V *>(out) + i, (apply_vec<Op, T>(ctx, va, vb)), !KEEP_STORES);
     } else if (i == n_vec) {
         for (int k = 0; k < tail; ++k) out[n_vec * W + k] = Op::apply(a[n_vec * W + k], b[n_vec * W + k]);
     }
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
 // second load in flight is what covers the arithmetic.  Full tiles are guard-free (per-vector guards make the compiler
 // wait for each load in turn); the last, partial tile and the n % W scalar tail belong to the last workgroup.
 constexpr int kTileBlock = 256;
-// PLAIN_STORES: the write side's policy (ops.hip.h: store_stream_if) as a template parameter -- as a run-time branch in
+// KEEP_STORES: the write side's policy (ops.hip.h: store_stream_if) as a template parameter -- as a run-time branch in
 // front of each store it cut the arithmetic of the tile's vectors apart (config 4: 73.2 -> 79.0 us).
-template <typename T, typename Op, int KIND, int U, bool PLAIN_STORES>
+template <typename T, typename Op, int KIND, int U, bool KEEP_STORES>
 __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
                                                                 T *__restrict__ out, size_t n_vec, int tail, int nt) {
     typedef typename VecTraits<T>::vec_t V;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             ctx.template commit<kTileBlock>(staged);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * kTileBlock, eval(va[u], KIND == 0 ? vb[u] : va[u]), !PLAIN_STORES);
+        for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * kTileBlock, eval(va[u], KIND == 0 ? vb[u] : va[u]), !KEEP_STORES);
         return;
     }
     ctx.template commit<kTileBlock>(staged);
@@ -207,7 +207,7 @@ void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int ta
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
     const int nt = stream_policy((KIND == 0 ? 2 : 1) * n_vec * 16, n_vec * 16);
-    if (nt & kStorePlain) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
+    if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
     else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
 }
 
@@ -233,12 +233,13 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     } else if (n_vec >= kBigThreshold) {
         if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
         const int pol = stream_policy(2 * n * sizeof(T), n * sizeof(T));
-        if (pol & kStorePlain) hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, true>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
+        if (pol & kStoreKeep) hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, true>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
         else hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, false>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
     } else {
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        // below kBigThreshold vectors (16 MiB per operand) the footprint is under the plain-store floor
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall, false>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)) & ~kStorePlain);
+        // below kBigThreshold vectors (16 MiB per operand: 48 MiB in all at most) a footprint above the keep-store floor
+        // is a corner this form does not serve
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall, false>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)) & ~kStoreKeep);
     }
     SMHIP_LAUNCH_CHECK("contiguous");
     return SMHIP_OK;

@@ -72,11 +72,12 @@ constexpr int kReduceFoldSpan = 1024;  // = reduce.hip's kGroupTarget: partial b
 // Read streams of a launch get the non-temporal hint when together they exceed the Infinity Cache (ops.hip.h: load_stream_if).
 constexpr size_t kInfinityCacheBytes = (size_t)256 << 20;
 inline int stream_reads(size_t bytes_read) { return bytes_read > kInfinityCacheBytes ? 1 : 0; }
-// ... and results are stored plainly when the launch's whole footprint fits it, so that the next operator finds them
-// there (ops.hip.h: store_stream_if; bit 1 of the same word).  Small footprints keep the non-temporal store: at 32 and
-// 48 MiB (1R+1W of 16 MiB, 2R+1W of 16 MiB -- about what the eight 4 MiB L2s hold) it was the faster one in every setting of
-// tools/sweep_chain.hip / tools/chain_rates.py.  SMHIP_STORE_POLICY=nt switches the rule off (experiments).
-constexpr size_t kStorePlainFloor = (size_t)64 << 20;
+// ... and results are stored so that they stay in it (ops.hip.h: store_stream_if, an `sc1` store; bit 1 of the same
+// word) when the launch's whole footprint fits: the next operator then finds them there.  Small footprints keep the
+// non-temporal store: at 16 and 32 MiB (1R+1W of 8 / 16 MiB per array -- about what the eight 4 MiB L2s hold) it was the
+// faster one in every setting of tools/sweep_store_sc1.hip; from 48 MiB (2R+1W of 16 MiB) on the `sc1` store wins.
+// SMHIP_STORE_POLICY=nt switches the rule off (experiments).
+constexpr size_t kStoreKeepFloor = (size_t)40 << 20;
 int stream_policy(size_t bytes_read, size_t bytes_written);
 
 inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }

@@ -183,23 +183,16 @@ template <typename T> struct VecTraits;
 #define SMHIP_VEC(T, N) template <> struct VecTraits<T> { typedef T full_t __attribute__((ext_vector_type(N))); \
     typedef full_t vec_t __attribute__((aligned(sizeof(T)))); typedef T half_full_t __attribute__((ext_vector_type(N / 2))); \
     typedef half_full_t half_t __attribute__((aligned(sizeof(T)))); static constexpr int width = N; \
-    static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } \
-    static __device__ __forceinline__ half_full_t lo(full_t v) { return __builtin_shufflevector(v, v, SMHIP_LO_##N); } \
-    static __device__ __forceinline__ half_full_t hi(full_t v) { return __builtin_shufflevector(v, v, SMHIP_HI_##N); } };
+    static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } };
 #define SMHIP_JOIN_4 0, 1, 2, 3
 #define SMHIP_JOIN_2 0, 1
-#define SMHIP_LO_4 0, 1
-#define SMHIP_HI_4 2, 3
-#define SMHIP_LO_2 0
-#define SMHIP_HI_2 1
 SMHIP_VEC(float, 4) SMHIP_VEC(int32_t, 4) SMHIP_VEC(double, 2) SMHIP_VEC(int64_t, 2)
-constexpr int kLoadNt = 1, kStorePlain = 2;  // bits of a launch's stream-policy word (ops.hip.h)
+constexpr int kLoadNt = 1, kStoreKeep = 2;  // bits of a launch's stream-policy word (ops.hip.h)
 #define load_stream(ptr) __builtin_nontemporal_load(ptr)
 #define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
 #define store_stream_as(T, ptr, value, NT) do { typedef VecTraits<T> smhip_tr_; typename smhip_tr_::vec_t *smhip_q_ = (ptr); const typename smhip_tr_::full_t smhip_w_ = (value); \
-    if constexpr (NT) { __builtin_nontemporal_store(smhip_w_, smhip_q_); } else { typename smhip_tr_::half_t *smhip_g_ = reinterpret_cast<typename smhip_tr_::half_t *>(smhip_q_); \
-    smhip_g_[0] = smhip_tr_::lo(smhip_w_); smhip_g_[1] = smhip_tr_::hi(smhip_w_); } } while (0)
-#define store_stream_if(T, ptr, value, pol) do { if ((pol) & kStorePlain) store_stream_as(T, ptr, value, false); else store_stream_as(T, ptr, value, true); } while (0)
+    if constexpr (NT) { __builtin_nontemporal_store(smhip_w_, smhip_q_); } else { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(smhip_q_), "v"(smhip_w_)); } } while (0)
+#define store_stream_if(T, ptr, value, pol) do { if ((pol) & kStoreKeep) store_stream_as(T, ptr, value, false); else store_stream_as(T, ptr, value, true); } while (0)
 #define load_stream_as(T, ptr, NT) ({ typedef VecTraits<T> smhip_tr_; const typename smhip_tr_::vec_t *smhip_p_ = (ptr); typename smhip_tr_::full_t smhip_v_; \
     if constexpr (NT) { smhip_v_ = __builtin_nontemporal_load(smhip_p_); } else { const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \
     const typename smhip_tr_::half_full_t smhip_lo_ = smhip_h_[0], smhip_hi_ = smhip_h_[1]; smhip_v_ = smhip_tr_::join(smhip_lo_, smhip_hi_); } smhip_v_; })

@@ -29,7 +29,7 @@ namespace dev {
 // 6.3 TB/s; one element per lane: 5.3).  So views that start mid-row, odd row pitches and sliced operands all
 // take the same vector kernels -- there is no per-element fallback for alignment.
 // Bits of a launch's stream-policy word (host side: internal.h, stream_policy()).
-constexpr int kLoadNt = 1, kStorePlain = 2;
+constexpr int kLoadNt = 1, kStoreKeep = 2;
 template <typename T> struct VecTraits;
 #define SMHIP_VEC(T, N)                                                       \
     template <> struct VecTraits<T> {                                         \
@@ -39,15 +39,9 @@ template <typename T> struct VecTraits;
         typedef half_full_t half_t __attribute__((aligned(sizeof(T))));      \
         static constexpr int width = N;                                       \
         static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } \
-        static __device__ __forceinline__ half_full_t lo(full_t v) { return __builtin_shufflevector(v, v, SMHIP_LO_##N); } \
-        static __device__ __forceinline__ half_full_t hi(full_t v) { return __builtin_shufflevector(v, v, SMHIP_HI_##N); } \
     };
 #define SMHIP_JOIN_4 0, 1, 2, 3
 #define SMHIP_JOIN_2 0, 1
-#define SMHIP_LO_4 0, 1
-#define SMHIP_HI_4 2, 3
-#define SMHIP_LO_2 0
-#define SMHIP_HI_2 1
 SMHIP_VEC(float, 4)
 SMHIP_VEC(int32_t, 4)
 SMHIP_VEC(double, 2)
@@ -107,12 +101,16 @@ SMHIP_VEC(int64_t, 2)
     })
 
 // The WRITE side's policy, the other bit of the same launch-time word (internal.h: stream_policy).  Results are written
-// non-temporally unless the launch's whole footprint -- reads and writes -- fits the Infinity Cache: then a plain store
-// leaves the result where the NEXT operator's plain loads find it.  tools/sweep_chain.hip -> profiles/r02_sweep_chain.txt,
-// 1R+1W ping-pong (each launch reads what the previous one wrote), 64 / 128 MiB per array: plain loads + nt stores 72 / 76 %
-// of HBM peak, plain + plain 86 / 90 % -- the rate bench.py's setting (every launch re-reads the SAME operands) shows
-// with either store.  Above the cache (256 MiB per array) plain stores cost 17 % when the operands repeat.  The plain arm
-// is two half-width stores for the reason given above (one store with different metadata per arm would be merged).
+// non-temporally unless the launch's whole footprint -- reads and writes -- fits the Infinity Cache: then they are stored
+// so that the NEXT operator's plain loads find them there.  tools/sweep_chain.hip -> profiles/r02_sweep_chain.txt, 1R+1W
+// ping-pong (each launch reads what the previous one wrote), 64 / 128 MiB per array: nt stores 72 / 76 % of HBM peak, plain
+// stores 86 / 90 % -- the rate bench.py's setting (every launch re-reads the SAME operands) shows with either.
+// Which store: `sc1` (tools/sweep_store_flavours.hip, tools/sweep_store_sc1.hip -> profiles/r02_sweep_store_sc1.txt).
+// It keeps the chain rate of a plain store without a plain store's cost in the repeated-operand setting -- 1R+1W at
+// 32 MiB: same / chain 109 / 81 % against 79 / 78 % (plain) and 82 / 64 % (nt); 2R+1W at 16 MiB: 121 / 92 % against
+// 74 / 74 % and 95 / 71 %.  The compiler has no spelling for it on a 16-byte vector (nontemporal = nt, a system-scope
+// atomic store is 8 bytes at most), hence the one-instruction asm; nothing else reads the destination, so it needs no
+// memory clobber, and a wave may end with the store in flight like any other.
 #define store_stream_as(T, ptr, value, NT)                                                         \
     do {                                                                                           \
         typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
@@ -121,9 +119,7 @@ SMHIP_VEC(int64_t, 2)
         if constexpr (NT) {                                                                        \
             __builtin_nontemporal_store(smhip_w_, smhip_q_);                                       \
         } else {                                                                                   \
-            typename smhip_tr_::half_t *smhip_g_ = reinterpret_cast<typename smhip_tr_::half_t *>(smhip_q_); \
-            smhip_g_[0] = smhip_tr_::lo(smhip_w_);                                                 \
-            smhip_g_[1] = smhip_tr_::hi(smhip_w_);                                                 \
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(smhip_q_), "v"(smhip_w_));   \
         }                                                                                          \
     } while (0)
 #ifdef SMHIP_STORES_ALWAYS_NT  // experiment switch: no branch, no plain arm
@@ -131,7 +127,7 @@ SMHIP_VEC(int64_t, 2)
 #else
 #define store_stream_if(T, ptr, value, pol)                                                        \
     do {                                                                                           \
-        if ((pol) & ::smhip::dev::kStorePlain) store_stream_as(T, ptr, value, false);              \
+        if ((pol) & ::smhip::dev::kStoreKeep) store_stream_as(T, ptr, value, false);              \
         else store_stream_as(T, ptr, value, true);                                                 \
     } while (0)
 #endif

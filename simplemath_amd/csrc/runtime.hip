@@ -288,7 +288,7 @@ int stream_policy(size_t bytes_read, size_t bytes_written) {
     static const bool stores_always_nt = [] { const char *e = getenv("SMHIP_STORE_POLICY"); return e && strcmp(e, "nt") == 0; }();
     int policy = stream_reads(bytes_read);  // bit 0: dev::kLoadNt
     const size_t footprint = bytes_read + bytes_written;
-    if (!stores_always_nt && footprint >= kStorePlainFloor && footprint <= kInfinityCacheBytes) policy |= 2;  // dev::kStorePlain
+    if (!stores_always_nt && footprint >= kStoreKeepFloor && footprint <= kInfinityCacheBytes) policy |= 2;  // dev::kStoreKeep
     return policy;
 }
 

@@ -1220,8 +1220,8 @@ def test_user_ops_first_used_from_many_threads(smhip, tmp_path, monkeypatch):
     assert not errors, errors[:3]
 
 
-def test_store_policy_plain_arm(smhip):
-    """Results whose launch footprint (reads + writes) lies between 64 and 256 MiB are stored plainly instead of
+def test_store_policy_keep_arm(smhip):
+    """Results whose launch footprint (reads + writes) lies between 40 and 256 MiB are stored with `sc1` instead of
     non-temporally (csrc/internal.h: stream_policy) -- a different store instruction in every streaming kernel.  One case
     per kernel, sized into that window, against numpy (bit-exact; pow within its bar)."""
     rng = np.random.default_rng(77)
@@ -1266,8 +1266,8 @@ def test_store_policy_plain_arm(smhip):
 
 
 @pytest.mark.parametrize("dtn", ["f64", "i32", "i64"])
-def test_store_policy_plain_arm_other_types(smhip, dtn):
-    """The plain-store arm for the other element widths: contiguous, array-scalar, row and tile kernels inside the
+def test_store_policy_keep_arm_other_types(smhip, dtn):
+    """The keep-in-cache (`sc1`) store arm for the other element widths: contiguous, array-scalar, row and tile kernels inside the
     64-256 MiB window, bit for bit against numpy (integer + and * wrap in both)."""
     dt = DT[dtn]
     rng = np.random.default_rng(78)
