@@ -25,7 +25,10 @@ constexpr size_t kInlineBytes = SMHIP_INLINE_MAX_BYTES;
 template <int CAP> struct alignas(16) InlineBlock {  // FIRST kernel argument: it sits at offset 0 of the kernarg segment
     unsigned char a[CAP], b[CAP];
 };
-constexpr int kSmallCap = 128;
+#ifndef SMHIP_INLINE_SMALL_CAP
+#define SMHIP_INLINE_SMALL_CAP 128
+#endif
+constexpr int kSmallCap = SMHIP_INLINE_SMALL_CAP;
 struct InlineParams {
     int64_t sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];  // innermost first
     uint32_t shape[SMHIP_MAX_NDIM];                   // innermost first
