@@ -64,17 +64,36 @@ typedef TYPE T;
 typedef T V0 __attribute__((ext_vector_type(WIDTH)));
 typedef V0 V __attribute__((aligned(sizeof(T))));   // element-aligned 16-byte accesses are legal on gfx950
 struct UserOp { static __device__ __forceinline__ T apply(T a, T b) { return (T)(EXPR); } };
+// the launch's stream-policy word (csrc/internal.h: stream_policy): bit 0 = loads non-temporal, bit 1 = stores `sc1`.  The
+// plain load is two half-width loads on purpose, the keep-store an asm, for the reasons given in csrc/ops.hip.h.
+typedef T H0 __attribute__((ext_vector_type(WIDTH / 2)));
+typedef H0 H __attribute__((aligned(sizeof(T))));
+#if WIDTH == 4
+#define SMHIP_JOIN(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3)
+#else
+#define SMHIP_JOIN(lo, hi) __builtin_shufflevector(lo, hi, 0, 1)
+#endif
+__device__ __forceinline__ V0 smhip_ld(const V* p, int pol) {
+    if (pol & 1) return __builtin_nontemporal_load(p);
+    const H* h = (const H*)p;
+    const H0 lo = h[0], hi = h[1];
+    return SMHIP_JOIN(lo, hi);
+}
+__device__ __forceinline__ void smhip_st(V* p, V0 r, int pol) {
+    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r));
+    else __builtin_nontemporal_store(r, p);
+}
 
 extern "C" __global__ __launch_bounds__(256) void smhip_user_contig(const T* __restrict__ a, const T* __restrict__ b,
                                                                      T* __restrict__ out, unsigned long long n_vec,
-                                                                     unsigned long long n, int vec) {
+                                                                     unsigned long long n, int vec, int pol) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (vec) {
         if (i < n_vec) {
-            const V va = __builtin_nontemporal_load((const V*)a + i), vb = __builtin_nontemporal_load((const V*)b + i);
-            V r;
+            const V0 va = smhip_ld((const V*)a + i, pol), vb = smhip_ld((const V*)b + i, pol);
+            V0 r;
             for (int k = 0; k < WIDTH; ++k) r[k] = UserOp::apply(va[k], vb[k]);
-            __builtin_nontemporal_store(r, (V*)out + i);
+            smhip_st((V*)out + i, r, pol);
         } else if (i == n_vec) {
             for (unsigned long long k = n_vec * WIDTH; k < n; ++k) out[k] = UserOp::apply(a[k], b[k]);
         }
@@ -84,13 +103,13 @@ extern "C" __global__ __launch_bounds__(256) void smhip_user_contig(const T* __r
 }
 
 extern "C" __global__ __launch_bounds__(256) void smhip_user_scalar(const T* __restrict__ a, T s, T* __restrict__ out,
-                                                                     unsigned long long n_vec, unsigned long long n, int swapped) {
+                                                                     unsigned long long n_vec, unsigned long long n, int swapped, int pol) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n_vec) {
-        const V va = __builtin_nontemporal_load((const V*)a + i);
-        V r;
+        const V0 va = smhip_ld((const V*)a + i, pol);
+        V0 r;
         for (int k = 0; k < WIDTH; ++k) r[k] = swapped ? UserOp::apply(s, va[k]) : UserOp::apply(va[k], s);
-        __builtin_nontemporal_store(r, (V*)out + i);
+        smhip_st((V*)out + i, r, pol);
     } else if (i == n_vec) {
         for (unsigned long long k = n_vec * WIDTH; k < n; ++k) out[k] = swapped ? UserOp::apply(s, a[k]) : UserOp::apply(a[k], s);
     }
@@ -104,22 +123,48 @@ const char *kExprSource = R"SRC(
 typedef TYPE T;
 typedef T V0 __attribute__((ext_vector_type(WIDTH)));
 typedef V0 V __attribute__((aligned(sizeof(T))));
+// the launch's stream-policy word (csrc/internal.h: stream_policy): bit 0 = loads non-temporal, bit 1 = stores `sc1`.  The
+// plain load is two half-width loads on purpose, the keep-store an asm, for the reasons given in csrc/ops.hip.h.
+typedef T H0 __attribute__((ext_vector_type(WIDTH / 2)));
+typedef H0 H __attribute__((aligned(sizeof(T))));
+#if WIDTH == 4
+#define SMHIP_JOIN(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3)
+#else
+#define SMHIP_JOIN(lo, hi) __builtin_shufflevector(lo, hi, 0, 1)
+#endif
+__device__ __forceinline__ V0 smhip_ld(const V* p, int pol) {
+    if (pol & 1) return __builtin_nontemporal_load(p);
+    const H* h = (const H*)p;
+    const H0 lo = h[0], hi = h[1];
+    return SMHIP_JOIN(lo, hi);
+}
+__device__ __forceinline__ void smhip_st(V* p, V0 r, int pol) {
+    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r));
+    else __builtin_nontemporal_store(r, p);
+}
 struct Operands { const T* p[8]; };
 struct Scalars { T v[4]; };
 __device__ __forceinline__ T smhip_eval(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7, T s0, T s1, T s2, T s3) { return (T)(EXPR); }
 extern "C" __global__ __launch_bounds__(256) void smhip_user_expr(Operands in, Scalars sc, T* __restrict__ out, unsigned long long n_vec,
-                                                                   unsigned long long n) {
+                                                                   unsigned long long n, int pol) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n_vec) {
-        V v[8];
+        V0 v[8];
+        if (pol & 1) {  // one branch around the group of loads (csrc/ops.hip.h: load_stream_as)
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < NOPS) v[k] = __builtin_nontemporal_load((const V*)in.p[k] + i);
-            else v[k] = v[0];
-        V r;
+            for (int k = 0; k < 8; ++k)
+                if (k < NOPS) v[k] = smhip_ld((const V*)in.p[k] + i, 1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < NOPS) v[k] = smhip_ld((const V*)in.p[k] + i, 0);
+        }
+#pragma unroll
+        for (int k = NOPS; k < 8; ++k) v[k] = v[0];
+        V0 r;
 #pragma unroll
         for (int e = 0; e < WIDTH; ++e) r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);
-        __builtin_nontemporal_store(r, (V*)out + i);
+        smhip_st((V*)out + i, r, pol);
     } else if (i == n_vec) {
         for (unsigned long long j = n_vec * WIDTH; j < n; ++j) {
             T x[8];
@@ -135,22 +180,29 @@ typedef ACC A;
 __device__ __forceinline__ A smhip_widen(T x) { return WIDEN; }
 extern "C" __global__ __launch_bounds__(256) void smhip_user_expr_sum(Operands in, Scalars sc, T* __restrict__ out, int store,
                                                                        unsigned long long n_vec, unsigned long long n,
-                                                                       A* __restrict__ partials) {
+                                                                       A* __restrict__ partials, int pol) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     A acc = 0;
     if (i < n_vec) {
-        V v[8];
+        V0 v[8];
+        if (pol & 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < NOPS) v[k] = __builtin_nontemporal_load((const V*)in.p[k] + i);
-            else v[k] = v[0];
-        V r;
+            for (int k = 0; k < 8; ++k)
+                if (k < NOPS) v[k] = smhip_ld((const V*)in.p[k] + i, 1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < NOPS) v[k] = smhip_ld((const V*)in.p[k] + i, 0);
+        }
+#pragma unroll
+        for (int k = NOPS; k < 8; ++k) v[k] = v[0];
+        V0 r;
 #pragma unroll
         for (int e = 0; e < WIDTH; ++e) {
             r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);
             acc += smhip_widen(r[e]);
         }
-        if (store) __builtin_nontemporal_store(r, (V*)out + i);
+        if (store) smhip_st((V*)out + i, r, pol);
     } else if (i == n_vec) {
         for (unsigned long long j = n_vec * WIDTH; j < n; ++j) {
             T x[8];
@@ -402,7 +454,8 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
     const size_t threads = vec ? n_vec + 1 : n;
     const size_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
-    void *args[] = {&a, &b, &out, &n_vec, &nn, &vec};
+    int pol = stream_policy(2 * n * dtype_size(dtype), n * dtype_size(dtype));
+    void *args[] = {&a, &b, &out, &n_vec, &nn, &vec, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }
@@ -417,7 +470,8 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
     unsigned char scalar[8];
     memcpy(scalar, value_host, dtype_size(dtype));
-    void *args[] = {&a, scalar, &out, &n_vec, &nn, &swapped};
+    int pol = stream_policy(n * dtype_size(dtype), n * dtype_size(dtype));
+    void *args[] = {&a, scalar, &out, &n_vec, &nn, &swapped, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
 }
@@ -498,8 +552,9 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused expression: array too large for one launch");
     unsigned char sc[32] = {};  // Scalars { T v[4]; }: runtime values, so changing them does not recompile
     if (n_scalars > 0) memcpy(sc, scalars_host, (size_t)n_scalars * dtype_size(dtype));
+    int pol = stream_policy((size_t)n_operands * n * dtype_size(dtype), out ? n * dtype_size(dtype) : 0);
     if (!sum_dev) {
-        void *args[] = {&in, sc, &out, &n_vec, &nn};
+        void *args[] = {&in, sc, &out, &n_vec, &nn, &pol};
         SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
         return SMHIP_OK;
     }
@@ -508,7 +563,7 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     ScratchLease lease;
     if (int rc = lease.take(grid + grid / kReduceFoldSpan + 2, &scratch)) return rc;
     int store = out != nullptr;
-    void *args[] = {&in, sc, &out, &store, &n_vec, &nn, &scratch};
+    void *args[] = {&in, sc, &out, &store, &n_vec, &nn, &scratch, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return reduce_finish(dtype, scratch, grid, sum_dev, s);
 }

@@ -1263,6 +1263,14 @@ def test_store_policy_keep_arm(smhip):
     k = 1 << 22
     got = smhip.fused(sma.OP_ADD, sma.OP_MUL, sub(da, k), sub(db, k), sub(da, k)).numpy()
     assert np.array_equal(got, (a[:k] + b[:k]) * a[:k])
+    # the run-time-compiled flat kernels (user Op, fused expression) carry the same policy word
+    op = smhip.register_op("(a + b) * 2")
+    assert np.array_equal(smhip.contiguous(op, da, db).numpy(), (a + b) * np.float32(2))
+    assert np.array_equal(smhip.array_scalar(op, da, np.float32(0.5)).numpy(), (a + np.float32(0.5)) * np.float32(2))
+    assert np.array_equal(smhip.fused_expr("(a0 - a1) * 4", da, db).numpy(), (a - b) * np.float32(4))
+    total, diff = smhip.fused_expr_sum("a0 - a1", da, db, store=True)      # reads 72 MiB, writes 36 MiB
+    assert np.array_equal(diff.numpy(), a - b)
+    assert abs(total - float(np.sum((a - b).astype(np.float64)))) <= 1e-9 * n
 
 
 @pytest.mark.parametrize("dtn", ["f64", "i32", "i64"])
