@@ -95,12 +95,12 @@ enum Mode { kSum = 0, kDot = 1, kFused = 2 };
 // One vector's contribution: MODE kSum: acc += a;  kDot: acc += a*b;  kFused: out = a op b, acc += out.
 template <typename T, typename Op, int MODE, typename A>
 __device__ __forceinline__ void consume(const OpCtx<Op> &ctx, A &acc, typename VecTraits<T>::vec_t va, typename VecTraits<T>::vec_t vb,
-                                        typename VecTraits<T>::vec_t *out_slot) {
+                                        typename VecTraits<T>::vec_t *out_slot, int nt) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     if constexpr (MODE == kFused) {
         const V r = apply_vec<Op, T>(ctx, va, vb);
-        store_stream(out_slot, r);
+        store_stream_if(T, out_slot, r, nt);
 #pragma unroll
         for (int k = 0; k < W; ++k) acc += widen<T, A>(r[k]);
     } else if constexpr (MODE == kDot) {
@@ -178,14 +178,14 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
             else vb[u] = va[u];
         }
 #pragma unroll
-        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock);
+        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock, nt);
     } else {
         for (int u = 0; u < kVecPerThread; ++u) {
             const size_t i = tile0 + (size_t)u * kBlock;
             if (i < n_vec) {
                 const V va = load_stream(av + i);
                 const V vb = MODE != kSum ? load_stream(bv + i) : va;
-                consume<T, Op, MODE, A>(ctx, acc, va, vb, ov + i);
+                consume<T, Op, MODE, A>(ctx, acc, va, vb, ov + i, nt);
             }
         }
         // scalar tail (n % W elements): the last workgroup's first lane
@@ -337,7 +337,7 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
         if (int rc = lease.take(blocks + blocks / kGroupTarget + 2, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
     hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
-                       static_cast<T *>(out_native), stream_reads((MODE == kSum ? 1 : 2) * n * sizeof(T)));
+                       static_cast<T *>(out_native), stream_policy((MODE == kSum ? 1 : 2) * n * sizeof(T), MODE == kFused ? n * sizeof(T) : 0));
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
     return launch_finish<T, MODE != kDot>(partials, blocks, out8, static_cast<T *>(out_native), s);
