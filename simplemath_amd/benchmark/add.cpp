@@ -6,6 +6,7 @@
 // 2's size (N = 2^28) with the achieved HBM rate.
 #include <sm.h>
 
+#include <string>
 #include <vector>
 
 #include "minibench.h"
@@ -46,6 +47,26 @@ int main() {
         char extra[96];
         std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s (12 B/elem)", n / r.ns_per_iter, 12.0 * n / r.ns_per_iter);
         print(r, extra);
+    }
+    {
+        // An operator CHAIN on resident arrays -- every operator reads what the previous one wrote (temporaries come from
+        // and go back to the device pool): (A * row + B) * 0.5f on 4096 x 4096, 28 bytes per element over the three
+        // launches.  SMHIP_STORE_POLICY=nt in the environment shows it without the write-side policy.
+        // 2048 x 4096: the five arrays alive at a time (160 MiB) fit the Infinity Cache; 4096 x 4096: they do not (320 MiB).
+        for (const std::size_t rows : {std::size_t(2048), std::size_t(4096)}) {
+            const std::size_t cols = 4096, n = rows * cols;
+            const sm::SMArray<float> A = sm::ones<float>(rows, cols), B = sm::ones<float>(rows, cols), row = sm::ones<float>(1, cols);
+            auto r = run("chain_check/" + std::to_string(rows) + "x4096", [&] {
+                auto t1 = A * row;
+                auto t2 = t1 + B;
+                auto t3 = t2 * 0.5f;
+                DoNotOptimize(t3);
+                ClobberMemory();
+            }, sync, 200);
+            char extra[112];
+            std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s (28 B/elem over 3 launches)", n / r.ns_per_iter, 28.0 * n / r.ns_per_iter);
+            print(r, extra);
+        }
     }
     {
         // The host-pointer loop template (include/math/calculate.h), i.e. the boundary handing over HOST buffers:

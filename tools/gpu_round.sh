@@ -22,7 +22,9 @@ f=$(find $out/prof_add -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head
 for wl in bcast_mul pow add_sum transpose_add; do bash tools/prof_wl.sh $tag $wl --steps 200 > $out/prof_$wl.txt 2>&1; tail -3 $out/prof_$wl.txt | cut -c1-300; done
 bash tools/pmc_traffic.sh $tag add bcast_mul pow add_sum transpose_add > $out/pmc_traffic.txt 2>&1; grep ratio $out/pmc_traffic.txt
 bash tools/pmc_sq.sh $tag add pow bcast_mul add_sum > $out/pmc_sq.txt 2>&1; grep "workload\|of the wave\|INSTS_VALU" $out/pmc_sq.txt
-timeout -k 10 100 simplemath_amd/bin/benchmark_add > $out/cpp_benchmarks.txt 2>&1; timeout -k 10 100 simplemath_amd/bin/benchmark_pow >> $out/cpp_benchmarks.txt 2>&1; cat $out/cpp_benchmarks.txt
+timeout -k 10 100 simplemath_amd/bin/benchmark_add > $out/cpp_benchmarks.txt 2>&1; timeout -k 10 100 simplemath_amd/bin/benchmark_pow >> $out/cpp_benchmarks.txt 2>&1
+echo "with SMHIP_STORE_POLICY=nt (results always stored non-temporally):" >> $out/cpp_benchmarks.txt
+SMHIP_STORE_POLICY=nt timeout -k 10 100 simplemath_amd/bin/benchmark_add 2>&1 | grep chain_check >> $out/cpp_benchmarks.txt; cat $out/cpp_benchmarks.txt
 timeout -k 10 200 python tools/op_matrix.py > $out/op_matrix.txt 2>&1
 timeout -k 10 200 python tools/bcast_matrix.py > $out/bcast_matrix.txt 2>&1
 timeout -k 10 200 python tools/reduce_rates.py > $out/reduce_rates.txt 2>&1
