@@ -212,8 +212,102 @@ struct StridedParams {
     uint32_t nt;      // non-temporal reads: the launch fetches more lines than the Infinity Cache holds
 };
 
+// Stride 2 (with the other side stepping by 2 as well, dense, or one value per row) has a lane mapping of its own.  In the
+// general form above lane l loads vectors 2l and 2l+1 of the row: each load INSTRUCTION then touches every line of the
+// wave's span and uses half of it.  Here a wave owns 64 W consecutive outputs = 128 input vectors, lane l loads vectors l
+// and l + 64 -- two fully contiguous instructions -- keeps the W/2 even elements of each, and stores two half-vectors:
+// outputs [l W/2, +W/2) and [32 W + l W/2, +W/2) of the chunk, again contiguous across the lanes.  No shuffles, every line
+// requested by one instruction.  (StridedParams: vpr = chunks per row, slots = rows x chunks; a chunk is
+// kStrided2Groups x 32 W outputs.)
+#ifndef SMHIP_STRIDED2_U
+#define SMHIP_STRIDED2_U 1
+#endif
+constexpr int kStrided2Groups = 2 * SMHIP_STRIDED2_U;  // groups of W/2 outputs per lane; a wave owns 32 W of them per group
+template <typename T, typename Op, int SA, int SB>
+__device__ __forceinline__ void strided2_row_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, StridedParams p) {
+    constexpr int W = VecTraits<T>::width, H = W / 2, G = kStrided2Groups;
+    typedef typename VecTraits<T>::vec_t V;
+    typedef typename VecTraits<T>::half_t HV;
+    typedef typename VecTraits<T>::half_full_t HF;
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (chunk >= p.slots) return;
+    uint32_t row, c;
+    p.vpr.divmod(chunk, row, c);
+    int64_t offA = 0, offB = 0;
+    {
+        uint32_t rem = row;
+        for (int k = 0; k < p.n_outer - 1; ++k) {
+            uint32_t q, idx;
+            p.shape[k].divmod(rem, q, idx);
+            rem = q;
+            offA += (int64_t)idx * p.sa[k];
+            offB += (int64_t)idx * p.sb[k];
+        }
+        if (p.n_outer > 0) {
+            offA += (int64_t)rem * p.sa[p.n_outer - 1];
+            offB += (int64_t)rem * p.sb[p.n_outer - 1];
+        }
+    }
+    T *orow = out + (size_t)row * p.inner;
+    const uint32_t o0 = c * (32u * W * G) + lane * H;  // the lane's first group of H outputs; the others follow 32 W apart
+    // strictly inside the row: a strided vector reads one element past its last kept one, which then still belongs to the
+    // row (the row's last outputs are done element by element)
+    if (o0 + 32u * W * (G - 1) + H < p.inner) {
+        T xa[G][H], xb[G][H];
+        auto fetch = [&](const T *base, auto stride_tag, auto nt_tag, uint32_t o, T (&dst)[H]) {
+            constexpr int S = decltype(stride_tag)::value;
+            if constexpr (S == 0) {
+                const T v = *base;
+#pragma unroll
+                for (int k = 0; k < H; ++k) dst[k] = v;
+            } else if constexpr (S == 1) {  // the dense side: a half-vector, non-temporal whatever the read policy
+                const HF v = __builtin_nontemporal_load(reinterpret_cast<const HV *>(base + o));
+#pragma unroll
+                for (int k = 0; k < H; ++k) dst[k] = v[k];
+            } else {
+                const V v = load_stream_as(T, reinterpret_cast<const V *>(base + (int64_t)o * 2), decltype(nt_tag)::value);
+#pragma unroll
+                for (int k = 0; k < H; ++k) dst[k] = v[2 * k];
+            }
+        };
+        if (p.nt & kLoadNt) {  // ONE branch around all the loads of the lane (see load_stream_as)
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(a + offA, IntTag<SA>{}, BoolTag<true>{}, o0 + 32u * W * g, xa[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(b + offB, IntTag<SB>{}, BoolTag<true>{}, o0 + 32u * W * g, xb[g]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(a + offA, IntTag<SA>{}, BoolTag<false>{}, o0 + 32u * W * g, xa[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(b + offB, IntTag<SB>{}, BoolTag<false>{}, o0 + 32u * W * g, xb[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            T res[H];
+            apply_n<Op, T, H>(ctx, xa[g], xb[g], res);
+            HF r;
+#pragma unroll
+            for (int k = 0; k < H; ++k) r[k] = res[k];
+            __builtin_nontemporal_store(r, reinterpret_cast<HV *>(orow + o0 + 32u * W * g));
+        }
+    } else {
+        for (int g = 0; g < G; ++g)
+            for (uint32_t k = 0; k < (uint32_t)H; ++k) {
+                const uint32_t o = o0 + 32u * W * g + k;
+                if (o < p.inner) orow[o] = Op::apply(a[offA + (int64_t)o * SA], b[offB + (int64_t)o * SB]);
+            }
+    }
+}
+
 template <typename T, typename Op, int SA, int SB>
 __device__ __forceinline__ void strided_row_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, StridedParams p) {
+    if constexpr ((SA == 2 || SB == 2) && SA <= 2 && SB <= 2) {
+        strided2_row_body<T, Op, SA, SB>(a, b, out, p);
+        return;
+    }
     constexpr int W = VecTraits<T>::width;
     typedef typename VecTraits<T>::vec_t V;
     OpCtx<Op> ctx;

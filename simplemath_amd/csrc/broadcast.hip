@@ -311,6 +311,14 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             }
             p.vpr = FastDiv((uint32_t)vpr);
             p.slots = (uint32_t)(rows * vpr);
+            size_t blocks = (rows * vpr + 255) / 256;
+            if (big == 2) {  // strided2_row_body: a WAVE owns 64 W consecutive outputs of a row, four waves per workgroup
+                const size_t per_chunk = (size_t)32 * W * kStrided2Groups;
+                const size_t cpr = ((size_t)inner + per_chunk - 1) / per_chunk;
+                p.vpr = FastDiv((uint32_t)cpr);
+                p.slots = (uint32_t)(rows * cpr);
+                blocks = (rows * cpr + 3) / 4;
+            }
             {   // lines fetched: a strided operand touches `stride` times its elements
                 size_t da = 1, db = 1;
                 for (int d = 0; d < nd - 1; ++d) {
@@ -324,7 +332,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             L->kind = Launch::kStrided;
             L->ia = (int)ia;
             L->ib = (int)ib;
-            L->grid = (unsigned)((rows * vpr + 255) / 256);
+            L->grid = (unsigned)blocks;
             return SMHIP_OK;
         }
     }
