@@ -22,6 +22,19 @@ f32 = C.c_int(0)
 one = C.c_float(1.0000001)
 print("%-44s %8s %10s %10s" % ("case", "MiB", "same", "chain"))
 def row(name, mib, byts, same, chain): print("%-44s %8d %7.1f us %5.1f%% %7.1f us %5.1f%%" % (name, mib, same, byts / same * 1e-3 / 80, chain, byts / chain * 1e-3 / 80), flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "rotate":
+    # cold operands: launches walk K different (a, out) pairs, K x 2 x size >= 2 GiB, so nothing a launch reads or writes
+    # was touched recently -- the setting the read / write policies are NOT tuned for
+    print("%-44s %8s %10s" % ("case (rotating operands)", "MiB", "rotate"))
+    for mib in (32, 64, 128):
+        n = mib << 18
+        K = max(2, 1024 // mib)
+        srcs = [lib.uniform_f32(n, 10 + k, 0.5, 2.0) for k in range(K)]; dsts = [lib.empty((n,), np.float32) for _ in range(K)]
+        fns = [(lambda s_, d_: (lambda: lib.c.smhip_array_scalar(C.c_int(2), f32, C.c_void_p(s_.ptr), C.byref(one), C.c_size_t(n), C.c_void_p(d_.ptr))))(srcs[k], dsts[k]) for k in range(K)]
+        t = timeit(fns, steps=3 * K)
+        print("%-44s %8d %7.1f us %5.1f%%" % ("a * s (array_scalar), K = %d pairs" % K, mib, t, 8.0 * n / t * 1e-3 / 80), flush=True)
+        del srcs, dsts, fns; lib.pool_trim()
+    sys.exit(0)
 for mib in (16, 32, 64, 128, 256):
     n = mib << 18
     a = lib.uniform_f32(n, 1, 0.5, 2.0); b = lib.uniform_f32(n, 2, 0.5, 2.0); c = lib.empty((n,), np.float32)
