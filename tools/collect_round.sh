@@ -16,4 +16,5 @@ cp $src/cpp_benchmarks.txt ${pre}_cpp_benchmarks.txt
 [ -s $src/small_breakdown.txt ] && ! grep -q "failed to run" $src/small_breakdown.txt && cp $src/small_breakdown.txt ${pre}_small_array_breakdown.txt
 for t in op_matrix bcast_matrix reduce_rates misc_rates pow_shapes pow_exhaustive; do cp $src/$t.txt ${pre}_$t.txt; done
 for t in chain_rates pow64_rate tile_modes; do [ -s $src/$t.txt ] && cp $src/$t.txt ${pre}_${t}_final.txt; done
+[ -s $src/pitch_views.txt ] && cp $src/pitch_views.txt ${pre}_pitch_views.txt
 echo collected

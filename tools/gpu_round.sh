@@ -33,6 +33,7 @@ timeout -k 10 100 python tools/pow_shapes.py > $out/pow_shapes.txt 2>&1
 timeout -k 10 200 python tools/chain_rates.py > $out/chain_rates.txt 2>&1
 timeout -k 10 200 python tools/pow64_rate.py > $out/pow64_rate.txt 2>&1
 timeout -k 10 100 python tools/tile_modes.py > $out/tile_modes.txt 2>&1
+timeout -k 10 100 python tools/pitch_views.py > $out/pitch_views.txt 2>&1
 bash tools/pmc_sq_pow_shapes.sh $tag > $out/pmc_sq_pow_shapes.txt 2>&1
 mkdir -p tools/bin && g++ -std=c++20 -O2 -Iinclude tools/small_breakdown.cpp -Lsimplemath_amd/lib -lsmhip -Wl,-rpath,$PWD/simplemath_amd/lib -o tools/bin/small_breakdown 2> $out/small_breakdown_build.log \
   && timeout -k 10 100 tools/bin/small_breakdown > $out/small_breakdown.txt 2>&1
