@@ -755,6 +755,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         }
     }
     const bool heavy = op == SMHIP_OP_POW && (dtype == SMHIP_F32 || dtype == SMHIP_F64);  // as launch_aot's kRows: float / double pow only
+    if (heavy && pl.ndim == 2 && pl.sa[0] == pl.shape[1] && pl.sa[1] == 1 && pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) == 0 &&
+        ((pl.sb[0] == 0 && pl.sb[1] == 1) || (pl.sb[0] == 1 && pl.sb[1] == 0))) {
+        // config 3's shape with pow: a dense base against one row / one column of exponents takes the heavy tile kernel
+        return launch_pow_rows(dtype, a, b, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sb[0] == 0, s);
+    }
     Launch L;
     if (int rc = plan_launch(pl, (int)dtype_size(dtype), heavy, &L)) return rc;
     if (user) return jit_launch(op, dtype, L, a, b, out, s);

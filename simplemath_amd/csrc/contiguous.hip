@@ -114,9 +114,14 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
 constexpr int kTileBlock = 256;
 // KEEP_STORES: the write side's policy (ops.hip.h: store_stream_if) as a template parameter -- as a run-time branch in
 // front of each store it cut the arithmetic of the tile's vectors apart (config 4: 73.2 -> 79.0 us).
+// KIND 0: a op b, 1: a op s, 2: s op a; 3 / 4: a dense (rows x cols) against ONE ROW / ONE COLUMN of b -- config 3's shape
+// with a heavy Op.  cv = cols / W; b's vector for output vector i is b[i mod cv] (read through the caches: every workgroup
+// wants the same few KiB), resp. the single element b[i / cv].  Through the row kernel this shape paid ~35 vector
+// instructions per wave of index arithmetic on top of pow's 257 and staged the tables before its loads: 23.9 us at
+// 4096 x 4096 against 21.x us here (profiles/r02_pmc_sq_pow_shapes.txt).
 template <typename T, typename Op, int KIND, int U, bool KEEP_STORES>
 __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
-                                                                T *__restrict__ out, size_t n_vec, int tail, int nt) {
+                                                                T *__restrict__ out, size_t n_vec, int tail, int nt, FastDiv cv) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
@@ -124,8 +129,22 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
     V *ov = reinterpret_cast<V *>(out);
     const size_t base = (size_t)blockIdx.x * (kTileBlock * U) + threadIdx.x;
     auto eval = [&](const V &xa, const V &xb) {
-        if constexpr (KIND == 0) return apply_vec<Op, T>(ctx, xa, xb);
+        if constexpr (KIND == 0 || KIND >= 3) return apply_vec<Op, T>(ctx, xa, xb);
         else return apply_vec_scalar<Op, T, KIND == 2>(ctx, xa, s);
+    };
+    // the broadcast operand's vector for output vector i (KIND 3 / 4; launches of those kinds stay below 2^32 vectors)
+    auto bcast = [&](size_t i) {
+        uint32_t q, r;
+        cv.divmod((uint32_t)i, q, r);
+        V v;
+        if constexpr (KIND == 3) {
+            v = bv[r];
+        } else {
+            const T y = b[q];
+#pragma unroll
+            for (int k = 0; k < W; ++k) v[k] = y;
+        }
+        return v;
     };
     // The Op's tables (a round trip to the L2, LDS writes and a barrier: OpCtx) are fetched first and committed after a
     // full tile's own loads have gone out, so the two latencies overlap instead of adding up -- this one-shot form
@@ -143,6 +162,7 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             for (int u = 0; u < U; ++u) {
                 va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, true);
                 if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * kTileBlock, true);
+                if constexpr (KIND >= 3) vb[u] = bcast(base + (size_t)u * kTileBlock);
             }
             ctx.template commit<kTileBlock>(staged);
         } else {
@@ -150,11 +170,12 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             for (int u = 0; u < U; ++u) {
                 va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, false);
                 if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * kTileBlock, false);
+                if constexpr (KIND >= 3) vb[u] = bcast(base + (size_t)u * kTileBlock);
             }
             ctx.template commit<kTileBlock>(staged);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * kTileBlock, eval(va[u], KIND == 0 ? vb[u] : va[u]), !KEEP_STORES);
+        for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * kTileBlock, eval(va[u], (KIND == 0 || KIND >= 3) ? vb[u] : va[u]), !KEEP_STORES);
         return;
     }
     ctx.template commit<kTileBlock>(staged);
@@ -162,14 +183,16 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
         const size_t i = base + (size_t)u * kTileBlock;
         if (i < n_vec) {
             const V va = load_stream(av + i);
-            const V vb = KIND == 0 ? load_stream(bv + i) : va;
+            V vb = va;
+            if constexpr (KIND == 0) vb = load_stream(bv + i);
+            if constexpr (KIND >= 3) vb = bcast(i);
             store_stream(ov + i, eval(va, vb));
         }
     }
     if (threadIdx.x == 0) {
         for (int k = 0; k < tail; ++k) {
             const T x = a[n_vec * W + k];
-            const T y = KIND == 0 ? b[n_vec * W + k] : s;
+            const T y = KIND == 0 ? b[n_vec * W + k] : s;  // KIND 3 / 4 have no tail: cols is a multiple of W
             out[n_vec * W + k] = KIND == 2 ? Op::apply(y, x) : Op::apply(x, y);
         }
     }
@@ -207,8 +230,31 @@ void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int ta
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
     const int nt = stream_policy((KIND == 0 ? 2 : 1) * n_vec * 16, n_vec * 16);
-    if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
-    else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
+    if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
+    else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
+}
+
+// a (rows x cols, dense) op one row / one column of b, for the heavy Ops (KIND 3 / 4 of heavy_tile_kernel)
+template <typename T, typename Op>
+int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    constexpr int U = HeavyTile<T, 0>::value;  // per-lane exponents: the array form's tile
+    const size_t n_vec = rows * (cols / W);
+    const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;
+    const int nt = stream_policy(rows * cols * sizeof(T), rows * cols * sizeof(T));
+    const FastDiv cv((uint32_t)(cols / W));
+    const T *pa = static_cast<const T *>(a), *pb = static_cast<const T *>(b);
+    T *po = static_cast<T *>(out);
+    const dim3 grid((unsigned)tiles), block(kTileBlock);
+    if (b_is_row) {
+        if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 3, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+    } else {
+        if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 4, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 4, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+    }
+    SMHIP_LAUNCH_CHECK("heavy rows");
+    return SMHIP_OK;
 }
 
 inline int grid_for(size_t threads, int block, unsigned *grid) {
@@ -338,6 +384,16 @@ int launch_contiguous(int op, int dtype, const void *a, const void *b, void *out
     SMHIP_DISPATCH(F)
 #undef F
     return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
+}
+
+// pow of a dense (rows x cols) base by one row / one column of exponents, f32 / f64 (broadcast.hip routes that shape here)
+int launch_pow_rows(int dtype, const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
+    if (rows == 0 || cols == 0) return SMHIP_OK;
+    switch (dtype) {
+        case SMHIP_F32: return run_heavy_rows<float, PowOp<float>>(a, b, out, rows, cols, b_is_row, s);
+        case SMHIP_F64: return run_heavy_rows<double, PowOp<double>>(a, b, out, rows, cols, b_is_row, s);
+    }
+    return fail(SMHIP_ERR_INVALID, "pow rows: bad dtype %d", dtype);
 }
 
 int launch_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s) {

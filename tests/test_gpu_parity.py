@@ -275,6 +275,30 @@ def test_broadcast_pow_vs_oracle(smhip, oracle):
     assert np.array_equal(got, oracle.binary(orc.POW, ib, ie))
 
 
+def test_pow_by_a_row_or_column_of_exponents(smhip):
+    """Config 3's shape with pow -- a dense base against ONE ROW or ONE COLUMN of exponents -- takes the heavy tile kernel
+    (KIND 3 / 4 of heavy_tile_kernel): f32 and f64, extents that end inside a tile, that span many tiles, a single row, and
+    special exponents in the broadcast operand; against numpy's correctly rounded power."""
+    rng = np.random.default_rng(91)
+    for dt, ulp_of, bar in ((np.float32, orc.ulp_diff_f32, POW_ULP), (np.float64, None, 1)):
+        w = 16 // np.dtype(dt).itemsize
+        for rows, cols in ((37, 16 * w), (300, 256 * w), (1, 64 * w), (1025, 4 * w), (513, 130 * w)):
+            base = rng.uniform(0.05, 30.0, (rows, cols)).astype(dt)
+            for eshape in ((1, cols), (rows, 1)):
+                e = rng.uniform(-3.0, 3.0, eshape).astype(dt)
+                flat = e.reshape(-1)
+                for k, special in enumerate((0.0, 1.0, 2.0, -1.0, 0.5, 3.0, -0.0)):
+                    flat[(k * 5) % flat.size] = special
+                got = smhip.binary(sma.OP_POW, smhip.to_device(base), smhip.to_device(e)).numpy()
+                with np.errstate(all="ignore"):
+                    exact = np.power(base.astype(np.longdouble), e.astype(np.longdouble)).astype(dt)
+                if ulp_of is not None:
+                    assert ulp_of(got, exact).max() <= bar, (dt, rows, cols, eshape)
+                else:
+                    d = np.abs(got.view(np.int64) - exact.view(np.int64))
+                    assert d.max() <= bar, (dt, rows, cols, eshape)
+
+
 def test_transposed_and_permuted_views(smhip, oracle):
     """Operands whose contiguous axis is not the output's inner axis go through the LDS tile
     kernel; patch edges, both operands transposed, permuted 3-D / 4-D views,
