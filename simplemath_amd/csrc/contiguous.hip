@@ -133,17 +133,16 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
         else return apply_vec_scalar<Op, T, KIND == 2>(ctx, xa, s);
     };
     // the broadcast operand's vector for output vector i (KIND 3 / 4; launches of those kinds stay below 2^32 vectors)
-    auto bcast = [&](size_t i) {
+    auto bcast_row = [&](size_t i) {
         uint32_t q, r;
         cv.divmod((uint32_t)i, q, r);
+        return bv[r];
+    };
+    auto bcast_col = [&](size_t i) { return b[cv.div((uint32_t)i)]; };
+    auto splat = [](T y) {
         V v;
-        if constexpr (KIND == 3) {
-            v = bv[r];
-        } else {
-            const T y = b[q];
 #pragma unroll
-            for (int k = 0; k < W; ++k) v[k] = y;
-        }
+        for (int k = 0; k < W; ++k) v[k] = y;
         return v;
     };
     // The Op's tables (a round trip to the L2, LDS writes and a barrier: OpCtx) are fetched first and committed after a
@@ -153,6 +152,7 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
     ctx.template fetch<kTileBlock>(staged);
     const bool full = (size_t)(blockIdx.x + 1) * (kTileBlock * U) <= n_vec;  // uniform over the workgroup
     V va[U], vb[U];
+    T ys[U];  // KIND 4: the rows' exponents, splat only after the tables are committed
     if (full) {
         // the commit sits inside each arm of the read-policy branch, in straight-line code behind the tile's loads, so
         // that the wait in front of its LDS writes is a counted one (vmcnt = the tile's loads still in flight); past a
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             for (int u = 0; u < U; ++u) {
                 va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, true);
                 if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * kTileBlock, true);
-                if constexpr (KIND >= 3) vb[u] = bcast(base + (size_t)u * kTileBlock);
+                if constexpr (KIND == 3) vb[u] = bcast_row(base + (size_t)u * kTileBlock);
+                if constexpr (KIND == 4) ys[u] = bcast_col(base + (size_t)u * kTileBlock);
             }
             ctx.template commit<kTileBlock>(staged);
         } else {
@@ -170,9 +171,19 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             for (int u = 0; u < U; ++u) {
                 va[u] = load_stream_as(T, av + base + (size_t)u * kTileBlock, false);
                 if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * kTileBlock, false);
-                if constexpr (KIND >= 3) vb[u] = bcast(base + (size_t)u * kTileBlock);
+                if constexpr (KIND == 3) vb[u] = bcast_row(base + (size_t)u * kTileBlock);
+                if constexpr (KIND == 4) ys[u] = bcast_col(base + (size_t)u * kTileBlock);
             }
             ctx.template commit<kTileBlock>(staged);
+        }
+        if constexpr (KIND == 4) {
+            // the per-row exponents become visible to the optimiser only here: otherwise it hoists the exponent-only part of
+            // pow above the commit's barrier and waits for every load of the tile in front of it (vmcnt(0) instead of a count)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                asm volatile("" : "+v"(ys[u]));
+                vb[u] = splat(ys[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * kTileBlock, eval(va[u], (KIND == 0 || KIND >= 3) ? vb[u] : va[u]), !KEEP_STORES);
@@ -185,7 +196,8 @@ __global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restr
             const V va = load_stream(av + i);
             V vb = va;
             if constexpr (KIND == 0) vb = load_stream(bv + i);
-            if constexpr (KIND >= 3) vb = bcast(i);
+            if constexpr (KIND == 3) vb = bcast_row(i);
+            if constexpr (KIND == 4) vb = splat(bcast_col(i));
             store_stream(ov + i, eval(va, vb));
         }
     }
