@@ -1018,6 +1018,17 @@ def test_fuzz_views_smoke(smhip):
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
+def test_fuzz_policy_smoke(smhip):
+    """A short run of tests/fuzz_policy.py: random Ops on 4-70 MiB arrays, i.e. footprints on both sides of the stream-policy
+    thresholds, through every kernel family that takes the policy word (3 x 160 cases ran clean when it last changed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_policy.py"), "20", "17"], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "ok: 20 policy cases" in r.stdout, r.stdout + r.stderr
+
+
 def test_device_copy(smhip):
     """smhip_copy: word-sized copies run through the streaming kernel, anything else through the runtime's memcpy."""
     src = gen.gen(np.int32, 100003, 111, "wide")
