@@ -204,6 +204,17 @@ def cpu_baseline(wl, log2n):
         res.update(kind="port", value=r["best"], cores=cores, one_core=r["shipped"],
                    note="the reference's float pow has no array body that links (pow.h:12-13); its arithmetic is PowOp<float>::apply = "
                         "std::pow per element (pow.h:8-10), run here as array_scalar_op's OpenMP loop would (calculate.h:152) on all usable cores")
+    elif wl == "transpose_add":
+        rows = cols = 2048  # a 2048 x 2048 sample of the 8192 x 8192 workload: the reference's loop takes ~1 s per call at full size
+        o.set_threads(cores)
+        A, B = o.uniform_f32(rows * cols, 1, -1.0, 1.0), o.uniform_f32(rows * cols, 2, -1.0, 1.0)
+        res["sample"] = "A.T + B on 2048 x 2048 float32 (1/16 of the 8192 x 8192 workload), seeds 1/2"
+        eng = ref if ref is not None else o
+        fn = lambda: eng.elementwise(orc.ADD, A, [1, cols], B, [cols, 1], [rows, cols])
+        r = both(fn, cores, fn, rows * cols, reps=3)
+        res.update(kind="reference" if ref is not None else "port", value=r["best"], cores=cores,
+                   note="element_wise_op<float, AddOp> (calculate.h:5-99) with the transposed view's strides {1, cols}: the general "
+                        "scalar loop, OpenMP over 1024-element chunks on all usable cores, result allocated per call")
     else:
         return None
     try:
