@@ -38,7 +38,9 @@ def test_cpu_baseline_for_the_other_configs(oracle):
     assert r["value"] > 0 and r["one_core"] > 0 and r["cores"] == r["usable_cores"] and "std::pow" in r["note"]
     r = b.cpu_baseline("add_sum", 18)
     assert r["value"] > 0 and r["best_effort"]["value"] > 0 and "seeds 6/7" in r["sample"]
-    assert b.cpu_baseline("transpose_add", 16) is None
+    r = b.cpu_baseline("transpose_add", 16)   # the reference's general loop on a transposed view (a 2048 x 2048 sample)
+    assert r["value"] > 0 and r["cores"] == r["usable_cores"] and "2048 x 2048" in r["sample"] and "calculate.h:5-99" in r["note"]
+    assert b.cpu_baseline("no_such_workload", 16) is None
 
 
 def test_usable_cores_accounts_for_quota(monkeypatch):
