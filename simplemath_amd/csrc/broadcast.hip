@@ -643,7 +643,11 @@ __global__ __launch_bounds__(256) void strided_copy_kernel(const T *__restrict__
     const uint32_t e0 = col * W;
     if constexpr (VEC) {
         if (e0 + W <= p.inner) {
+#ifdef SMHIP_COPY_PLAIN_STORES
             *reinterpret_cast<V *>(dst + offD + e0) = load_stream_if(T, reinterpret_cast<const V *>(src + offS + e0), p.nt);
+#else
+            store_stream_if(T, reinterpret_cast<V *>(dst + offD + e0), load_stream_if(T, reinterpret_cast<const V *>(src + offS + e0), p.nt), p.nt);
+#endif
         } else {
             for (uint32_t e = e0; e < p.inner; ++e) dst[offD + e] = src[offS + e];
         }
@@ -674,7 +678,9 @@ int run_copy_strided(const void *src_, void *dst_, const Plan &pl, hipStream_t s
     const size_t slots = pl.n / (size_t)p.inner * per_row;
     p.slots_per_row = FastDiv((uint32_t)per_row);
     p.slots = (uint32_t)slots;
-    p.nt = (uint32_t)stream_reads(2 * pl.n * sizeof(T));  // its stores are plain (partial lines want the L2's write combining): they occupy the cache too
+    // the element form's stores are plain (partial lines want the L2's write combining) and occupy the cache too; the
+    // vector form (rows contiguous on both sides) streams like the row kernel: nt / sc1 stores by the launch's footprint
+    p.nt = vec ? (uint32_t)stream_policy(pl.n * sizeof(T), pl.n * sizeof(T)) : (uint32_t)stream_reads(2 * pl.n * sizeof(T));
     const unsigned grid = (unsigned)((slots + 255) / 256);
     if (vec) hipLaunchKernelGGL((strided_copy_kernel<T, true>), dim3(grid), dim3(256), 0, s, src, dst, p);
     else hipLaunchKernelGGL((strided_copy_kernel<T, false>), dim3(grid), dim3(256), 0, s, src, dst, p);
