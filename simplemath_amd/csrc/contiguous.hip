@@ -28,6 +28,8 @@ namespace {
 
 using namespace dev;
 
+static_assert(kLoadNt == kPolicyLoadNt && kStoreKeep == kPolicyStoreKeep, "device and host disagree on the stream-policy bits");
+
 constexpr int kBlockBig = 1024;   // n_vec >= kBigThreshold
 constexpr int kBlockSmall = 256;
 constexpr size_t kBigThreshold = (size_t)1 << 20;

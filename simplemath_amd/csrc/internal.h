@@ -78,6 +78,7 @@ inline int stream_reads(size_t bytes_read) { return bytes_read > kInfinityCacheB
 // faster one in every setting of tools/sweep_store_sc1.hip; from 48 MiB (2R+1W of 16 MiB) on the `sc1` store wins.
 // SMHIP_STORE_POLICY=nt switches the rule off (experiments).
 constexpr size_t kStoreKeepFloor = (size_t)40 << 20;
+constexpr int kPolicyLoadNt = 1, kPolicyStoreKeep = 2;  // the word's bits; ops.hip.h (dev::kLoadNt / kStoreKeep) and jit.hip's preludes mirror them
 int stream_policy(size_t bytes_read, size_t bytes_written);
 
 inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }

@@ -286,9 +286,9 @@ int current_device() { return tls.device < 0 ? 0 : tls.device; }
 
 int stream_policy(size_t bytes_read, size_t bytes_written) {
     static const bool stores_always_nt = [] { const char *e = getenv("SMHIP_STORE_POLICY"); return e && strcmp(e, "nt") == 0; }();
-    int policy = stream_reads(bytes_read);  // bit 0: dev::kLoadNt
+    int policy = stream_reads(bytes_read) ? kPolicyLoadNt : 0;
     const size_t footprint = bytes_read + bytes_written;
-    if (!stores_always_nt && footprint >= kStoreKeepFloor && footprint <= kInfinityCacheBytes) policy |= 2;  // dev::kStoreKeep
+    if (!stores_always_nt && footprint >= kStoreKeepFloor && footprint <= kInfinityCacheBytes) policy |= kPolicyStoreKeep;
     return policy;
 }
 
