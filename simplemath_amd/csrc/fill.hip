@@ -14,14 +14,14 @@ namespace {
 using namespace dev;
 
 template <typename T>
-__global__ __launch_bounds__(256) void fill_vec_kernel(T *__restrict__ dst, T v, size_t n_vec, size_t n) {
+__global__ __launch_bounds__(256) void fill_vec_kernel(T *__restrict__ dst, T v, size_t n_vec, size_t n, int pol) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     V vv;
 #pragma unroll
     for (int k = 0; k < W; ++k) vv[k] = v;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n_vec) store_stream(reinterpret_cast<V *>(dst) + i, vv);
+    if (i < n_vec) store_stream_if(T, reinterpret_cast<V *>(dst) + i, vv, pol);  // a 40-256 MiB array is born in the Infinity Cache
     else if (i == n_vec)
         for (size_t k = n_vec * W; k < n; ++k) dst[k] = v;
 }
@@ -51,7 +51,7 @@ int run_fill(void *dst, const void *value_host, size_t n, hipStream_t s) {
     const size_t n_vec = n / W;
     const size_t g = (n_vec + 1 + 255) / 256;
     if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fill too large");
-    hipLaunchKernelGGL(fill_vec_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, p, v, n_vec, n);
+    hipLaunchKernelGGL(fill_vec_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, p, v, n_vec, n, stream_policy(0, n * sizeof(T)));
     SMHIP_LAUNCH_CHECK("fill");
     return SMHIP_OK;
 }
