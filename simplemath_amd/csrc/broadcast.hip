@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__
         V r;
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = v[(k * S) / W][(k * S) % W];
-        store_stream(reinterpret_cast<V *>(d), r);
+        store_stream_if(T, reinterpret_cast<V *>(d), r, nt);
     } else {
         for (uint32_t k = 0; e0 + k < inner; ++k) d[k] = s[(int64_t)k * S];
     }
@@ -535,7 +535,7 @@ int run_deinterleave(const void *src, void *out, size_t rows, uint32_t inner, in
     const T *a = static_cast<const T *>(src);
     T *o = static_cast<T *>(out);
     const FastDiv vpr((uint32_t)per_row);
-    const int nt = stream_reads(rows * (size_t)inner * (size_t)stride * sizeof(T));  // the lines it fetches
+    const int nt = stream_policy(rows * (size_t)inner * (size_t)stride * sizeof(T), rows * (size_t)inner * sizeof(T));  // reads: the lines it fetches
     switch (stride) {
         case 2: hipLaunchKernelGGL((deinterleave_kernel<T, 2>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots, nt); break;
         case 3: hipLaunchKernelGGL((deinterleave_kernel<T, 3>), grid, block, 0, s, a, o, pitch, inner, vpr, (uint32_t)slots, nt); break;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void short_rows_kernel(const T *__restrict__ x
         V rv;
 #pragma unroll
         for (int k = 0; k < W; ++k) rv[k] = res[k];
-        store_stream(reinterpret_cast<V *>(out + j0), rv);
+        store_stream_if(T, reinterpret_cast<V *>(out + j0), rv, nt);
     } else {
         for (uint32_t j = j0; j < n; ++j) out[j] = SWAPPED ? Op::apply(y[j / r.d], x[j]) : Op::apply(x[j], y[j / r.d]);
     }
@@ -596,7 +596,7 @@ int run_short_rows(const void *x, const void *y, void *out, size_t rows, uint32_
     const size_t n = rows * r;
     const uint32_t n_vec = (uint32_t)(n / W);
     const dim3 grid((unsigned)(((size_t)n_vec + 1 + 255) / 256)), block(256);
-    const int nt = stream_reads((n + rows) * sizeof(T));
+    const int nt = stream_policy((n + rows) * sizeof(T), n * sizeof(T));
     if (swapped) hipLaunchKernelGGL((short_rows_kernel<T, Op, true>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n, nt);
     else hipLaunchKernelGGL((short_rows_kernel<T, Op, false>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n, nt);
     SMHIP_LAUNCH_CHECK("short_rows_kernel");
