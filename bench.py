@@ -319,7 +319,7 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound):
         out = lib.empty((rows, cols), F32)
         step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([cols, 1]),
                      C.c_void_p(r.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr))
-        return (step, rows * cols, 4 * (2 * rows * cols + cols), "row_kernel<float, MultiplyOp<float>, 1, 1, false, true, 256, 2>",
+        return (step, rows * cols, 4 * (2 * rows * cols + cols), "flat_tile_kernel<float, MultiplyOp<float>, 3, 2, true>",
                 "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident", (A, r, out), {})
     if wl == "transpose_add":
         rows = cols = 8192
@@ -337,7 +337,7 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound):
     exponent = C.c_float(2.5)
     step = bound(lib.c.smhip_array_scalar, C.c_int(sma.OP_POW), C.c_int(sma.F32), C.c_void_p(a.ptr), C.byref(exponent),
                  C.c_size_t(n), C.c_void_p(out.ptr))
-    return (step, n, 8 * n, "heavy_tile_kernel<float, PowOp<float>, 1, 2, false>",
+    return (step, n, 8 * n, "flat_tile_kernel<float, PowOp<float>, 1, 2, false>",
             f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident", (a, out, exponent), {"log2n": log2n})
 
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ void row_body(const T *__restrict__ a, const T *__res
     constexpr int W = VecTraits<T>::width;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int TY = 256 / TX;
-    // (Staging pow's tables behind the rows' loads, as heavy_tile_kernel does with OpCtx's fetch / commit, was measured
+    // (Staging pow's tables behind the rows' loads, as flat_tile_kernel does with OpCtx's fetch / commit, was measured
     // here and made it slower -- 22.7 -> 24.0 us for the 4096 x 4096 row pow: with this body's control flow the commit
     // waits for every load of both rows, where the first row's arithmetic now starts as soon as its own data is in.)
     OpCtx<Op> ctx;

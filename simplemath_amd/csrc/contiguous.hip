@@ -122,7 +122,7 @@ constexpr int kTileBlock = 256;
 // instructions per wave of index arithmetic on top of pow's 257 and staged the tables before its loads: 23.9 us at
 // 4096 x 4096 against 21.x us here (profiles/r02_pmc_sq_pow_shapes.txt).
 template <typename T, typename Op, int KIND, int U, bool KEEP_STORES>
-__global__ __launch_bounds__(kTileBlock) void heavy_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
+__global__ __launch_bounds__(kTileBlock) void flat_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
                                                                 T *__restrict__ out, size_t n_vec, int tail, int nt, FastDiv cv) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
@@ -244,15 +244,20 @@ void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int ta
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
     const int nt = stream_policy((KIND == 0 ? 2 : 1) * n_vec * 16, n_vec * 16);
-    if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
-    else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
+    if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
+    else hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
 }
 
-// a (rows x cols, dense) op one row / one column of b, for the heavy Ops (KIND 3 / 4 of heavy_tile_kernel)
+#ifndef SMHIP_FLAT_ROWS_U
+#define SMHIP_FLAT_ROWS_U 2
+#endif
+// a (rows x cols, dense) op one row / one column of b (KIND 3 / 4 of flat_tile_kernel), every built-in Op
 template <typename T, typename Op>
 int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
-    constexpr int U = HeavyTile<T, 0>::value;  // per-lane exponents: the array form's tile
+    // vectors per lane: the array form's tile for the heavy Ops (per-lane exponents); two for the others, like the row
+    // kernel's two rows per lane
+    constexpr int U = IsHeavy<Op>::value ? HeavyTile<T, 0>::value : SMHIP_FLAT_ROWS_U;
     const size_t n_vec = rows * (cols / W);
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;
     const int nt = stream_policy(rows * cols * sizeof(T), rows * cols * sizeof(T));
@@ -261,11 +266,11 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
     T *po = static_cast<T *>(out);
     const dim3 grid((unsigned)tiles), block(kTileBlock);
     if (b_is_row) {
-        if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
-        else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 3, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
     } else {
-        if (nt & kStoreKeep) hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 4, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
-        else hipLaunchKernelGGL((heavy_tile_kernel<T, Op, 4, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 4, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 4, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
     }
     SMHIP_LAUNCH_CHECK("heavy rows");
     return SMHIP_OK;
@@ -400,14 +405,14 @@ int launch_contiguous(int op, int dtype, const void *a, const void *b, void *out
     return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
 }
 
-// pow of a dense (rows x cols) base by one row / one column of exponents, f32 / f64 (broadcast.hip routes that shape here)
-int launch_pow_rows(int dtype, const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
+// a dense (rows x cols) array against one row / one column of b -- config 3's shape -- through the flat tile kernel
+// (broadcast.hip routes that shape here for the built-in Ops)
+int launch_flat_rows(int op, int dtype, const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
     if (rows == 0 || cols == 0) return SMHIP_OK;
-    switch (dtype) {
-        case SMHIP_F32: return run_heavy_rows<float, PowOp<float>>(a, b, out, rows, cols, b_is_row, s);
-        case SMHIP_F64: return run_heavy_rows<double, PowOp<double>>(a, b, out, rows, cols, b_is_row, s);
-    }
-    return fail(SMHIP_ERR_INVALID, "pow rows: bad dtype %d", dtype);
+#define F(T, OP) run_heavy_rows<T, OP>(a, b, out, rows, cols, b_is_row, s)
+    SMHIP_DISPATCH(F)
+#undef F
+    return fail(SMHIP_ERR_INVALID, "flat rows: bad op %d / dtype %d", op, dtype);
 }
 
 int launch_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s) {

@@ -88,9 +88,9 @@ inline bool valid_op(int op) { return op >= SMHIP_OP_ADD && op <= SMHIP_OP_LEFT;
 // Kernel launchers (one translation unit each).
 int launch_contiguous(int op, int dtype, const void *a, const void *b, void *out, size_t n, hipStream_t s);
 int launch_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out, hipStream_t s);
-// f32 / f64 pow of a dense (rows x cols) base by one row (b_is_row) or one column of exponents; cols a multiple of the
-// 16-byte vector width, rows * cols / width < 2^32
-int launch_pow_rows(int dtype, const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s);
+// a dense (rows x cols) a against one row (b_is_row) or one column of b; cols a multiple of the 16-byte vector width,
+// rows * cols / width < 2^32
+int launch_flat_rows(int op, int dtype, const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s);
 // b is a device pointer to ONE element (a fully broadcast operand); `swapped`
 // computes value op a[i] instead of a[i] op value.
 int launch_array_devscalar(int op, int dtype, const void *a, const void *value_dev, size_t n, void *out,

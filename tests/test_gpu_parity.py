@@ -277,7 +277,7 @@ def test_broadcast_pow_vs_oracle(smhip, oracle):
 
 def test_pow_by_a_row_or_column_of_exponents(smhip):
     """Config 3's shape with pow -- a dense base against ONE ROW or ONE COLUMN of exponents -- takes the heavy tile kernel
-    (KIND 3 / 4 of heavy_tile_kernel): f32 and f64, extents that end inside a tile, that span many tiles, a single row, and
+    (KIND 3 / 4 of flat_tile_kernel): f32 and f64, extents that end inside a tile, that span many tiles, a single row, and
     special exponents in the broadcast operand; against numpy's correctly rounded power."""
     rng = np.random.default_rng(91)
     for dt, ulp_of, bar in ((np.float32, orc.ulp_diff_f32, POW_ULP), (np.float64, None, 1)):

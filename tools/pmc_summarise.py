@@ -11,7 +11,7 @@ import os
 import sys
 from collections import defaultdict
 
-DOMINANT = {"add": "contiguous_vec_kernel", "bcast_mul": "row_kernel", "pow": "heavy_tile_kernel", "add_sum": "reduce_kernel",
+DOMINANT = {"add": "contiguous_vec_kernel", "bcast_mul": "flat_tile_kernel", "pow": "flat_tile_kernel", "add_sum": "reduce_kernel",
             "transpose_add": "tile_kernel"}
 ALGORITHMIC = {"add": 12 * 2 ** 28, "bcast_mul": 4 * (2 * 4096 * 4096 + 4096), "pow": 8 * 2 ** 26, "add_sum": 12 * 2 ** 28,
                "transpose_add": 12 * 8192 * 8192}
