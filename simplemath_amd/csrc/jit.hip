@@ -80,7 +80,7 @@ __device__ __forceinline__ V0 smhip_ld(const V* p, int pol) {
     return SMHIP_JOIN(lo, hi);
 }
 __device__ __forceinline__ void smhip_st(V* p, V0 r, int pol) {
-    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r));
+    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r));
     else __builtin_nontemporal_store(r, p);
 }
 
@@ -139,7 +139,7 @@ __device__ __forceinline__ V0 smhip_ld(const V* p, int pol) {
     return SMHIP_JOIN(lo, hi);
 }
 __device__ __forceinline__ void smhip_st(V* p, V0 r, int pol) {
-    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r));
+    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r));
     else __builtin_nontemporal_store(r, p);
 }
 struct Operands { const T* p[8]; };
@@ -247,7 +247,7 @@ constexpr int kLoadNt = 1, kStoreKeep = 2;  // bits of a launch's stream-policy 
 #define load_stream(ptr) __builtin_nontemporal_load(ptr)
 #define store_stream(ptr, ...) __builtin_nontemporal_store((__VA_ARGS__), (ptr))
 #define store_stream_as(T, ptr, value, NT) do { typedef VecTraits<T> smhip_tr_; typename smhip_tr_::vec_t *smhip_q_ = (ptr); const typename smhip_tr_::full_t smhip_w_ = (value); \
-    if constexpr (NT) { __builtin_nontemporal_store(smhip_w_, smhip_q_); } else { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(smhip_q_), "v"(smhip_w_)); } } while (0)
+    if constexpr (NT) { __builtin_nontemporal_store(smhip_w_, smhip_q_); } else { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(smhip_q_), "v"(smhip_w_)); } } while (0)
 #define store_stream_if(T, ptr, value, pol) do { if ((pol) & kStoreKeep) store_stream_as(T, ptr, value, false); else store_stream_as(T, ptr, value, true); } while (0)
 #define load_stream_as(T, ptr, NT) ({ typedef VecTraits<T> smhip_tr_; const typename smhip_tr_::vec_t *smhip_p_ = (ptr); typename smhip_tr_::full_t smhip_v_; \
     if constexpr (NT) { smhip_v_ = __builtin_nontemporal_load(smhip_p_); } else { const typename smhip_tr_::half_t *smhip_h_ = reinterpret_cast<const typename smhip_tr_::half_t *>(smhip_p_); \

@@ -109,8 +109,12 @@ SMHIP_VEC(int64_t, 2)
 // It keeps the chain rate of a plain store without a plain store's cost in the repeated-operand setting -- 1R+1W at
 // 32 MiB: same / chain 109 / 81 % against 79 / 78 % (plain) and 82 / 64 % (nt); 2R+1W at 16 MiB: 121 / 92 % against
 // 74 / 74 % and 95 / 71 %.  The compiler has no spelling for it on a 16-byte vector (nontemporal = nt, a system-scope
-// atomic store is 8 bytes at most), hence the one-instruction asm; nothing else reads the destination, so it needs no
-// memory clobber, and a wave may end with the store in flight like any other.
+// atomic store is 8 bytes at most), hence the asm; nothing else reads the destination, so it needs no memory clobber, and
+// a wave may end with the store in flight like any other.  The `s_nop 1` behind it is NOT optional: gfx940-class hardware
+// needs two wait states between a VMEM store of more than 8 bytes and a VALU instruction that overwrites the VGPRs holding
+// its data; the compiler inserts them behind stores it can see and cannot see into an asm.  Without them the next vector's
+// multiply overwrote a component the store had not read yet (found by tests/fuzz_policy.py in the column form of the flat
+// tile kernel, where two results are computed into the same registers back to back: every fourth element wrong).
 #define store_stream_as(T, ptr, value, NT)                                                         \
     do {                                                                                           \
         typedef typename ::smhip::dev::VecTraits<T> smhip_tr_;                                     \
@@ -119,7 +123,7 @@ SMHIP_VEC(int64_t, 2)
         if constexpr (NT) {                                                                        \
             __builtin_nontemporal_store(smhip_w_, smhip_q_);                                       \
         } else {                                                                                   \
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(smhip_q_), "v"(smhip_w_));   \
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(smhip_q_), "v"(smhip_w_));   \
         }                                                                                          \
     } while (0)
 #ifdef SMHIP_STORES_ALWAYS_NT  // experiment switch: no branch, no plain arm

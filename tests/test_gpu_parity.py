@@ -1018,6 +1018,28 @@ def test_fuzz_views_smoke(smhip):
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
+def test_keep_store_is_followed_by_its_wait_states(smhip):
+    """Regression: the `sc1` store is an inline asm, and gfx940-class hardware needs two wait states between a 16-byte
+    store and a VALU write of its data registers -- which the compiler cannot insert behind an asm.  The column form of
+    the flat tile kernel computes two results into the same registers back to back; without the `s_nop 1` inside the asm
+    every fourth element of (8192, 672) * (8192, 1) was wrong (found by tests/fuzz_policy.py, seed 52 case 56)."""
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64, np.int32):
+        w = 16 // np.dtype(dt).itemsize
+        for rows, cols in ((8192, 168 * w), (8192, 256 * w), (16384, 168 * w)):
+            if dt == np.int32:
+                a = rng.integers(-1000, 1000, rows * cols, dtype=dt); b = rng.integers(-1000, 1000, rows, dtype=dt)
+            else:
+                a = rng.uniform(0.25, 4.0, rows * cols).astype(dt); b = rng.uniform(0.25, 4.0, rows).astype(dt)
+            da, db = smhip.to_device(a), smhip.to_device(b)
+            A = a.reshape(rows, cols)
+            dA = sma.DeviceArray(smhip, da.base_ptr, dt, (rows, cols), (cols, 1), 0, da._owner)
+            for shape, strides, ref in (((rows, 1), (1, 1), b.reshape(rows, 1)), ((1, cols), (cols, 1), b[:cols].reshape(1, cols))):
+                dB = sma.DeviceArray(smhip, db.base_ptr, dt, shape, strides, 0, db._owner)
+                for op, fn in ((sma.OP_MUL, np.multiply), (sma.OP_ADD, np.add)):
+                    assert np.array_equal(smhip.binary(op, dA, dB).numpy(), fn(A, ref)), (dt, rows, cols, shape, op)
+
+
 def test_fuzz_policy_smoke(smhip):
     """A short run of tests/fuzz_policy.py: random Ops on 4-70 MiB arrays, i.e. footprints on both sides of the stream-policy
     thresholds, through every kernel family that takes the policy word (3 x 160 cases ran clean when it last changed)."""
