@@ -32,11 +32,11 @@ cases = []
 def case(name, shape, sa, sb, off_a=0, off_b=0, op=0, dt=np.float32): cases.append((name, shape, sa, sb, off_a, off_b, op, dt))
 M = 8192
 case("dense (8192,8192) + same              [contig]", (M, M), dense((M, M)), dense((M, M)))
-case("C3 (4096,4096) * (1,4096)              [row]", (4096, 4096), (4096, 1), (0, 1), op=2)
-case("(8192,8192) * (1,8192)                 [row]", (M, M), (M, 1), (0, 1), op=2)
-case("(8192,8192) * (8192,1) column          [row]", (M, M), (M, 1), (1, 0), op=2)
+case("C3 (4096,4096) * (1,4096)              [flat]", (4096, 4096), (4096, 1), (0, 1), op=2)
+case("(8192,8192) * (1,8192)                 [flat]", (M, M), (M, 1), (0, 1), op=2)
+case("(8192,8192) * (8192,1) column          [flat]", (M, M), (M, 1), (1, 0), op=2)
 case("(8192,1) * (1,8192) outer product      [row]", (M, M), (1, 0), (0, 1), op=2)
-case("(64,56,56,256) + (1,1,1,256) bias      [row]", (64, 56, 56, 256), dense((64, 56, 56, 256)), (0, 0, 0, 1))
+case("(64,56,56,256) + (1,1,1,256) bias      [flat]", (64, 56, 56, 256), dense((64, 56, 56, 256)), (0, 0, 0, 1))
 case("(256,224,224,3) + (1,224,1,3) ref test [lds]", (256, 224, 224, 3), dense((256, 224, 224, 3)), (0, 3, 0, 1))
 case("(256,224,224,3) + (1,1,1,3) RGB bias   [lds]", (256, 224, 224, 3), dense((256, 224, 224, 3)), (0, 0, 0, 1))
 case("(16,1024,1024,4) * (16,1,1,4)          [lds]", (16, 1024, 1024, 4), dense((16, 1024, 1024, 4)), (4, 0, 0, 1), op=2)
@@ -50,10 +50,10 @@ case("A[:, ::2] + B[:, ::2] (8192,4096)      [gather]", (M, M // 2), (M, 2), (M,
 case("A[::2, :] + B[::2, :] (4096,8192)      [row]", (M // 2, M), (2 * M, 1), (2 * M, 1))
 case("column A[:,5] + B[:,7] (8192)          [gather]", (M,), (M,), (M,), off_a=5, off_b=7)
 case("(2^24,3) / (2^24,1) per-pixel scale     [short rows]", (1 << 24, 3), (3, 1), (1, 0), op=3)
-case("f64 (8192,4096) * (1,4096)             [row]", (M, 4096), (4096, 1), (0, 1), op=2, dt=np.float64)
+case("f64 (8192,4096) * (1,4096)             [flat]", (M, 4096), (4096, 1), (0, 1), op=2, dt=np.float64)
 case("f64 A.T + B (4096,4096)                [tile]", (4096, 4096), (1, 4096), (4096, 1), dt=np.float64)
-case("i32 (8192,8192) + (1,8192)             [row]", (M, M), (M, 1), (0, 1), dt=np.int32)
-case("pow (4096,4096) ^ (1,4096)             [row]", (4096, 4096), (4096, 1), (0, 1), op=4)
+case("i32 (8192,8192) + (1,8192)             [flat]", (M, M), (M, 1), (0, 1), dt=np.int32)
+case("pow (4096,4096) ^ (1,4096)             [flat]", (4096, 4096), (4096, 1), (0, 1), op=4)
 
 DT = {np.float32: 0, np.float64: 1, np.int32: 2, np.int64: 3}
 print("%-62s %11s %9s %8s %7s" % ("case", "n", "us", "GB/s", "% peak"))
