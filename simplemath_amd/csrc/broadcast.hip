@@ -765,16 +765,18 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
     }
     const bool heavy = op == SMHIP_OP_POW && (dtype == SMHIP_F32 || dtype == SMHIP_F64);  // as launch_aot's kRows: float / double pow only
     if (!user && op != SMHIP_OP_LEFT && pl.ndim == 2 && pl.sa[0] == pl.shape[1] && pl.sa[1] == 1 &&
-        pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) == 0 && pl.shape[1] >= SMHIP_FLAT_ROWS_MIN_COLS &&
-        ((pl.sb[0] == 0 && pl.sb[1] == 1) || (pl.sb[0] == 1 && pl.sb[1] == 0))) {
+        pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) == 0 &&
+        ((pl.sb[0] == 0 && pl.sb[1] == 1) || (pl.sb[0] == 1 && pl.sb[1] == 0 && pl.shape[1] >= SMHIP_FLAT_ROWS_MIN_COLS))) {
+        // (one COLUMN against rows of fewer than 16 elements stays with the short-rows kernel: 82 % there, 74-78 % here;
+        // one ROW of 4 / 8 / 12 elements is faster here than through the LDS kernel: 91 against 88 %)
         // config 3's shape: a dense array against one row / one column takes the flat tile kernel -- output vector i pairs
         // a[i] with b[i mod cols/W] (resp. b[i / (cols/W)]): one fast division per vector instead of the row kernel's
         // per-row index arithmetic.  4096 x 4096 f32: multiply 19.9 -> 19.2 us (84.3 -> 87.4 %), pow 23 -> 20.2 us.
         return launch_flat_rows(op, dtype, a, b, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sb[0] == 0, s);
     }
     if (!user && (op == SMHIP_OP_ADD || op == SMHIP_OP_MUL) && pl.ndim == 2 && pl.sb[0] == pl.shape[1] && pl.sb[1] == 1 &&
-        pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) == 0 && pl.shape[1] >= SMHIP_FLAT_ROWS_MIN_COLS &&
-        ((pl.sa[0] == 0 && pl.sa[1] == 1) || (pl.sa[0] == 1 && pl.sa[1] == 0))) {
+        pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) == 0 &&
+        ((pl.sa[0] == 0 && pl.sa[1] == 1) || (pl.sa[0] == 1 && pl.sa[1] == 0 && pl.shape[1] >= SMHIP_FLAT_ROWS_MIN_COLS))) {
         // the same shape with the roles exchanged (row + A, column * A): + and * commute bit for bit
         return launch_flat_rows(op, dtype, b, a, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sa[0] == 0, s);
     }
