@@ -763,6 +763,50 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
             case SMHIP_F64: case SMHIP_I64: return run_repeat<int64_t>(a, out, (size_t)pl.shape[0], (uint32_t)pl.shape[1], s);
         }
     }
+    // A dense operand against a small one that repeats along the FLAT index -- the reference tests' own pattern,
+    // (N,224,224,3) op (1,224,1,3) (tests/add.cpp:59-92), or a per-channel bias (..., 3) op (3,): every leading axis the small
+    // operand ignores makes its values periodic in the output's linear index, with period P = the product of the axes from
+    // the first one it does not ignore.  The period (made a multiple of the vector width by repeating it) is written out
+    // once -- 588 KiB for the pattern above, L2-resident -- and the problem becomes config 3's shape, rows of P against
+    // one row: the flat tile kernel instead of the LDS kernel's per-vector index chains (88 vector instructions per 16
+    // bytes in round 1).  Writing the period out is a launch of its own (~5 us with its dependency), so only outputs of
+    // 128 MiB and more go this way: (256,224,224,3) + (1,224,1,3) 49.5-52 -> 46.5 us; at half that size it is a wash.
+    if (!user && op != SMHIP_OP_LEFT && pl.ndim >= 2 && pl.n * dtype_size(dtype) >= ((size_t)128 << 20)) {
+        const size_t esz = dtype_size(dtype);
+        const int64_t W = 16 / (int64_t)esz;
+        for (int role = 0; role < 2; ++role) {
+            const int64_t *sx = role == 0 ? pl.sa : pl.sb, *sy = role == 0 ? pl.sb : pl.sa;
+            if (role == 1 && op != SMHIP_OP_ADD && op != SMHIP_OP_MUL) break;  // the small operand on the left: commutative Ops only
+            bool dense = true;
+            int64_t run = 1;
+            for (int d = pl.ndim - 1; d >= 0; --d) {
+                dense &= sx[d] == run;
+                run *= pl.shape[d];
+            }
+            int k = 0;
+            while (k < pl.ndim && sy[k] == 0) ++k;
+            if (!dense || k == 0 || k == pl.ndim) continue;  // x is a view, or y ignores no leading axis, or y is a single value
+            size_t period = 1;
+            for (int d = k; d < pl.ndim; ++d) period *= (size_t)pl.shape[d];
+            size_t rep = 1;
+            while ((period * rep) % (size_t)W) ++rep;  // at most W copies make the period a whole number of vectors
+            const size_t cols = period * rep, rows = pl.n / cols;
+            if (pl.n % cols || rows < 4 || cols * esz > ((size_t)2 << 20)) continue;
+            if (k == pl.ndim - 1 && rep == 1) continue;  // already rows against one row: the flat route below takes it as it is
+            ScratchLease lease;
+            double *tmp8;
+            if (int rc = lease.take((cols * esz + 7) / 8, &tmp8)) return rc;
+            // the period, written out: (rep, shape[k..]) with y's strides (0, sy[k..]) through the LEFT Op (out = a)
+            int64_t eshape[SMHIP_MAX_NDIM + 1], esy[SMHIP_MAX_NDIM + 1], zeros[SMHIP_MAX_NDIM + 1];
+            int en = 0;
+            eshape[en] = (int64_t)rep; esy[en] = 0; zeros[en] = 0; ++en;
+            for (int d = k; d < pl.ndim; ++d) { eshape[en] = pl.shape[d]; esy[en] = sy[d]; zeros[en] = 0; ++en; }
+            const void *x = role == 0 ? a : b, *y = role == 0 ? b : a;
+            const Plan sub = normalise(eshape, esy, zeros, en);
+            if (int rc = launch_plan(SMHIP_OP_LEFT, dtype, y, y, tmp8, sub, s)) return rc;
+            return launch_flat_rows(op, dtype, x, tmp8, out, rows, cols, true, s);
+        }
+    }
     const bool heavy = op == SMHIP_OP_POW && (dtype == SMHIP_F32 || dtype == SMHIP_F64);  // as launch_aot's kRows: float / double pow only
     if (!user && op != SMHIP_OP_LEFT && pl.ndim == 2 && pl.sa[0] == pl.shape[1] && pl.sa[1] == 1 &&
         pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) == 0 &&

@@ -1040,6 +1040,35 @@ def test_keep_store_is_followed_by_its_wait_states(smhip):
                     assert np.array_equal(smhip.binary(op, dA, dB).numpy(), fn(A, ref)), (dt, rows, cols, shape, op)
 
 
+def test_periodic_small_operand_is_written_out_once(smhip):
+    """A dense operand against a small one that ignores the leading axes (the reference tests' (N,224,224,3) op
+    (1,224,1,3), a per-channel bias) at >= 128 MiB: the small operand's period is materialised and the flat tile kernel
+    takes rows of it -- both operand orders, a period that needs repeating to fill a vector, f64, pow; against numpy."""
+    rng = np.random.default_rng(101)
+    def dev(arr): return smhip.to_device(np.ascontiguousarray(arr))
+    x = rng.uniform(0.5, 2.0, (224, 224, 224, 3)).astype(np.float32)             # 128.6 MiB
+    y = rng.uniform(0.5, 2.0, (1, 224, 1, 3)).astype(np.float32)
+    dx, dy = dev(x), dev(y)
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dx, dy).numpy(), x + y)
+    assert np.array_equal(smhip.binary(sma.OP_SUB, dx, dy).numpy(), x - y)
+    assert np.array_equal(smhip.binary(sma.OP_MUL, dy, dx).numpy(), y * x)       # small operand on the left, commutative
+    assert np.array_equal(smhip.binary(sma.OP_SUB, dy, dx).numpy(), y - x)       # ... not commutative: the LDS kernel
+    got = smhip.binary(sma.OP_POW, dx, dy).numpy()
+    want = np.power(x.astype(np.float64), y.astype(np.float64)).astype(np.float32)
+    assert orc.ulp_diff_f32(got.reshape(-1), want.reshape(-1)).max() <= POW_ULP
+    c = rng.uniform(0.5, 2.0, (3,)).astype(np.float32)                           # period 3 -> repeated to 12
+    assert np.array_equal(smhip.binary(sma.OP_DIV, dx, dev(c)).numpy(), x / c)
+    xd = rng.uniform(0.5, 2.0, (170, 224, 224, 2)).astype(np.float64)            # 130 MiB of f64; period 224*224*2
+    yd = rng.uniform(0.5, 2.0, (224, 224, 1)).astype(np.float64)
+    assert np.array_equal(smhip.binary(sma.OP_MUL, dev(xd), dev(yd)).numpy(), xd * yd)
+    xi = rng.integers(-1000, 1000, (4097 * 8, 1024), dtype=np.int32)              # 128 MiB against a plain row: the flat route as before
+    ri = rng.integers(-1000, 1000, (1024,), dtype=np.int32)
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dev(xi), dev(ri)).numpy(), xi + ri)
+    x5 = rng.uniform(0.5, 2.0, (17, 7, 300000)).astype(np.float32)               # 136 MiB; the small operand ignores only the outermost axis
+    y5 = rng.uniform(0.5, 2.0, (7, 1)).astype(np.float32)                        # period 7 * 300000 = 8 MiB: too long, stays where it was
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dev(x5), dev(y5)).numpy(), x5 + y5)
+
+
 def test_fuzz_policy_smoke(smhip):
     """A short run of tests/fuzz_policy.py: random Ops on 4-70 MiB arrays, i.e. footprints on both sides of the stream-policy
     thresholds, through every kernel family that takes the policy word (3 x 160 cases ran clean when it last changed)."""

@@ -37,8 +37,9 @@ case("(8192,8192) * (1,8192)                 [flat]", (M, M), (M, 1), (0, 1), op
 case("(8192,8192) * (8192,1) column          [flat]", (M, M), (M, 1), (1, 0), op=2)
 case("(8192,1) * (1,8192) outer product      [row]", (M, M), (1, 0), (0, 1), op=2)
 case("(64,56,56,256) + (1,1,1,256) bias      [flat]", (64, 56, 56, 256), dense((64, 56, 56, 256)), (0, 0, 0, 1))
-case("(256,224,224,3) + (1,224,1,3) ref test [lds]", (256, 224, 224, 3), dense((256, 224, 224, 3)), (0, 3, 0, 1))
-case("(256,224,224,3) + (1,1,1,3) RGB bias   [lds]", (256, 224, 224, 3), dense((256, 224, 224, 3)), (0, 0, 0, 1))
+case("(256,224,224,3) + (1,224,1,3) ref test [flat]", (256, 224, 224, 3), dense((256, 224, 224, 3)), (0, 3, 0, 1))
+case("(128,224,224,3) + (1,224,1,3) ref test [lds]", (128, 224, 224, 3), dense((128, 224, 224, 3)), (0, 3, 0, 1))
+case("(256,224,224,3) + (1,1,1,3) RGB bias   [flat]", (256, 224, 224, 3), dense((256, 224, 224, 3)), (0, 0, 0, 1))
 case("(16,1024,1024,4) * (16,1,1,4)          [lds]", (16, 1024, 1024, 4), dense((16, 1024, 1024, 4)), (4, 0, 0, 1), op=2)
 case("A.T + B (8192,8192)                    [tile]", (M, M), (1, M), (M, 1))
 case("A.T + B.T (8192,8192)                  [tile]", (M, M), (1, M), (1, M))
