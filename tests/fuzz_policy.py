@@ -35,6 +35,23 @@ def main():
             a = rng.integers(info.min, info.max, n, dtype=dt); b = rng.integers(info.min, info.max, n, dtype=dt)
         da, db = lib.to_device(a), lib.to_device(b)
         kind = rng.choice(["contig", "scalar", "row", "col", "tile", "powrow", "powcol", "powscalar", "fused"])
+        if rng.random() < 0.06:
+            # a dense operand of >= 128 MiB against a small one that ignores the leading axes: the periodic route
+            d1, d2, ch = int(rng.choice([7, 16, 28])), int(rng.choice([5, 16, 24])), int(rng.choice([2, 3, 4]))
+            lead = (33 << 20) // (d1 * d2 * ch) + int(rng.integers(1, 9))
+            xs = (lead, d1, d2, ch)
+            xb = rng.uniform(0.25, 4.0, xs).astype(np.float32)
+            ysm = rng.uniform(0.25, 4.0, (1, d1, 1, ch)).astype(np.float32)
+            popn = str(rng.choice(["add", "sub", "mul"]))
+            pop, pref = ops[popn]
+            left = popn != "sub" and rng.random() < 0.5
+            dxb, dys = lib.to_device(xb), lib.to_device(ysm)
+            gotp = (lib.binary(pop, dys, dxb) if left else lib.binary(pop, dxb, dys)).numpy()
+            wantp = pref(ysm, xb) if left else pref(xb, ysm)
+            assert np.array_equal(gotp, wantp), f"case {case}: periodic {popn} {xs} left={left}"
+            del dxb, dys, xb, gotp, wantp
+            lib.pool_trim()
+            continue
         opn = rng.choice(list(ops))
         op, ref = ops[opn]
         A = a.reshape(rows, cols)
