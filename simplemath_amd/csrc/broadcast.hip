@@ -771,7 +771,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
     // one row: the flat tile kernel instead of the LDS kernel's per-vector index chains (88 vector instructions per 16
     // bytes in round 1).  Writing the period out is a launch of its own (~5 us with its dependency), so only outputs of
     // 128 MiB and more go this way: (256,224,224,3) + (1,224,1,3) 49.5-52 -> 46.5 us; at half that size it is a wash.
-    if (!user && op != SMHIP_OP_LEFT && pl.ndim >= 2 && pl.n * dtype_size(dtype) >= ((size_t)128 << 20)) {
+    static const size_t periodic_min_bytes = [] {  // SMHIP_PERIODIC_MIN_MIB: experiments (tools/periodic_threshold.py)
+        const char *e = getenv("SMHIP_PERIODIC_MIN_MIB");
+        return (size_t)(e ? atol(e) : 128) << 20;
+    }();
+    if (!user && op != SMHIP_OP_LEFT && pl.ndim >= 2 && pl.n * dtype_size(dtype) >= periodic_min_bytes) {
         const size_t esz = dtype_size(dtype);
         const int64_t W = 16 / (int64_t)esz;
         for (int role = 0; role < 2; ++role) {
