@@ -120,7 +120,7 @@ constexpr int kTileBlock = 256;
 // with a heavy Op.  cv = cols / W; b's vector for output vector i is b[i mod cv] (read through the caches: every workgroup
 // wants the same few KiB), resp. the single element b[i / cv].  Through the row kernel this shape paid ~35 vector
 // instructions per wave of index arithmetic on top of pow's 257 and staged the tables before its loads: 23.9 us at
-// 4096 x 4096 against 21.x us here (profiles/r02_pmc_sq_pow_shapes.txt).
+// 4096 x 4096 against 20.2 us here (profiles/r02_pow_shapes.txt; 21.1-21.8 us under the profiler, r02_pmc_sq_pow_shapes.txt).
 template <typename T, typename Op, int KIND, int U, bool KEEP_STORES>
 __global__ __launch_bounds__(kTileBlock) void flat_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
                                                                 T *__restrict__ out, size_t n_vec, int tail, int nt, FastDiv cv) {
