@@ -116,8 +116,8 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
 constexpr int kTileBlock = 256;
 // KEEP_STORES: the write side's policy (ops.hip.h: store_stream_if) as a template parameter -- as a run-time branch in
 // front of each store it cut the arithmetic of the tile's vectors apart (config 4: 73.2 -> 79.0 us).
-// KIND 0: a op b, 1: a op s, 2: s op a; 3 / 4: a dense (rows x cols) against ONE ROW / ONE COLUMN of b -- config 3's shape
-// with a heavy Op.  cv = cols / W; b's vector for output vector i is b[i mod cv] (read through the caches: every workgroup
+// KIND 0: a op b, 1: a op s, 2: s op a (the heavy Ops only); 3 / 4: a dense (rows x cols) against ONE ROW / ONE COLUMN of
+// b -- config 3's shape, for EVERY built-in Op (launch_flat_rows).  cv = cols / W; b's vector for output vector i is b[i mod cv] (read through the caches: every workgroup
 // wants the same few KiB), resp. the single element b[i / cv].  Through the row kernel this shape paid ~35 vector
 // instructions per wave of index arithmetic on top of pow's 257 and staged the tables before its loads: 23.9 us at
 // 4096 x 4096 against 20.2 us here (profiles/r02_pow_shapes.txt; 21.1-21.8 us under the profiler, r02_pmc_sq_pow_shapes.txt).
