@@ -25,6 +25,18 @@ roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024, fals
          kernel runs on) over the timed region / launches; peak = 8000 GB/s (MI355X HBM3E spec).  `traffic` is NOT
          measured by this run: it is the HBM byte count of the last committed rocprofv3 --pmc passes
          (tools/pmc_traffic.sh -> profiles/traffic_latest.json) and `traffic_source` says so; null if that file is absent.
+configs  the N = 1 line also carries BASELINE configs 3, 4 and 5's per-GPU step under "configs": {"c3", "c4", "c5_shard"}, each
+         timed in TWO settings and priced against the same 8 TB/s:
+           replay  every launch re-reads the same operands (the headline's setting).  For configs 3 and 4 the reads fit the
+                   256 MiB Infinity Cache, so `bound` reads "hbm+infinity_cache": the rate is cache-fed.
+           cold    launches rotate through K disjoint operand sets, K x footprint >= 2.5 GiB: nothing a launch reads or writes
+                   was touched recently -- an operator's realistic first call.  `bound` "hbm".
+         plus that config's cpu_baseline, and -- c5_shard -- the one-rank run of config 5's exchange step through libsmhip's
+         own device group (smhip_set_devices(1) + smhip_sharded_contiguous_sum: the ncclAllReduce is issued for real, with
+         one rank; no torch).  "rccl" says what RCCL itself reports: its version and the ranks the communicator counts
+         (ncclCommCount) -- at N > 1 that is how the line shows the collective saw N ranks -- and the N > 1 line adds
+         "per_gpu": [{rank, device, kernel_ms, frac}].  `--configs none` leaves the legs out; `--workload W --setting cold`
+         runs one workload's whole timed region in the cold setting (what the rocprofv3 summaries under profiles/ time).
 cpu_baseline  rank 0, N = 1 only, on a bounded sample: `value` = the reference's own operator path as shipped (oracle/_ref,
          kind "reference") if the prebuilt .so travelled, else the oracle's restatement (kind "port"); `best_effort` =
          the restatement on every core this process may use (cgroup quota / affinity / SMT accounted for), output
@@ -70,6 +82,11 @@ def parse():
                     help="torch.distributed backend for the barrier and the max over ranks: nccl = RCCL; gloo = CPU rehearsal")
     ap.add_argument("--cpu-log2n", type=int, default=26)
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steps before the W warm-up steps (clock ramp)")
+    ap.add_argument("--setting", default="replay", choices=["replay", "cold"],
+                    help="replay = every step re-reads the same operands; cold = steps rotate through >= 2.5 GiB of disjoint operand sets")
+    ap.add_argument("--configs", default="all", choices=["all", "none"],
+                    help="all = the N=1 `add` line also times BASELINE configs 3, 4 and 5's shard (replay and cold) and the one-rank RCCL leg")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="seconds after which self-started ranks are killed")
     return ap.parse_args()
 
 
@@ -257,18 +274,83 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def gpu_count_without_hip():
+    """How many GPUs a rank of this job would see -- asked of a CHILD process (libsmhip's smhip_device_count, i.e.
+    hipGetDeviceCount under this environment's *_VISIBLE_DEVICES), so that this process, which is about to start the ranks,
+    never initialises HIP itself.  None if the child could not say."""
+    code = ("import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); n = ctypes.c_int(0); "
+            "rc = l.smhip_device_count(ctypes.byref(n)); print(n.value if rc == 0 else -1)")
+    lib = os.path.join(ROOT, "simplemath_amd", "lib", "libsmhip.so")
+    try:
+        r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=120)
+        return int(r.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        return None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as children.  This process
-    has not imported torch or touched HIP, and it never becomes a rank itself."""
+    has not imported torch or touched HIP, and it never becomes a rank itself.  Fails fast and loudly: fewer GPUs than ranks
+    is refused before anything starts (exit 2, one line); the first rank that exits non-zero takes its siblings with it
+    (each rank is a fresh child in its own process group, killed by that exact group id) and its code is returned; the
+    whole job has a deadline."""
+    import signal
+    if args.dist_backend == "nccl":
+        have = gpu_count_without_hip()
+        if have is not None and have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node shows {max(have, 0)} GPU(s) to a rank; refusing to start "
+                  "(one process per GPU; use --dist-backend gloo to rehearse ranks on fewer devices)", file=sys.stderr)
+            return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGTERM)  # q.pid is the id of the session / group this child leads
+                except OSError:
+                    pass
+        t_end = time.time() + 10
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                q.wait()
+
+    deadline = time.time() + args.rank_timeout
+    rc = 0
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                i, c = bad[0]
+                print(f"bench.py: rank {i} exited with code {c}; stopping the other ranks", file=sys.stderr)
+                rc = c if c > 0 else 128 - c  # a signal's negative code, shell style
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                print(f"bench.py: ranks still running after {args.rank_timeout:.0f} s; stopping them", file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
+    return rc
 
 
 def traffic_from_profiles(wl):
@@ -289,59 +371,176 @@ def traffic_from_profiles(wl):
     return t, src
 
 
-def build_workload(lib, sma, np, C, wl, args, rank, bound):
-    """(step, units, algorithmic bytes, kernel name, workload text, keep-alive objects, extras) on the current device."""
+COLD_ROTATION_BYTES = 2560 << 20  # a cold setting's operand sets cover at least this much (10 x the Infinity Cache)
+
+
+def build_workload(lib, sma, np, C, wl, args, rank, bound, setting="replay", log2n=None):
+    """(steps, units, algorithmic bytes, kernel name, workload text, keep-alive objects, extras) on the current device.
+    `steps` holds one bound call per operand set: one set for `replay`, K disjoint sets for `cold` (step i uses set i % K)."""
     F32 = np.float32
     i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
+    log2n = log2n or args.log2n
+
+    def sets_for(footprint):
+        return 1 if setting == "replay" else max(2, -(-COLD_ROTATION_BYTES // footprint))
+
+    steps, keep = [], []
     if wl in ("add", "add_sum"):
-        log2n = args.log2n or 28
+        log2n = log2n or 28
         n = 1 << log2n
         first = rank * n  # this rank's shard of the global array
         seeds, lo = ((1, 2), -1.0) if wl == "add" else ((6, 7), 0.0)
-        a = lib.uniform_f32(n, seeds[0], lo, 1.0, first=first)
-        b = lib.uniform_f32(n, seeds[1], lo, 1.0, first=first)
-        c = lib.empty((n,), F32)
         sum_ptr = lib.alloc(8)
-        if wl == "add":
-            step = bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
-                         C.c_void_p(c.ptr), C.c_size_t(n))
-            kernel = "contiguous_vec_kernel<float, AddOp<float>, 1024, false>"
-        else:
-            step = bound(lib.c.smhip_contiguous_sum_async, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
-                         C.c_void_p(c.ptr), C.c_size_t(n), C.c_void_p(sum_ptr))
-            kernel = "reduce_kernel<float, AddOp<float>, kFused>"
+        K = sets_for(12 * n)
+        for k in range(K):
+            # set k > 0: other streams of the same generator (seed + 100 k): same distribution, disjoint memory
+            a = lib.uniform_f32(n, seeds[0] + 100 * k, lo, 1.0, first=first)
+            b = lib.uniform_f32(n, seeds[1] + 100 * k, lo, 1.0, first=first)
+            c = lib.empty((n,), F32)
+            keep.append((a, b, c))
+            if wl == "add":
+                steps.append(bound(lib.c.smhip_contiguous, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+                                   C.c_void_p(c.ptr), C.c_size_t(n)))
+            else:
+                steps.append(bound(lib.c.smhip_contiguous_sum_async, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr),
+                                   C.c_void_p(b.ptr), C.c_void_p(c.ptr), C.c_size_t(n), C.c_void_p(sum_ptr)))
+        kernel = ("contiguous_vec_kernel<float, AddOp<float>, 1024, false>" if wl == "add"
+                  else "reduce_kernel<float, AddOp<float>, kFused> (+ finish_kernel)")
         text = f"1D float32 {'add' if wl == 'add' else 'fused add+sum'}, N=2^{log2n} per GPU, contiguous, HBM-resident"
-        return step, n, 12 * n, kernel, text, (a, b, c), {"log2n": log2n, "n": n, "sum_ptr": sum_ptr}
+        return steps, n, 12 * n, kernel, text, keep, {"log2n": log2n, "n": n, "sum_ptr": sum_ptr}
     if wl == "bcast_mul":
         rows = cols = 4096
-        A = lib.uniform_f32(rows * cols, 3, -1.0, 1.0)
         r = lib.uniform_f32(cols, 4, -1.0, 1.0)
-        out = lib.empty((rows, cols), F32)
-        step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([cols, 1]),
-                     C.c_void_p(r.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr))
-        return (step, rows * cols, 4 * (2 * rows * cols + cols), "flat_tile_kernel<float, MultiplyOp<float>, 3, 2, true>",
-                "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident", (A, r, out), {})
+        keep.append(r)
+        for k in range(sets_for(8 * rows * cols)):
+            A = lib.uniform_f32(rows * cols, 3 + 100 * k, -1.0, 1.0)
+            out = lib.empty((rows, cols), F32)
+            keep.append((A, out))
+            steps.append(bound(lib.c.smhip_elementwise, C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([cols, 1]),
+                               C.c_void_p(r.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr)))
+        return (steps, rows * cols, 4 * (2 * rows * cols + cols), "flat_tile_kernel<float, MultiplyOp<float>, 3, 2, *>",
+                "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident", keep, {})
     if wl == "transpose_add":
         rows = cols = 8192
-        A = lib.uniform_f32(rows * cols, 8, -1.0, 1.0)
-        B = lib.uniform_f32(rows * cols, 9, -1.0, 1.0)
-        out = lib.empty((cols, rows), F32)
-        step = bound(lib.c.smhip_elementwise, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([1, cols]),
-                     C.c_void_p(B.ptr), i64([rows, 1]), i64([cols, rows]), C.c_int(2), C.c_void_p(out.ptr))
-        return (step, rows * cols, 12 * rows * cols, "tile_kernel<float, AddOp<float>, true, 1, 0>",
-                "2D float32 A.T + B, 8192x8192, A read through a transposed view, HBM-resident", (A, B, out), {})
-    log2n = args.log2n or 26
+        for k in range(sets_for(12 * rows * cols)):
+            A = lib.uniform_f32(rows * cols, 8 + 100 * k, -1.0, 1.0)
+            B = lib.uniform_f32(rows * cols, 9 + 100 * k, -1.0, 1.0)
+            out = lib.empty((cols, rows), F32)
+            keep.append((A, B, out))
+            steps.append(bound(lib.c.smhip_elementwise, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(A.ptr), i64([1, cols]),
+                               C.c_void_p(B.ptr), i64([rows, 1]), i64([cols, rows]), C.c_int(2), C.c_void_p(out.ptr)))
+        return (steps, rows * cols, 12 * rows * cols, "tile_kernel<float, AddOp<float>, true, 1, 0>",
+                "2D float32 A.T + B, 8192x8192, A read through a transposed view, HBM-resident", keep, {})
+    log2n = log2n or 26
     n = 1 << log2n
-    a = lib.uniform_f32(n, 5, 0.01, 100.0)
-    out = lib.empty((n,), F32)
     exponent = C.c_float(2.5)
-    step = bound(lib.c.smhip_array_scalar, C.c_int(sma.OP_POW), C.c_int(sma.F32), C.c_void_p(a.ptr), C.byref(exponent),
-                 C.c_size_t(n), C.c_void_p(out.ptr))
-    return (step, n, 8 * n, "flat_tile_kernel<float, PowOp<float>, 1, 2, false>",
-            f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident", (a, out, exponent), {"log2n": log2n})
+    keep.append(exponent)
+    for k in range(sets_for(8 * n)):
+        a = lib.uniform_f32(n, 5 + 100 * k, 0.01, 100.0)
+        out = lib.empty((n,), F32)
+        keep.append((a, out))
+        steps.append(bound(lib.c.smhip_array_scalar, C.c_int(sma.OP_POW), C.c_int(sma.F32), C.c_void_p(a.ptr), C.byref(exponent),
+                           C.c_size_t(n), C.c_void_p(out.ptr)))
+    return (steps, n, 8 * n, "flat_tile_kernel<float, PowOp<float>, 1, 2, *>",
+            f"1D float32 pow(a, 2.5), N=2^{log2n}, a in (0.01,100), HBM-resident", keep, {"log2n": log2n})
 
 
-def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra):
+def bound_reads(wl, setting, alg_bytes):
+    """`roofline.bound`: what feeds the kernel.  A replayed workload whose reads fit the 256 MiB Infinity Cache is cache-fed."""
+    read_bytes = {"add": alg_bytes * 2 // 3, "add_sum": alg_bytes * 2 // 3, "transpose_add": alg_bytes * 2 // 3,
+                  "bcast_mul": alg_bytes // 2, "pow": alg_bytes // 2}[wl]
+    return "hbm+infinity_cache" if setting == "replay" and read_bytes <= (256 << 20) else "hbm"
+
+
+def time_steps(lib, steps, n_steps, warmup, barrier=None):
+    """Average launch duration in ms from HIP events on the kernels' stream, wall seconds of the timed region."""
+    K = len(steps)
+    for i in range(max(warmup, K)):  # every set is visited before the clock starts (first touches are not timed)
+        steps[i % K]()
+    e0, e1 = lib.event(), lib.event()
+    (barrier or lib.synchronize)()
+    t0 = time.perf_counter()
+    lib.record(e0)
+    for i in range(n_steps):
+        steps[i % K]()
+    lib.record(e1)
+    (barrier or lib.synchronize)()
+    wall = time.perf_counter() - t0
+    ms = lib.elapsed_ms(e0, e1) / n_steps
+    lib.event_destroy(e0)
+    lib.event_destroy(e1)
+    return ms, wall
+
+
+def config_legs(lib, sma, np, C, args, bound):
+    """BASELINE configs 3, 4 and 5's per-GPU step, each replayed and cold, on the current device (rank 0, N = 1)."""
+    legs = {}
+    for key, wl, n_steps in (("c3", "bcast_mul", 200), ("c4", "pow", 100), ("c5_shard", "add_sum", 30)):
+        leg = None
+        for setting in ("replay", "cold"):
+            steps, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, 0, bound, setting, log2n=0)
+            ms, _ = time_steps(lib, steps, n_steps, 20)
+            if leg is None:
+                leg = {"workload": workload, "kernel": kernel, "algorithmic_bytes_per_launch": alg_bytes, "elements": units}
+            achieved = alg_bytes / (ms * 1e-3) / 1e9
+            leg[setting] = {"bound": bound_reads(wl, setting, alg_bytes), "kernel_ms": ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "value": units / (ms * 1e-3) / 1e9, "value_unit": "Gelem/s",
+                            "launches": n_steps, "operand_sets": len(steps)}
+            if setting == "cold":
+                leg[setting]["rotating_bytes"] = len(steps) * alg_bytes
+            if "sum_ptr" in info:
+                lib.free(info["sum_ptr"])
+            del steps, keep
+            lib.synchronize()
+            lib.pool_trim()
+        legs[key] = leg
+    return legs
+
+
+def one_rank_rccl_leg(lib, sma, np, C, log2n=28):
+    """Config 5's exchange step with ONE rank, through the product's own device group: smhip_set_devices(1) (RCCL loaded,
+    ncclCommInitAll), then per step the fused add + sum and ONE ncclAllReduce(1 x fp64) inside ncclGroupStart/End, the scalar
+    read back to the host.  Returns (leg, rccl) -- or an error text in both if RCCL is not usable here."""
+    n = 1 << log2n
+    try:
+        with _StdoutToStderr():
+            lib.set_devices(1)
+    except sma.SmhipError as e:
+        return {"error": str(e)}, {"error": str(e)}
+    try:
+        nr, rk, dev = lib.group_info(0)
+        rccl = {"nranks": nr, "rank": rk, "device": dev, "version": lib.rccl_version(),
+                "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion through libsmhip (smhip_group_info, smhip_rccl_version)"}
+        a = lib.uniform_f32(n, 6, 0.0, 1.0)
+        b = lib.uniform_f32(n, 7, 0.0, 1.0)
+        c = lib.empty((n,), np.float32)
+        pt = lambda x: (C.c_void_p * 1)(x.ptr)
+        pa, pb, pc, ns = pt(a), pt(b), pt(c), (C.c_size_t * 1)(n)
+        total = C.c_double(0)
+
+        def step():
+            rc = lib.c.smhip_sharded_contiguous_sum(C.c_int(sma.OP_ADD), C.c_int(sma.F32), pa, pb, pc, ns, C.byref(total))
+            if rc < 0:
+                raise sma.SmhipError(rc, lib.c.smhip_last_error().decode())
+
+        for _ in range(3):
+            step()
+        lib.sharded_synchronize()
+        t = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            step()
+        lib.sharded_synchronize()
+        t = (time.perf_counter() - t) / reps
+        leg = {"workload": f"fused add+sum over 1 x 2^{log2n} f32 (uniform[0,1), seeds 6/7) + one all-reduce of 1 x fp64, scalar read back each step",
+               "path": "smhip_set_devices(1) -> smhip_sharded_contiguous_sum -> ncclGroupStart / ncclAllReduce / ncclGroupEnd (no torch)",
+               "ms_per_step": t * 1e3, "value": n / t / 1e9, "unit": "Gelem/s", "global_sum": total.value, "expected_sum_approx": float(n)}
+        return leg, rccl
+    finally:
+        lib.set_devices(0)
+
+
+def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra, setting="replay"):
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic, traffic_source = traffic_from_profiles(wl)
     line = {
@@ -350,8 +549,10 @@ def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, s
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "elements_per_gpu": units, "sharding": f"outer-dim x{world}, no data-path collective",
-                   "kernel": kernel, "processes": "one per GPU" if mode == "ranks" else "one process, one host thread, all GPUs (smhip_set_devices)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "kernel": kernel, "processes": "one per GPU" if mode == "ranks" else "one process, one host thread, all GPUs (smhip_set_devices)",
+                   "setting": setting + (": every step re-reads the same operands" if setting == "replay"
+                                         else ": steps rotate through >= 2.5 GiB of disjoint operand sets")},
+        "roofline": {"bound": bound_reads(wl, setting, alg_bytes), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                      "kernel_ms_median_of_20_single_launches": singles[len(singles) // 2], "kernel_ms_min": singles[0],
@@ -372,6 +573,13 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    die = os.environ.get("SMHIP_BENCH_TEST_DIE_RANK")  # rehearsal hook (tests): this rank dies before the rendezvous
+    if die is not None and int(die) == rank:
+        print(f"bench.py: rank {rank} dying on request (SMHIP_BENCH_TEST_DIE_RANK)", file=sys.stderr)
+        return 7
+
+    if os.environ.get("SMHIP_BENCH_TEST_HANG_RANK") == str(rank):  # rehearsal hook (tests): this rank never gets anywhere
+        time.sleep(3600)
 
     # SMHIP_BENCH_FORCE_DIST=1: take the multi-rank code path (torch.distributed, libsmhip's communicator, the config-5
     # leg) even with ONE rank -- how the one-GPU test box exercises it through the real RCCL calls.
@@ -379,17 +587,25 @@ def run_rank(args):
     dist = torch = None
     if dist_on:
         # torch first: libsmhip then binds to the HIP runtime and the RCCL torch already loaded (same sonames)
+        import datetime
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank %= max(torch.cuda.device_count(), 1)  # identity on a full node; lets a rehearsal share one GPU
-        torch.cuda.set_device(local_rank)
-        with _StdoutToStderr():
-            if args.dist_backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        limit = datetime.timedelta(seconds=120)  # a rank that never arrives fails the others here, not after the default half hour
+        if args.dist_backend == "nccl":
+            have = torch.cuda.device_count()
+            if local_rank >= have:
+                print(f"bench.py: rank {rank} wants GPU {local_rank} but this process sees {have}: one process per GPU "
+                      "(--dist-backend gloo rehearses ranks on fewer devices)", file=sys.stderr)
+                return 2
+            torch.cuda.set_device(local_rank)
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
                 dist.barrier()  # torch creates the communicator lazily: do it now, while stdout is parked
-            else:
-                dist.init_process_group("gloo")
+        else:
+            with _StdoutToStderr():
+                dist.init_process_group("gloo", timeout=limit)
+            local_rank %= max(torch.cuda.device_count(), 1)  # the gloo rehearsal may share one GPU among its ranks
 
     import ctypes as C
     import numpy as np
@@ -442,41 +658,40 @@ def run_rank(args):
         return call
 
     wl = args.workload
-    step, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, rank, bound)
+    steps, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, rank, bound, args.setting)
+    K = len(steps)
 
     # Clock ramp: the chip needs tens of milliseconds of continuous work to leave its idle clocks (a VALU-heavy launch
     # measures 115 us cold and 94 us ramped), and W short steps may not last that long.
     t_pre = time.perf_counter()
+    i_pre = 0
     while time.perf_counter() - t_pre < args.prewarm:
         for _ in range(20):
-            step()
+            steps[i_pre % K]()
+            i_pre += 1
         lib.synchronize()
-    for _ in range(args.warmup):
-        step()
-    e0, e1 = lib.event(), lib.event()
-    barrier()
-    t0 = time.perf_counter()
-    lib.record(e0)
-    for _ in range(args.steps):
-        step()
-    lib.record(e1)
-    barrier()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    kern_ms = lib.elapsed_ms(e0, e1) / args.steps  # average launch duration, back-to-back on one stream
+    kern_ms, wall = time_steps(lib, steps, args.steps, args.warmup, barrier)  # barrier + synchronise on both sides of exactly K steps
+    my_kern_ms = kern_ms
 
     coll_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"
+    per_gpu = None
     if dist is not None:
         t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
+        mine = torch.zeros(world, 2, dtype=torch.float64, device=coll_dev)  # every rank's own figures, for "per_gpu"
+        mine[rank, 0], mine[rank, 1] = my_kern_ms, float(local_rank)
+        dist.all_reduce(mine)
+        per_gpu = [{"rank": r, "device": int(mine[r, 1]), "kernel_ms": float(mine[r, 0]),
+                    "frac": alg_bytes / (float(mine[r, 0]) * 1e-3) / 1e9 / HBM_PEAK_GBS} for r in range(world)]
 
     # per-launch distribution (SURVEY 8d asks for median and min): 20 launches timed one by one, after the
     # contract's timed region so the extra event records do not touch it
     singles = []
-    for _ in range(20):
+    e0, e1 = lib.event(), lib.event()
+    for i in range(20):
         lib.record(e0)
-        step()
+        steps[i % K]()
         lib.record(e1)
         lib.event_sync(e1)
         singles.append(lib.elapsed_ms(e0, e1))
@@ -487,9 +702,10 @@ def run_rank(args):
 
     # config 5's exchange step: fused add+sum per shard, then ONE all-reduce of the fp64 scalar
     c5 = None
+    rccl = None
     if wl == "add" and dist_on:
         n, log2n = info["n"], info["log2n"]
-        del keep, step  # the headline operands go back to the pool; config 5 has its own (seeds 6/7 in [0,1))
+        del keep, steps  # the headline operands go back to the pool; config 5 has its own (seeds 6/7 in [0,1))
         a5 = lib.uniform_f32(n, 6, 0.0, 1.0, first=rank * n)
         b5 = lib.uniform_f32(n, 7, 0.0, 1.0, first=rank * n)
         c5out = lib.empty((n,), np.float32)
@@ -520,6 +736,9 @@ def run_rank(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if use_lib_comm:
             backend = "libsmhip -> ncclAllReduce (RCCL over xGMI), on the kernel's stream"
+            nr, rk = lib.comm_info()
+            rccl = {"nranks": nr, "rank": rk, "version": lib.rccl_version(),
+                    "source": "ncclCommCount / ncclCommUserRank / ncclGetVersion through libsmhip (smhip_comm_info, smhip_rccl_version), rank 0's communicator"}
         elif args.dist_backend == "gloo":
             backend = "gloo on the host (rehearsal, not RCCL)"
         else:
@@ -527,9 +746,25 @@ def run_rank(args):
         c5 = {"workload": f"fused add+sum over {world} x 2^{log2n} f32 (uniform[0,1), seeds 6/7) + one all-reduce of 1 x fp64",
               "allreduce": backend, "ms_per_step": float(tt[0]) * 1e3, "value": world * n / float(tt[0]) / 1e9, "unit": "Gelem/s",
               "global_sum": total, "expected_sum_approx": float(world) * n}
+        del a5, b5, c5out
 
     if rank == 0:
         extra = {}
+        if per_gpu is not None:
+            extra["per_gpu"] = per_gpu
+        if rccl is not None:
+            extra["rccl"] = rccl
+        if world == 1 and wl == "add" and args.configs == "all" and not dist_on and args.setting == "replay":
+            # the other BASELINE configs, replayed and cold, and config 5's exchange step with one rank through libsmhip's own group
+            steps = keep = None
+            lib.pool_trim()
+            legs = config_legs(lib, sma, np, C, args, bound)
+            legs["c5_shard"]["one_rank_rccl"], extra["rccl"] = one_rank_rccl_leg(lib, sma, np, C)
+            lib.pool_trim()
+            if not args.no_cpu_baseline:
+                for key, cwl in (("c3", "bcast_mul"), ("c4", "pow"), ("c5_shard", "add_sum")):
+                    legs[key]["cpu_baseline"] = cpu_baseline(cwl, args.cpu_log2n)
+            extra["configs"] = legs
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(wl, args.cpu_log2n)
             if cb is not None:
@@ -549,7 +784,7 @@ def run_rank(args):
                     small()
                 lib.synchronize()
                 cb["config1_million_check"]["gpu_ns"] = (time.perf_counter() - tq) / 2000 * 1e9
-        emit(args, wl, world, "ranks", value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra)
+        emit(args, wl, world, "ranks", value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra, args.setting)
 
     if use_lib_comm:
         lib.synchronize()
@@ -571,12 +806,15 @@ def run_single(args):
         raise SystemExit("--mode single runs the headline `add` workload (and its config-5 leg)")
     lib = sma.load()
     G = args.gpus
+    have = lib.device_count()
+    if G > have:  # before anything is allocated or any communicator is built
+        print(f"bench.py: --mode single --gpus {G} but this process sees {have} GPU(s); refusing", file=sys.stderr)
+        return 2
     with _StdoutToStderr():
         lib.set_devices(G)
     log2n = args.log2n or 28
     n = 1 << log2n
     F32 = np.float32
-    arrays = []
 
     def on_each(seed_a, seed_b, lo):
         aa, bb, cc = [], [], []
@@ -628,7 +866,8 @@ def run_single(args):
     record(ev, 1)
     lib.sharded_synchronize()
     wall = time.perf_counter() - t0
-    kern_ms = max(lib.elapsed_ms(e0, e1) for e0, e1 in ev) / args.steps
+    each_ms = [lib.elapsed_ms(e0, e1) / args.steps for e0, e1 in ev]
+    kern_ms = max(each_ms)
 
     lib.set_device(0)
     singles = []
@@ -665,7 +904,10 @@ def run_single(args):
           "ms_per_step": tc * 1e3, "value": G * n / tc / 1e9, "unit": "Gelem/s", "global_sum": total.value,
           "expected_sum_approx": float(G) * n}
 
-    extra = {}
+    info = [lib.group_info(g) for g in range(G)]
+    extra = {"rccl": {"nranks": info[0][0], "version": lib.rccl_version(), "communicators": [{"rank": r, "device": d, "nranks": nr} for nr, r, d in info],
+                      "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion through libsmhip (smhip_group_info, smhip_rccl_version)"},
+             "per_gpu": [{"rank": g, "device": g, "kernel_ms": each_ms[g], "frac": 12 * n / (each_ms[g] * 1e-3) / 1e9 / HBM_PEAK_GBS} for g in range(G)]}
     if G == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline("add", args.cpu_log2n)
         if cb is not None:

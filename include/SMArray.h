@@ -222,6 +222,7 @@ public:
         if (_shape != other._shape) throw std::runtime_error("Shape mismatch in assignment");
         if constexpr (hip::dtype_of<T>::id >= 0) {
             if (totalSize == 0) return *this;
+            hip::DeviceGuard on(common_device(*this, other));
             std::unique_ptr<SMArray> holder;
             const SMArray *src = &other;
             if (other.data.storage() == data.storage()) {
@@ -322,6 +323,7 @@ public:
     T operator%(const SMArray &arr) const {
         if (totalSize != arr.totalSize) throw std::runtime_error("dot product: element counts differ");
         if constexpr (hip::dtype_of<T>::id >= 0) {
+            hip::DeviceGuard on(common_device(*this, arr));
             std::unique_ptr<SMArray> lhs_holder, rhs_holder;
             const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
             return hip::dot_device<T>(pa, pb, totalSize);
@@ -355,6 +357,7 @@ public:
                                        : sm::broadcast(_shape, _strides, rhs._shape, rhs._strides);
         if (br.resultShape.size() > MAX_NDIM) throw std::runtime_error("rank exceeds MAX_NDIM");
         if constexpr (hip::on_device_v<T, Op>) {
+            hip::DeviceGuard on(common_device(*this, rhs));  // the kernel runs where the operands live; the result is born there
             SMArray out = device_empty(std::move(br.resultShape));
             if (!out._shape.empty() && out.totalSize <= SMHIP_INLINE_MAX_OUTPUTS && (host_only_small() || rhs.host_only_small()) &&
                 hip::device_op<Op>::id() <= SMHIP_OP_POW) {
@@ -390,6 +393,7 @@ public:
     template <typename Op>
     SMArray apply_scalar(T value) const {
         if constexpr (hip::on_device_v<T, Op>) {
+            hip::DeviceGuard on(device());
             SMArray out = device_empty(std::vector<std::size_t>(_shape));
             if (!_shape.empty() && totalSize <= SMHIP_INLINE_MAX_OUTPUTS && host_only_small() && hip::device_op<Op>::id() <= SMHIP_OP_POW) {
                 // host-built tiny array op scalar: both ride in the launch packet
@@ -461,6 +465,16 @@ public:
     bool is_dense() const { return is_contiguous(_shape, _strides); }
     bool is_view() const { return isView; }
     int device() const { return data.storage()->device; }  // the GPU this array's elements live on
+    // The GPU two operands of one operator share.  Kernels run on the operands' device (the operators take a DeviceGuard on
+    // it, whatever GPU the calling thread is on); operands resident on DIFFERENT GPUs cannot meet in one kernel -- peer
+    // access is not assumed -- and that is an error, not a silent wrong-device launch.
+    static int common_device(const SMArray &x, const SMArray &y) {
+        const int dx = x.device(), dy = y.device();
+        if (dx != dy)
+            throw std::runtime_error("simpleMath/MI355X: the operands live on different GPUs (" + std::to_string(dx) + " and " + std::to_string(dy) +
+                                     "); bring them to one device first (sm::Sharded<T>::gather / scatter, or build both on the same GPU)");
+        return dx;
+    }
 
     // A new dense array whose elements exist only in HBM so far.
     static SMArray device_empty(std::vector<std::size_t> &&shape) {
@@ -495,6 +509,7 @@ public:
     // Sum of all elements, accumulated in fp64 on the device.
     double sum() const {
         static_assert(hip::dtype_of<T>::id >= 0, "sum(): element type has no kernels");
+        hip::DeviceGuard on(device());
         std::unique_ptr<SMArray> holder;
         const T *p = dense_device(holder);
         double s = 0;
@@ -552,6 +567,7 @@ private:
     // (same element count): SMHIP_OP_LEFT through the broadcast kernels.
     SMArray gather(const std::vector<std::size_t> &vshape, const std::vector<std::size_t> &vstrides,
                    std::vector<std::size_t> &&outShape) const {
+        hip::DeviceGuard on(device());
         SMArray out = device_empty(std::move(outShape));
         const auto sh = hip::to_i64(vshape), st = hip::to_i64(vstrides);
         const std::vector<std::int64_t> zeros(sh.size(), 0);

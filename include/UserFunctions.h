@@ -48,6 +48,8 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, const SMArray<T> &c) 
         const int o1 = hip::device_op<Op1>::id(), o2 = hip::device_op<Op2>::id();
         if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV && a.shape() == b.shape() && a.shape() == c.shape() && a.is_dense() &&
             b.is_dense() && c.is_dense()) {
+            SMArray<T>::common_device(a, c);
+            hip::DeviceGuard on(SMArray<T>::common_device(a, b));
             SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(a.shape()));
             hip::check(smhip_fused_contiguous(o1, o2, hip::dtype_of<T>::id, a.device_data(), b.device_data(), c.device_data(),
                                               nullptr, out.device_data_mut(), a.totalSize));
@@ -61,6 +63,7 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, T c) {
     if constexpr (hip::on_device_v<T, Op1> && hip::on_device_v<T, Op2>) {
         const int o1 = hip::device_op<Op1>::id(), o2 = hip::device_op<Op2>::id();
         if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV && a.shape() == b.shape() && a.is_dense() && b.is_dense()) {
+            hip::DeviceGuard on(SMArray<T>::common_device(a, b));
             SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(a.shape()));
             hip::check(smhip_fused_contiguous(o1, o2, hip::dtype_of<T>::id, a.device_data(), b.device_data(), nullptr, &c,
                                               out.device_data_mut(), a.totalSize));
@@ -87,6 +90,8 @@ SMArray<T> expr(const char *expression, std::initializer_list<T> scalars, const 
     std::vector<SMArray<T>> dense;  // dense copies of strided operands, kept alive until the launch is queued
     dense.reserve(n);
     const void *ptrs[8] = {};
+    for (int k = 1; k < n; ++k) SMArray<T>::common_device(first, *arrays[k]);  // all operands on one GPU, or it throws
+    hip::DeviceGuard on(first.device());
     for (int k = 0; k < n; ++k) {
         if (arrays[k]->shape() != first.shape()) throw std::runtime_error("sm::expr: operands must have the same shape");
         if (arrays[k]->is_dense()) {
@@ -119,6 +124,8 @@ double expr_sum(const char *expression, std::initializer_list<T> scalars, const 
     std::vector<SMArray<T>> dense;
     dense.reserve(n);
     const void *ptrs[8] = {};
+    for (int k = 1; k < n; ++k) SMArray<T>::common_device(first, *arrays[k]);
+    hip::DeviceGuard on(first.device());
     for (int k = 0; k < n; ++k) {
         if (arrays[k]->shape() != first.shape()) throw std::runtime_error("sm::expr_sum: operands must have the same shape");
         if (arrays[k]->is_dense()) {

@@ -212,6 +212,18 @@ int smhip_set_devices(int n);
 int smhip_get_devices(int *n);
 /* Blocks until every device of the group has finished its queued work. */
 int smhip_sharded_synchronize(void);
+/* What RCCL ITSELF reports for the group's communicator on device `index` (ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice), so a caller -- bench.py's "rccl" field -- can check that the collective library saw as many ranks
+ * as it was asked for.  Any output may be NULL. */
+int smhip_group_info(int index, int *nranks, int *rank, int *device);
+/* ncclGetVersion (e.g. 22203); loads RCCL. */
+int smhip_rccl_version(int *version);
+/* `bytes` from device src_device's memory to device dst_device's, device to device (hipMemcpyPeerAsync, over xGMI when the
+ * pair has peer access, which is enabled on first use).  Asynchronous and stream-ordered on BOTH sides: the copy waits for
+ * what is queued on the source device's library stream, runs on the destination device's library stream, and the source's
+ * stream continues after it.  How sm::Sharded<T>::scatter / replicate / gather move device-resident arrays (the
+ * reference has no counterpart: its threads share one address space, calculate.h:47). */
+int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes);
 
 /* handle_contiguous_arrays per device: out[g][i] = a[g][i] op b[g][i], i < n[g].  Asynchronous, no collective. */
 int smhip_sharded_contiguous(int op, int dtype, const void *const *a, const void *const *b, void *const *out, const size_t *n);
@@ -239,6 +251,7 @@ int smhip_sharded_dot(int dtype, const void *const *a, const void *const *b, con
  * the communicator to the calling thread's current device and is collective over the ranks. */
 int smhip_comm_unique_id(void *id128);
 int smhip_comm_init_rank(int nranks, int rank, const void *id128);
+/* The communicator as RCCL reports it (ncclCommCount / ncclCommUserRank); 0 / -1 when there is none. */
 int smhip_comm_info(int *nranks, int *rank);
 int smhip_comm_destroy(void);
 /* In-place sum over the ranks of `count` values in device memory, on the calling thread's stream (so it is ordered

@@ -388,6 +388,20 @@ class Smhip:
         self._ck(self.c.smhip_get_devices(C.byref(n)))
         return n.value
 
+    def group_info(self, index):
+        """(nranks, rank, device) as RCCL reports them for the device group's communicator `index`."""
+        n, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(self.c.smhip_group_info(C.c_int(index), C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value
+
+    def rccl_version(self):
+        v = C.c_int(0)
+        self._ck(self.c.smhip_rccl_version(C.byref(v)))
+        return v.value
+
+    def copy_peer(self, dst_ptr, dst_device, src_ptr, src_device, nbytes):
+        self._ck(self.c.smhip_copy_peer(C.c_void_p(dst_ptr), C.c_int(dst_device), C.c_void_p(src_ptr), C.c_int(src_device), C.c_size_t(nbytes)))
+
     def sharded_synchronize(self):
         self._ck(self.c.smhip_sharded_synchronize())
 

@@ -830,6 +830,19 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
     }
     Launch L;
     if (int rc = plan_launch(pl, (int)dtype_size(dtype), heavy, &L)) return rc;
+    {   // the plan's policy word came from sizes alone; now the operands are known: cold ones are read non-temporally
+        // (internal.h: refine_policy), and the launch's touches go on record
+        const size_t esz = dtype_size(dtype);
+        auto span = [&](const void *p, const int64_t *st) {
+            int64_t last = 0;
+            for (int d = 0; d < pl.ndim; ++d) last += (pl.shape[d] - 1) * st[d];
+            return Span{p, (size_t)(last + 1) * esz};
+        };
+        uint32_t *word = L.kind == Launch::kRow ? &L.p.row.nt : L.kind == Launch::kLds ? &L.p.lds.nt : L.kind == Launch::kTile ? &L.p.tile.nt
+                         : L.kind == Launch::kStrided ? &L.p.strided.nt : nullptr;
+        const int refined = refine_policy(word ? (int)*word : 0, {span(a, pl.sa), span(b, pl.sb)}, Span{out, pl.n * esz});
+        if (word) *word = (uint32_t)refined;
+    }
     if (user) return jit_launch(op, dtype, L, a, b, out, s);
     // rows of 2..15 elements against one value per row: x dense (r, 1), y a dense vector (1, 0)
     if (L.kind == Launch::kGather && pl.ndim == 2 && pl.shape[1] >= 2 && pl.shape[1] < 16 && op != SMHIP_OP_LEFT) {

@@ -243,7 +243,7 @@ template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
-    const int nt = stream_policy((KIND == 0 ? 2 : 1) * n_vec * 16, n_vec * 16);
+    const int nt = KIND == 0 ? stream_policy({{pa, n_vec * 16}, {pb, n_vec * 16}}, {po, n_vec * 16}) : stream_policy({{pa, n_vec * 16}}, {po, n_vec * 16});
     if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
     else hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
 }
@@ -260,10 +260,10 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
     constexpr int U = IsHeavy<Op>::value ? HeavyTile<T, 0>::value : SMHIP_FLAT_ROWS_U;
     const size_t n_vec = rows * (cols / W);
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;
-    const int nt = stream_policy(rows * cols * sizeof(T), rows * cols * sizeof(T));
-    const FastDiv cv((uint32_t)(cols / W));
     const T *pa = static_cast<const T *>(a), *pb = static_cast<const T *>(b);
     T *po = static_cast<T *>(out);
+    const int nt = stream_policy({{pa, rows * cols * sizeof(T)}}, {po, rows * cols * sizeof(T)});
+    const FastDiv cv((uint32_t)(cols / W));
     const dim3 grid((unsigned)tiles), block(kTileBlock);
     if (b_is_row) {
         if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
@@ -297,14 +297,14 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
     } else if (n_vec >= kBigThreshold) {
         if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
-        const int pol = stream_policy(2 * n * sizeof(T), n * sizeof(T));
+        const int pol = stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)});
         if (pol & kStoreKeep) hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, true>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
         else hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, false>), dim3(grid), dim3(kBlockBig), 0, s, pa, pb, po, n_vec, tail, pol);
     } else {
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
         // below kBigThreshold vectors (16 MiB per operand: 48 MiB in all at most) a footprint above the keep-store floor
         // is a corner this form does not serve
-        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall, false>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy(2 * n * sizeof(T), n * sizeof(T)) & ~kStoreKeep);
+        hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockSmall, false>), dim3(grid), dim3(kBlockSmall), 0, s, pa, pb, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)}) & ~kStoreKeep);
     }
     SMHIP_LAUNCH_CHECK("contiguous");
     return SMHIP_OK;
@@ -339,10 +339,10 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         if (value == T(2) || value == T(1) || value == T(-1) || value == T(0.5)) {
             if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
             const dim3 g(grid), b(kBlockSmall);
-            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
-            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
-            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
-            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
+            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
+            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
+            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
+            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
             SMHIP_LAUNCH_CHECK("array_scalar pow (exact form)");
             return SMHIP_OK;
         }
@@ -355,7 +355,7 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
+        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
     }
     SMHIP_LAUNCH_CHECK("array_scalar");
     return SMHIP_OK;
@@ -371,7 +371,7 @@ int run_devscalar(const void *a, const void *sp, size_t n, void *out, hipStream_
     const size_t n_vec = n / W;
     const int tail = (int)(n % W);
     if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
-    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail, stream_policy(n * sizeof(T), n * sizeof(T)));
+    hipLaunchKernelGGL((devscalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, ps, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
     SMHIP_LAUNCH_CHECK("array_devscalar");
     return SMHIP_OK;
 }

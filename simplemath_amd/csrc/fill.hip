@@ -51,7 +51,7 @@ int run_fill(void *dst, const void *value_host, size_t n, hipStream_t s) {
     const size_t n_vec = n / W;
     const size_t g = (n_vec + 1 + 255) / 256;
     if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fill too large");
-    hipLaunchKernelGGL(fill_vec_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, p, v, n_vec, n, stream_policy(0, n * sizeof(T)));
+    hipLaunchKernelGGL(fill_vec_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, p, v, n_vec, n, stream_policy({}, {p, n * sizeof(T)}));
     SMHIP_LAUNCH_CHECK("fill");
     return SMHIP_OK;
 }
@@ -74,6 +74,7 @@ int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first,
     const size_t g = (n + 255) / 256;
     hipLaunchKernelGGL(uniform_f32_kernel, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(256), 0, s, dst, n,
                        seed * 0x9E3779B97F4A7C15ULL, first, lo, hi - lo);
+    (void)stream_policy({}, {dst, n * sizeof(float)});  // on record as just written (internal.h: residency)
     SMHIP_LAUNCH_CHECK("fill_uniform_f32");
     return SMHIP_OK;
 }

@@ -52,8 +52,8 @@ int run(const void *a_, const void *b_, const void *c_, const void *cs_host, voi
     const size_t n_vec = n / W, threads = n_vec + (n % W ? 1 : 0);
     const size_t g = (threads + kBlock - 1) / kBlock;
     if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused: array too large for one launch");
-    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_policy(2 * n * sizeof(T), n * sizeof(T)));
-    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_policy(3 * n * sizeof(T), n * sizeof(T)));
+    if (scalar) hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, true>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {out, n * sizeof(T)}));
+    else hipLaunchKernelGGL((fused_vec_kernel<T, Op1, Op2, false>), dim3((unsigned)g), dim3(kBlock), 0, s, a, b, c, cs, out, n_vec, (int)(n % W), stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}, {c, n * sizeof(T)}}, {out, n * sizeof(T)}));
     SMHIP_LAUNCH_CHECK("fused");
     return SMHIP_OK;
 }

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <initializer_list>
+
 #include "smhip.h"
 
 namespace smhip {
@@ -80,6 +82,20 @@ inline int stream_reads(size_t bytes_read) { return bytes_read > kInfinityCacheB
 constexpr size_t kStoreKeepFloor = (size_t)40 << 20;
 constexpr int kPolicyLoadNt = 1, kPolicyStoreKeep = 2;  // the word's bits; ops.hip.h (dev::kLoadNt / kStoreKeep) and jit.hip's preludes mirror them
 int stream_policy(size_t bytes_read, size_t bytes_written);
+// The same word for a launch whose operands are known: reads of spans that the library has NOT touched recently --
+// nothing of theirs can be in the Infinity Cache -- get the non-temporal hint at any size.  Round 2's rule (plain loads
+// whenever a launch reads <= 256 MiB) is tuned to operands that repeat or were just produced; on cold operands plain loads
+// cost 3-12 % (tools/sweep_cold.hip -> profiles/r03_sweep_cold.txt: 2R+1W at 64 MiB per array 35.7 us plain, 32.5 us nt).
+// The library cannot see the cache, but it knows what it launched: a per-device ring of the spans its recent launches read
+// and wrote, each stamped with the device's running byte count (runtime.hip: residency tracker).  A span is WARM when a
+// launch touched it within the last kWarmWindow bytes of library traffic on that device.  Also records this launch's
+// touches.  A hint only: a wrong guess costs a few percent, never a wrong result.  SMHIP_RESIDENCY=off restores round 2's rule.
+struct Span { const void *p; size_t bytes; };
+constexpr size_t kWarmWindow = (size_t)192 << 20, kTrackFloor = (size_t)2 << 20;
+int stream_policy(std::initializer_list<Span> reads, Span write);
+// The same refinement for a policy word that was planned from sizes alone (broadcast.hip's plans are shared with the
+// run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
+int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
 
 inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }
 inline bool valid_dtype(int dtype) { return dtype >= SMHIP_F32 && dtype <= SMHIP_I64; }

@@ -458,7 +458,7 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
     const size_t threads = vec ? n_vec + 1 : n;
     const size_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
-    int pol = stream_policy(2 * n * dtype_size(dtype), n * dtype_size(dtype));
+    int pol = stream_policy({{a, n * dtype_size(dtype)}, {b, n * dtype_size(dtype)}}, {out, n * dtype_size(dtype)});
     void *args[] = {&a, &b, &out, &n_vec, &nn, &vec, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
@@ -474,7 +474,7 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
     unsigned char scalar[8];
     memcpy(scalar, value_host, dtype_size(dtype));
-    int pol = stream_policy(n * dtype_size(dtype), n * dtype_size(dtype));
+    int pol = stream_policy({{a, n * dtype_size(dtype)}}, {out, n * dtype_size(dtype)});
     void *args[] = {&a, scalar, &out, &n_vec, &nn, &swapped, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
@@ -562,6 +562,13 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     unsigned char sc[32] = {};  // Scalars { T v[4]; }: runtime values, so changing them does not recompile
     if (n_scalars > 0) memcpy(sc, scalars_host, (size_t)n_scalars * dtype_size(dtype));
     int pol = stream_policy((size_t)n_operands * n * dtype_size(dtype), out ? n * dtype_size(dtype) : 0);
+    {   // operands nothing has touched recently are read non-temporally (internal.h: refine_policy); one call per operand
+        // keeps the initializer lists fixed-size -- the hint is per launch, so any cold majority decides
+        int refined = pol;
+        for (int k = 0; k < n_operands; ++k)
+            refined |= refine_policy(pol, {{operands[k], n * dtype_size(dtype)}}, {k == 0 ? out : nullptr, k == 0 && out ? n * dtype_size(dtype) : 0});
+        pol = refined;
+    }
     if (!sum_dev) {
         void *args[] = {&in, sc, &out, &n_vec, &nn, &pol};
         SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, 0, s, args, nullptr));

@@ -337,7 +337,8 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
         if (int rc = lease.take(blocks + blocks / kGroupTarget + 2, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
     hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
-                       static_cast<T *>(out_native), stream_policy((MODE == kSum ? 1 : 2) * n * sizeof(T), MODE == kFused ? n * sizeof(T) : 0));
+                       static_cast<T *>(out_native), MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
+                                    : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0}));
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
     return launch_finish<T, MODE != kDot>(partials, blocks, out8, static_cast<T *>(out_native), s);

@@ -292,6 +292,65 @@ int stream_policy(size_t bytes_read, size_t bytes_written) {
     return policy;
 }
 
+// ---- residency tracker (internal.h: stream_policy(reads, write)) ----
+namespace {
+struct Touch { uintptr_t lo = 0, hi = 0; uint64_t tick = 0; };
+struct Tracker {
+    std::mutex m;
+    uint64_t tick = 0;  // bytes the library's launches have moved on this device
+    Touch ring[32];
+    int next = 0;
+};
+Tracker g_track[kMaxDevices];
+
+bool warm(const Tracker &t, const Span &sp) {
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(sp.p), hi = lo + sp.bytes;
+    for (const Touch &e : t.ring)
+        if (e.hi > e.lo && e.lo <= lo && hi <= e.hi && t.tick - e.tick <= kWarmWindow) return true;
+    return false;
+}
+void touch(Tracker &t, const Span &sp) {
+    if (!sp.p || sp.bytes < kTrackFloor) return;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(sp.p), hi = lo + sp.bytes;
+    for (Touch &e : t.ring)
+        if (e.hi > e.lo && e.lo <= lo && hi <= e.hi) {  // inside a span already on record (the same array, or a view of it)
+            if (e.lo == lo && e.hi == hi) { e.tick = t.tick; return; }
+        }
+    for (Touch &e : t.ring)
+        if (e.hi > e.lo && lo <= e.lo && e.hi <= hi) e = Touch{};  // a wider touch replaces the records it covers
+    t.ring[t.next] = Touch{lo, hi, t.tick};
+    t.next = (t.next + 1) % 32;
+}
+}  // namespace
+
+int stream_policy(std::initializer_list<Span> reads, Span write) {
+    size_t bytes_read = 0;
+    for (const Span &r : reads) bytes_read += r.bytes;
+    return refine_policy(stream_policy(bytes_read, write.bytes), reads, write);
+}
+
+int refine_policy(int policy, std::initializer_list<Span> reads, Span write) {
+    size_t bytes_read = 0;
+    for (const Span &r : reads) bytes_read += r.bytes;
+    static const bool off = [] { const char *e = getenv("SMHIP_RESIDENCY"); return e && strcmp(e, "off") == 0; }();
+    if (off) return policy;
+    Tracker &t = g_track[current_device()];
+    std::lock_guard<std::mutex> lock(t.m);
+    if (!(policy & kPolicyLoadNt)) {
+        size_t considered = 0, cold = 0;
+        for (const Span &r : reads) {
+            if (!r.p || r.bytes < kTrackFloor) continue;  // small operands live in the L2s whatever the hint says
+            considered += r.bytes;
+            if (!warm(t, r)) cold += r.bytes;
+        }
+        if (considered && 2 * cold > considered) policy |= kPolicyLoadNt;
+    }
+    t.tick += bytes_read + write.bytes;
+    for (const Span &r : reads) touch(t, r);
+    touch(t, write);
+    return policy;
+}
+
 ThreadDeviceScope::ThreadDeviceScope(int device) : prev_device_(tls.device), prev_use_user_(tls.use_user_stream) {
     tls.device = device;
     tls.use_user_stream = false;

@@ -15,6 +15,8 @@
 // RCCL is dlopen'ed on first use: a single-GPU program never loads it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -35,6 +37,11 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: CommDestroy if absent
 };
 
 std::mutex g_mutex;  // guards everything below
@@ -64,9 +71,28 @@ int load_rccl() {  // caller holds g_mutex
     SMHIP_SYM(GroupStart, "ncclGroupStart");
     SMHIP_SYM(GroupEnd, "ncclGroupEnd");
     SMHIP_SYM(GetErrorString, "ncclGetErrorString");
+    SMHIP_SYM(GetVersion, "ncclGetVersion");
+    SMHIP_SYM(CommCount, "ncclCommCount");
+    SMHIP_SYM(CommUserRank, "ncclCommUserRank");
+    SMHIP_SYM(CommCuDevice, "ncclCommCuDevice");
 #undef SMHIP_SYM
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl_loaded = true;
     return SMHIP_OK;
+}
+
+// SMHIP_TEST_FAIL_COMM_INIT=1 makes smhip_set_devices behave as if ncclCommInitAll had failed: the error path's
+// clean-up (slots back to the pool, no group left behind) is then testable on a one-GPU box.
+bool test_hook_fail_comm_init() {
+    const char *e = getenv("SMHIP_TEST_FAIL_COMM_INIT");
+    return e && e[0] == '1';
+}
+
+// SMHIP_TEST_FAIL_ALLREDUCE=<g>: the group all-reduce fails when it reaches device g (after devices 0..g-1 have queued
+// their half) -- the "partly issued collective" path.
+bool test_hook_fail_allreduce(int g) {
+    const char *e = getenv("SMHIP_TEST_FAIL_ALLREDUCE");
+    return e && e[0] && atoi(e) == g;
 }
 
 #define SMHIP_NCCL(expr)                                                                                       \
@@ -75,13 +101,26 @@ int load_rccl() {  // caller holds g_mutex
         if (nccl_r_ != ncclSuccess) return fail(SMHIP_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(nccl_r_)); \
     } while (0)
 
-int dissolve_group() {  // caller holds g_mutex
-    for (int g = 0; g < g_ndev; ++g) {
+// Takes the group apart: devices 0..upto-1 (the whole group by default; a half-built one from smhip_set_devices' error
+// paths).  abort: a collective was only partly issued -- the communicators are aborted (ncclCommAbort tears the queued
+// work down instead of waiting for peers that will never arrive) rather than destroyed, and the streams are not waited for
+// first (they may be stuck behind that collective).  Caller holds g_mutex.
+int dissolve_group(int upto = -1, bool abort = false) {
+    if (upto < 0) upto = g_ndev;
+    for (int g = 0; g < upto; ++g) {
         ThreadDeviceScope scope(g);
         hipStream_t s;
-        if (acquire(&s) == SMHIP_OK) (void)hipStreamSynchronize(s);
-        if (g_comms[g]) (void)g_rccl.CommDestroy(g_comms[g]);
+        if (!abort && acquire(&s) == SMHIP_OK) (void)hipStreamSynchronize(s);
+        if (g_comms[g]) {
+            if (abort && g_rccl.CommAbort) (void)g_rccl.CommAbort(g_comms[g]);
+            else (void)g_rccl.CommDestroy(g_comms[g]);
+        }
         g_comms[g] = nullptr;
+    }
+    for (int g = 0; g < upto; ++g) {
+        ThreadDeviceScope scope(g);
+        hipStream_t s;
+        if (abort && acquire(&s) == SMHIP_OK) (void)hipStreamSynchronize(s);  // after the abort the streams drain
         if (g_slot[g]) smhip_free(g_slot[g]);
         g_slot[g] = nullptr;
     }
@@ -113,15 +152,28 @@ int group_allreduce(int n, ncclDataType_t type, size_t count) {
         if (int rc = acquire(&streams[g])) return rc;
     }
     std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_ndev != n) return fail(SMHIP_ERR_INVALID, "the device group changed while a sharded reduction was being issued");
     SMHIP_NCCL(g_rccl.GroupStart());
     for (int g = 0; g < n; ++g) {
-        const ncclResult_t r = g_rccl.AllReduce(g_slot[g], g_slot[g], count, type, ncclSum, g_comms[g], streams[g]);
+        const ncclResult_t r = test_hook_fail_allreduce(g) ? ncclInternalError
+                                                           : g_rccl.AllReduce(g_slot[g], g_slot[g], count, type, ncclSum, g_comms[g], streams[g]);
         if (r != ncclSuccess) {
+            // devices 0..g-1 have their half of the collective queued and would wait for the others for ever: close the
+            // group, abort the communicators, leave no group behind (the caller gets the error and may form a new one)
             (void)g_rccl.GroupEnd();
-            return fail(SMHIP_ERR_HIP, "ncclAllReduce on device %d: %s", g, g_rccl.GetErrorString(r));
+            char why[256];
+            snprintf(why, sizeof why, "%s", g_rccl.GetErrorString(r));
+            dissolve_group(-1, true);
+            return fail(SMHIP_ERR_HIP, "ncclAllReduce on device %d: %s; the device group was dissolved (call smhip_set_devices again)", g, why);
         }
     }
-    SMHIP_NCCL(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (end != ncclSuccess) {
+        char why[256];
+        snprintf(why, sizeof why, "%s", g_rccl.GetErrorString(end));
+        dissolve_group(-1, true);
+        return fail(SMHIP_ERR_HIP, "ncclGroupEnd: %s; the device group was dissolved (call smhip_set_devices again)", why);
+    }
     return SMHIP_OK;
 }
 
@@ -186,13 +238,33 @@ int smhip_set_devices(int n) {
         devlist[g] = g;
         ThreadDeviceScope scope(g);
         hipStream_t s;
-        if (int rc = acquire(&s)) return rc;  // checks the architecture and creates the device's stream
-        if (int rc = smhip_alloc(&g_slot[g], 16)) return rc;
+        int rc = acquire(&s);  // checks the architecture and creates the device's stream
+        if (!rc) rc = smhip_alloc(&g_slot[g], 16);
+        if (rc) {
+            dissolve_group(g, false);  // the slots of devices 0..g-1 go back to the pool; no group is left behind
+            return rc;
+        }
     }
+    ncclResult_t r;
     {
         // ncclCommInitAll leaves the last device current; put this thread back afterwards
         ThreadDeviceScope scope(current_device());
-        SMHIP_NCCL(g_rccl.CommInitAll(g_comms, n, devlist));
+        for (int g = 0; g < n; ++g) g_comms[g] = nullptr;
+        r = test_hook_fail_comm_init() ? ncclInternalError : g_rccl.CommInitAll(g_comms, n, devlist);
+    }
+    if (r != ncclSuccess) {
+        char why[256];
+        snprintf(why, sizeof why, "%s", g_rccl.GetErrorString(r));
+        dissolve_group(n, false);
+        return fail(SMHIP_ERR_HIP, "ncclCommInitAll(%d devices): %s", n, why);
+    }
+    // what RCCL itself says it built: every communicator must count n ranks and sit on its device
+    for (int g = 0; g < n; ++g) {
+        int count = -1, dev = -1;
+        if (g_rccl.CommCount(g_comms[g], &count) != ncclSuccess || g_rccl.CommCuDevice(g_comms[g], &dev) != ncclSuccess || count != n || dev != g) {
+            dissolve_group(n, false);
+            return fail(SMHIP_ERR_HIP, "ncclCommInitAll: communicator %d reports %d ranks on device %d (expected %d ranks on device %d)", g, count, dev, n, g);
+        }
     }
     g_ndev = n;
     return SMHIP_OK;
@@ -303,6 +375,74 @@ int smhip_sharded_dot(int dtype, const void *const *a, const void *const *b, con
     return SMHIP_OK;
 }
 
+/* ------------------------------------------------------ device to device */
+
+namespace {
+bool g_peer_enabled[kMaxGroup][kMaxGroup] = {};  // [accessing device][peer]; guarded by g_mutex
+
+// Lets `device` map `peer`'s memory (so copies between them go over xGMI directly).  A pair that cannot is left alone:
+// hipMemcpyPeerAsync then stages through the host by itself.
+void enable_peer(int device, int peer) {
+    if (device == peer || device >= kMaxGroup || peer >= kMaxGroup) return;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_peer_enabled[device][peer]) return;
+        g_peer_enabled[device][peer] = true;
+    }
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can) { (void)hipGetLastError(); return; }
+    ThreadDeviceScope scope(device);
+    hipStream_t s;
+    if (acquire(&s) != SMHIP_OK) return;
+    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled included
+}
+}  // namespace
+
+int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes) {
+    if (bytes == 0) return SMHIP_OK;
+    if (!dst || !src) return fail(SMHIP_ERR_INVALID, "copy_peer: null");
+    int have = 0;
+    smhip_device_count(&have);
+    if (dst_device < 0 || src_device < 0 || dst_device >= have || src_device >= have)
+        return fail(SMHIP_ERR_INVALID, "copy_peer: device %d -> %d, %d present", src_device, dst_device, have);
+    if (src_device == dst_device) {
+        ThreadDeviceScope scope(dst_device);
+        return smhip_copy(dst, src, bytes);
+    }
+    enable_peer(dst_device, src_device);
+    enable_peer(src_device, dst_device);
+    hipStream_t s_src, s_dst;
+    hipEvent_t ready = nullptr, done = nullptr;
+    {
+        ThreadDeviceScope scope(src_device);
+        if (int rc = acquire(&s_src)) return rc;
+        SMHIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        const hipError_t e = hipEventRecord(ready, s_src);  // everything queued on the source's stream so far
+        if (e != hipSuccess) { (void)hipEventDestroy(ready); return fail(SMHIP_ERR_HIP, "copy_peer: hipEventRecord: %s", hipGetErrorString(e)); }
+    }
+    int rc = SMHIP_OK;
+    {
+        ThreadDeviceScope scope(dst_device);
+        rc = acquire(&s_dst);
+        hipError_t e = hipSuccess;
+        if (!rc) e = hipStreamWaitEvent(s_dst, ready, 0);
+        if (!rc && e == hipSuccess) e = hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, s_dst);
+        if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (!rc && e == hipSuccess) e = hipEventRecord(done, s_dst);
+        if (!rc && e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "copy_peer %d -> %d: %s", src_device, dst_device, hipGetErrorString(e));
+    }
+    if (!rc) {
+        // the source's stream continues only after the copy has read it (its buffer may be freed or overwritten next)
+        ThreadDeviceScope scope(src_device);
+        const hipError_t e = hipStreamWaitEvent(s_src, done, 0);
+        if (e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "copy_peer: hipStreamWaitEvent: %s", hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(ready);  // destruction is deferred by the runtime until the recorded work has passed
+    if (done) (void)hipEventDestroy(done);
+    return rc;
+}
+
 /* -------------------------------------------------- one process per GPU */
 
 int smhip_comm_unique_id(void *id128) {
@@ -337,8 +477,35 @@ int smhip_comm_init_rank(int nranks, int rank, const void *id128) {
 
 int smhip_comm_info(int *nranks, int *rank) {
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (nranks) *nranks = g_rank_comm ? g_nranks : 0;
-    if (rank) *rank = g_rank_comm ? g_rank : -1;
+    int n = 0, r = -1;
+    if (g_rank_comm) {  // what RCCL says about the communicator, not what this library was told
+        SMHIP_NCCL(g_rccl.CommCount(g_rank_comm, &n));
+        SMHIP_NCCL(g_rccl.CommUserRank(g_rank_comm, &r));
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    return SMHIP_OK;
+}
+
+int smhip_group_info(int index, int *nranks, int *rank, int *device) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_ndev <= 0) return fail(SMHIP_ERR_INVALID, "group_info: no device group (call smhip_set_devices(n) first)");
+    if (index < 0 || index >= g_ndev) return fail(SMHIP_ERR_INVALID, "group_info: index %d outside the group of %d", index, g_ndev);
+    int n = 0, r = -1, d = -1;
+    SMHIP_NCCL(g_rccl.CommCount(g_comms[index], &n));
+    SMHIP_NCCL(g_rccl.CommUserRank(g_comms[index], &r));
+    SMHIP_NCCL(g_rccl.CommCuDevice(g_comms[index], &d));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
+    return SMHIP_OK;
+}
+
+int smhip_rccl_version(int *version) {
+    if (!version) return fail(SMHIP_ERR_INVALID, "rccl_version: null");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (int rc = load_rccl()) return rc;
+    SMHIP_NCCL(g_rccl.GetVersion(version));
     return SMHIP_OK;
 }
 

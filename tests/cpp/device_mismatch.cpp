@@ -1,0 +1,41 @@
+// Operands resident on different GPUs must be refused, not launched on the calling thread's device: needs no
+// second GPU and no GPU at all -- the check is host-side and comes before any device call.  Storage::device is what
+// sm::Sharded<T>::part(g) hands out for GPU g; here it is set by hand.
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "sm.h"
+
+template <typename F>
+static int expect_mismatch(const char *what, F &&f) {
+    try {
+        f();
+    } catch (const std::runtime_error &e) {
+        const std::string msg = e.what();
+        if (msg.find("different GPUs (0 and 1)") != std::string::npos || msg.find("different GPUs (1 and 0)") != std::string::npos) return 0;
+        std::printf("FAIL %s: threw \"%s\"\n", what, e.what());
+        return 1;
+    }
+    std::printf("FAIL %s: did not throw\n", what);
+    return 1;
+}
+
+int main() {
+    sm::SMArray<float> a = {1, 2, 3, 4}, b = {5, 6, 7, 8}, c = {1, 1, 1, 1};
+    sm::SMArray<int> ia = {1, 2, 3}, ib = {4, 5, 6};
+    b.data.storage()->device = 1;  // as if b lived on GPU 1
+    ib.data.storage()->device = 1;
+    int bad = 0;
+    bad += expect_mismatch("a + b", [&] { auto r = a + b; });
+    bad += expect_mismatch("b * a", [&] { auto r = b * a; });
+    bad += expect_mismatch("a % b", [&] { volatile float r = a % b; (void)r; });
+    bad += expect_mismatch("ia % ib", [&] { volatile int r = ia % ib; (void)r; });
+    bad += expect_mismatch("a(view) = b(view)", [&] { a(SLICE(0, 2)) = b(SLICE(0, 2)); });
+    bad += expect_mismatch("fused(a, c, b)", [&] { auto r = sm::fused<AddOp<float>, MultiplyOp<float>>(a, c, b); });
+    bad += expect_mismatch("fused(a, b, 2)", [&] { auto r = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, 2.0f); });
+    bad += expect_mismatch("expr(a, c, b)", [&] { auto r = sm::expr("a0 + a1 * a2", a, c, b); });
+    bad += expect_mismatch("expr_sum(a, b)", [&] { volatile double r = sm::expr_sum("a0 * a1", a, b); (void)r; });
+    std::printf(bad ? "%d FAILED\n" : "device_mismatch ok\n", bad);
+    return bad ? 1 : 0;
+}

@@ -4,6 +4,7 @@ import importlib.util
 import os
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -59,17 +60,55 @@ def test_metric_string_is_baselines():
     assert b.HBM_PEAK_GBS == 8000.0
 
 
-def test_plain_multi_gpu_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher starts one process per GPU itself (before touching HIP).  Here, without
-    a GPU, every rank must then fail loudly -- there is no CPU fallback -- and the failure is the children's, not a refusal
-    to start."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=600,
-                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
-    text = r.stderr + r.stdout
-    assert r.returncode != 0
-    assert "no CPU fallback" in text or "no HIP device" in text or "No HIP GPUs" in text or "ProcessGroupNCCL" in text, text[-2000:]
-    assert "launch multi-GPU runs with" not in text
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"), timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    return r, time.time() - t
+
+
+def test_more_ranks_than_gpus_is_refused_before_anything_starts():
+    """`python bench.py --gpus 2` with no launcher would start one process per GPU itself.  With fewer GPUs than ranks (here:
+    none) it refuses up front: exit 2, one line saying how many GPUs a rank would see -- the count comes from a child process,
+    so the parent still has not touched HIP."""
+    r, took = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stderr.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "--gpus 2" in lines[0] and "0 GPU(s)" in lines[0] and "refusing to start" in lines[0], r.stderr[-2000:]
+    assert r.stdout.strip() == "" and took < 120
+
+
+def test_a_dying_rank_takes_its_siblings_with_it():
+    """Self-started ranks (gloo rehearsal: no GPU count check): rank 1 exits with code 7 before the rendezvous; rank 0 is left
+    waiting there.  The parent must notice, stop rank 0 (by its own process group) and return 7 -- at once, not after
+    torch's rendezvous timeout."""
+    r, took = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--log2n", "20"],
+                         {"SMHIP_BENCH_TEST_DIE_RANK": "1"})
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 exited with code 7; stopping the other ranks" in r.stderr
+    assert took < 100, took  # init_process_group's own limit is 120 s; the parent does not wait for it
+
+
+def test_self_started_ranks_have_a_deadline():
+    r, took = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--log2n", "20", "--rank-timeout", "3"],
+                         {"SMHIP_BENCH_TEST_HANG_RANK": "0"})
+    assert r.returncode != 0 and took < 100
+    assert "still running after 3 s" in r.stderr or "exited with code" in r.stderr, r.stderr[-2000:]
+
+
+def test_a_rank_without_its_gpu_fails_at_once():
+    """Under a launcher (RANK in the environment) with the nccl backend a rank whose LOCAL_RANK has no GPU exits 2 with one
+    line: ranks are never folded onto fewer devices (only `--dist-backend gloo` rehearsals share a GPU)."""
+    r, took = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29571"}, drop=())
+    assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+    assert "wants GPU 1 but this process sees 0" in r.stderr and took < 200
+
+
+def test_single_mode_refuses_more_devices_than_present():
+    r, _ = _run_bench(["--gpus", "2", "--mode", "single", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 2 and "--mode single --gpus 2" in r.stderr and "refusing" in r.stderr, r.stderr[-2000:]
 
 
 import json

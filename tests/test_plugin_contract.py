@@ -47,3 +47,12 @@ def test_builtin_ops_never_take_the_host_path():
     prog = ('#include <sm.h>\n#include <complex>\nint main() { sm::SMArray<std::complex<double>> a = {{1, 2}}, b = {{3, 4}}; auto c = a + b; }\n')
     r = subprocess.run([CXX, "-std=c++20", "-fsyntax-only", f"-I{INC}", "-x", "c++", "-"], input=prog, capture_output=True, text=True)
     assert r.returncode != 0 and "no gfx950 kernels" in r.stderr  # std::complex arithmetic: diagnosed when compiled, not when run
+
+
+def test_operands_on_different_gpus_are_refused_on_the_host(smhip):
+    """ADVICE r02: an operator whose operands live on different GPUs (what sm::Sharded<T>::part(g) can hand out) throws
+    std::runtime_error before any device call -- it used to launch on the calling thread's device.  No GPU needed."""
+    from simplemath_amd import build
+    exe = build.build_host_programs()["device_mismatch"]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "device_mismatch ok" in r.stdout, r.stdout + r.stderr
