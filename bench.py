@@ -92,8 +92,23 @@ def parse():
 
 # ------------------------------------------------------------------------------------------- CPU baseline
 
+_USABLE = None
+
+
 def usable_cores():
-    """Physical cores this process may really use: affinity mask, SMT siblings and the cgroup CPU quota accounted for."""
+    """Physical cores this process may really use: affinity mask, SMT siblings and the cgroup CPU quota accounted for.
+    Counted ONCE per process: after libgomp has loaded with a binding policy (the first cpu_baseline leg) the calling thread
+    is pinned to one core and its affinity mask no longer says what the process may use."""
+    global _USABLE
+    env = os.environ.get("SMHIP_BENCH_CPU_THREADS")
+    if env:
+        return max(int(env), 1), dict((_USABLE or (0, {}))[1], override="SMHIP_BENCH_CPU_THREADS")
+    if _USABLE is None:
+        _USABLE = _count_usable_cores()
+    return _USABLE[0], dict(_USABLE[1])
+
+
+def _count_usable_cores():
     info = {}
     try:
         logical = len(os.sched_getaffinity(0))
@@ -131,10 +146,6 @@ def usable_cores():
     if quota is not None:
         info["cgroup_cpu_quota"] = quota
         cores = max(min(cores, int(quota)), 1)
-    env = os.environ.get("SMHIP_BENCH_CPU_THREADS")
-    if env:
-        cores = max(int(env), 1)
-        info["override"] = "SMHIP_BENCH_CPU_THREADS"
     return cores, info
 
 
@@ -479,6 +490,12 @@ def config_legs(lib, sma, np, C, args, bound):
         leg = None
         for setting in ("replay", "cold"):
             steps, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, 0, bound, setting, log2n=0)
+            t_pre, i_pre = time.perf_counter(), 0
+            while time.perf_counter() - t_pre < 0.05:  # the clocks sag while operand sets are freed and rebuilt
+                for _ in range(10):
+                    steps[i_pre % len(steps)]()
+                    i_pre += 1
+                lib.synchronize()
             ms, _ = time_steps(lib, steps, n_steps, 20)
             if leg is None:
                 leg = {"workload": workload, "kernel": kernel, "algorithmic_bytes_per_launch": alg_bytes, "elements": units}

@@ -464,6 +464,7 @@ public:
     T *device_data_mut() { return data.storage()->dev_wo() + data.offset(); }
     bool is_dense() const { return is_contiguous(_shape, _strides); }
     bool is_view() const { return isView; }
+    void copy_dense_out(T *dst) const { copy_dense_to(dst); }  // this array's elements, row-major, into host memory
     int device() const { return data.storage()->device; }  // the GPU this array's elements live on
     // The GPU two operands of one operator share.  Kernels run on the operands' device (the operators take a DeviceGuard on
     // it, whatever GPU the calling thread is on); operands resident on DIFFERENT GPUs cannot meet in one kernel -- peer

@@ -19,6 +19,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <utility>
 #include <vector>
@@ -51,46 +52,41 @@ public:
     static Sharded zeros(Dims... dims) { const T v{0}; return make({static_cast<std::size_t>(dims)...}, &v); }
     static Sharded full(std::vector<std::size_t> shape, T value) { return make(std::move(shape), &value); }
 
-    // Block g of `whole`'s outermost dimension goes to GPU g (staged through the host mirror: set-up, not hot path).
+    // Block g of `whole`'s outermost dimension goes to GPU g.  A device-resident array travels device to device
+    // (smhip_copy_peer: hipMemcpyPeerAsync over xGMI, all destinations in flight at once, stream-ordered on both sides); an
+    // array that exists only in host memory is uploaded block by block straight from its host mirror.
     static Sharded scatter(const SMArray<T> &whole) {
         Sharded r = layout(whole.shape(), false);
-        SMArray<T> dense_holder = whole.contiguous();
-        const T *src = dense_holder.data.read();
         const std::size_t inner = r.inner_size();
-        for (int g = 0; g < r.group(); ++g) {
-            hip::DeviceGuard on(g);
-            const std::size_t count = r.rows_[g] * inner;
-            T *buf = new T[count ? count : 1];
-            std::copy(src + r.starts_[g] * inner, src + r.starts_[g] * inner + count, buf);
-            r.parts_.emplace_back(buf, r.part_shape(g));
-            r.parts_.back().device_data();  // upload now, on its own GPU
-        }
+        r.fill_parts(whole, [&](int g) { return std::pair<std::size_t, std::size_t>(r.starts_[g] * inner, r.rows_[g] * inner); });
         return r;
     }
     // A full copy of `whole` on every GPU: how an operand that is broadcast along the outermost dimension takes part.
     static Sharded replicate(const SMArray<T> &whole) {
         Sharded r = layout(whole.shape(), true);
-        SMArray<T> dense_holder = whole.contiguous();
-        const T *src = dense_holder.data.read();
-        for (int g = 0; g < r.group(); ++g) {
-            hip::DeviceGuard on(g);
-            T *buf = new T[whole.totalSize ? whole.totalSize : 1];
-            std::copy(src, src + whole.totalSize, buf);
-            r.parts_.emplace_back(buf, std::vector<std::size_t>(whole.shape()));
-            r.parts_.back().device_data();
-        }
+        r.fill_parts(whole, [&](int) { return std::pair<std::size_t, std::size_t>(0, whole.totalSize); });
         return r;
     }
-    // The whole array again, on the calling thread's current GPU (through the host).
+    // The whole array again, on the calling thread's current GPU: one peer copy per block, device to device.
     SMArray<T> gather() const {
-        if (replicated_) return parts_[0].contiguous();
-        const std::size_t total = calculateTotalSize(shape_), inner = inner_size();
-        T *buf = new T[total ? total : 1];
-        for (int g = 0; g < group(); ++g) {
-            const T *p = parts_[g].data.read();
-            std::copy(p, p + rows_[g] * inner, buf + starts_[g] * inner);
+        if (replicated_) {
+            int here = 0;
+            hip::check(smhip_get_device(&here));
+            for (int g = 0; g < group(); ++g)
+                if (parts_[g].device() == here) return parts_[g].contiguous();
+            SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(shape_));
+            hip::check(smhip_copy_peer(out.device_data_mut(), here, parts_[0].device_data(), parts_[0].device(), out.totalSize * sizeof(T)));
+            return out;
         }
-        return SMArray<T>(buf, std::vector<std::size_t>(shape_));
+        SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(shape_));
+        const std::size_t inner = inner_size();
+        T *dst = out.device_data_mut();
+        for (int g = 0; g < group(); ++g) {
+            const std::size_t count = rows_[g] * inner;
+            if (count == 0) continue;
+            hip::check(smhip_copy_peer(dst + starts_[g] * inner, out.device(), parts_[g].device_data(), parts_[g].device(), count * sizeof(T)));
+        }
+        return out;
     }
 
     // ---- elementwise: no collective ---------------------------------------------------------
@@ -227,6 +223,43 @@ private:
         for (int g = 0; g < group(); ++g) {
             hip::DeviceGuard on(g);
             parts_.push_back(SMArray<T>::device_empty(part_shape(g)));
+        }
+    }
+    // parts_[g] = elements [first, first + count) of `whole` (dense, row-major), as range(g) says, resident on GPU g
+    template <typename Range>
+    void fill_parts(const SMArray<T> &whole, Range &&range) {
+        allocate();
+        const auto &st = whole.data.storage();
+        if (st && st->dev_valid) {  // device-resident: peer copies, no host staging
+            std::unique_ptr<SMArray<T>> holder;
+            const SMArray<T> *src = &whole;
+            if (!whole.is_dense()) {
+                holder.reset(new SMArray<T>(whole.contiguous()));
+                src = holder.get();
+            }
+            const T *from = src->device_data();
+            for (int g = 0; g < group(); ++g) {
+                const auto [first, count] = range(g);
+                if (count == 0) continue;
+                hip::check(smhip_copy_peer(parts_[g].device_data_mut(), g, from + first, src->device(), count * sizeof(T)));
+            }
+            return;
+        }
+        // host-born: each GPU's block goes up from the host mirror directly
+        std::unique_ptr<SMArray<T>> holder;
+        const SMArray<T> *src = &whole;
+        if (!whole.is_dense()) {  // a strided host view: made dense on the host side first (set-up, not hot path)
+            T *flat = new T[whole.totalSize ? whole.totalSize : 1];
+            whole.copy_dense_out(flat);
+            holder.reset(new SMArray<T>(flat, std::vector<std::size_t>(whole.shape())));
+            src = holder.get();
+        }
+        const T *from = src->cdata();
+        for (int g = 0; g < group(); ++g) {
+            const auto [first, count] = range(g);
+            if (count == 0) continue;
+            hip::DeviceGuard on(g);
+            hip::check(smhip_upload(parts_[g].device_data_mut(), from + first, count * sizeof(T)));
         }
     }
     static Sharded make(std::vector<std::size_t> shape, const T *fill) {

@@ -35,6 +35,7 @@ public:
 private:
     int prev_device_;
     bool prev_use_user_;
+    void *bridged_ = nullptr;  // the library stream that was ordered after the caller's own stream on entry (and back on exit)
 };
 
 // The partials of ONE reduction call: `count` doubles from the pool, handed back when the lease ends.  The pool's

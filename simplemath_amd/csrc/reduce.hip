@@ -93,14 +93,17 @@ template <> __device__ __forceinline__ void add_prod<double, double>(double &acc
 enum Mode { kSum = 0, kDot = 1, kFused = 2 };
 
 // One vector's contribution: MODE kSum: acc += a;  kDot: acc += a*b;  kFused: out = a op b, acc += out.
-template <typename T, typename Op, int MODE, typename A>
+// KEEP: the write side's policy (ops.hip.h) at compile time -- as a run-time branch in front of the fused kernel's one store
+// it cost what it cost the plain add (1.6 %, contiguous.hip): round 2's main kernel ran at 498.9 us where the same loop
+// without the branch runs at the add's 493-494 us (tools/sweep_reduce.hip, profiles/r01_sweep_fused_sum.txt).
+template <typename T, typename Op, int MODE, bool KEEP, typename A>
 __device__ __forceinline__ void consume(const OpCtx<Op> &ctx, A &acc, typename VecTraits<T>::vec_t va, typename VecTraits<T>::vec_t vb,
-                                        typename VecTraits<T>::vec_t *out_slot, int nt) {
+                                        typename VecTraits<T>::vec_t *out_slot) {
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     if constexpr (MODE == kFused) {
         const V r = apply_vec<Op, T>(ctx, va, vb);
-        store_stream_if(T, out_slot, r, nt);
+        store_stream_as(T, out_slot, r, !KEEP);
 #pragma unroll
         for (int k = 0; k < W; ++k) acc += widen<T, A>(r[k]);
     } else if constexpr (MODE == kDot) {
@@ -138,6 +141,9 @@ __device__ __forceinline__ void write_result(typename AccOf<T>::type acc, void *
 // counters at zero, so a stream's buffer is always ready for the next launch; two streams never share one.  (A caller
 // stream that is destroyed leaves its 4 KiB behind; a later stream that gets the same handle finds them zeroed.)
 int reduce_counters(hipStream_t s, uint32_t **out);
+// A finishing launch on (device, stream) failed to enqueue: its counters may not be what the next launch expects (they
+// are, if the kernel never ran -- but nothing is assumed): the next reduce_counters() call zeroes them on the stream first.
+void reduce_counters_suspect(hipStream_t s);
 
 // What the finishing launch of a multi-workgroup reduction needs (finish_kernel).
 template <typename A> struct Finish {
@@ -154,7 +160,7 @@ constexpr uint32_t kMaxGroups = 1024, kGroupTarget = 1024;
 // before the first use, so kVecPerThread (x2 operands) 16-byte loads are in flight
 // per lane.  (Per-vector bounds guards made the compiler wait on each load pair
 // in turn -- 2.6 TB/s instead of 6.)
-template <typename T, typename Op, int MODE>
+template <typename T, typename Op, int MODE, bool KEEP>
 __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                            size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials,
                                                            void *__restrict__ out8, T *__restrict__ out_native, int nt) {
@@ -171,21 +177,30 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
     A acc = A(0);
     if ((size_t)blockIdx.x * kTile + kTile <= n_vec) {
         V va[kVecPerThread], vb[kVecPerThread];
+        if (nt & kLoadNt) {  // ONE branch around the tile's loads (ops.hip.h: a branch per load parks a full wait at every join)
 #pragma unroll
-        for (int u = 0; u < kVecPerThread; ++u) {
-            va[u] = load_stream_if(T, av + tile0 + (size_t)u * kBlock, nt);
-            if constexpr (MODE != kSum) vb[u] = load_stream_if(T, bv + tile0 + (size_t)u * kBlock, nt);
-            else vb[u] = va[u];
+            for (int u = 0; u < kVecPerThread; ++u) {
+                va[u] = load_stream_as(T, av + tile0 + (size_t)u * kBlock, true);
+                if constexpr (MODE != kSum) vb[u] = load_stream_as(T, bv + tile0 + (size_t)u * kBlock, true);
+                else vb[u] = va[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kVecPerThread; ++u) {
+                va[u] = load_stream_as(T, av + tile0 + (size_t)u * kBlock, false);
+                if constexpr (MODE != kSum) vb[u] = load_stream_as(T, bv + tile0 + (size_t)u * kBlock, false);
+                else vb[u] = va[u];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock, nt);
+        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, KEEP, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock);
     } else {
         for (int u = 0; u < kVecPerThread; ++u) {
             const size_t i = tile0 + (size_t)u * kBlock;
             if (i < n_vec) {
                 const V va = load_stream(av + i);
                 const V vb = MODE != kSum ? load_stream(bv + i) : va;
-                consume<T, Op, MODE, A>(ctx, acc, va, vb, ov + i, nt);
+                consume<T, Op, MODE, KEEP, A>(ctx, acc, va, vb, ov + i);
             }
         }
         // scalar tail (n % W elements): the last workgroup's first lane
@@ -240,7 +255,9 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     if (threadIdx.x == 0) {
         __hip_atomic_store(&fin.level2[blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        // ACQUIRE on the ticket: the last arriver's reads of level2[] below may not be hoisted above it or served
+        // from a stale line -- an invalidate behind the atomic, not the L2 write-back a release would cost
+        last = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last) return;
@@ -316,7 +333,10 @@ int launch_finish(typename AccOf<T>::type *partials, size_t blocks, void *out8, 
     if (groups > 1)
         if (int rc = reduce_counters(s, &fin.counters)) return rc;
     hipLaunchKernelGGL((finish_kernel<T, AS_DOUBLE>), dim3(groups, planes), dim3(kBlock), 0, s, partials, (uint32_t)blocks, fin, out8, out_native);
-    SMHIP_LAUNCH_CHECK("reduce finish");
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+        if (groups > 1) reduce_counters_suspect(s);
+        return fail(SMHIP_ERR_HIP, "launch reduce finish: %s", hipGetErrorString(e));
+    }
     return SMHIP_OK;
 }
 
@@ -336,30 +356,48 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     if (blocks > 1)
         if (int rc = lease.take(blocks + blocks / kGroupTarget + 2, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
-    hipLaunchKernelGGL((reduce_kernel<T, Op, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
-                       static_cast<T *>(out_native), MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
-                                    : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0}));
+    const int pol = MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
+                                 : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0});
+    if (MODE == kFused && (pol & kStoreKeep))
+        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, MODE == kFused>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
+                           static_cast<T *>(out_native), pol);
+    else
+        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
+                           static_cast<T *>(out_native), pol);
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
     return launch_finish<T, MODE != kDot>(partials, blocks, out8, static_cast<T *>(out_native), s);
 }
 
+struct CounterBuf { uint32_t *p; bool suspect; };
+std::mutex g_counter_mutex;
+std::map<std::pair<int, hipStream_t>, CounterBuf> g_counter_bufs;
+constexpr size_t kCounterBytes = 64;  // two counters (the complex dot's planes), on a cache line of their own
+
 int reduce_counters(hipStream_t s, uint32_t **out) {
-    static std::mutex mutex;
-    static std::map<std::pair<int, hipStream_t>, uint32_t *> buffers;
     const std::pair<int, hipStream_t> key(current_device(), s);
-    std::lock_guard<std::mutex> lock(mutex);
-    auto it = buffers.find(key);
-    if (it == buffers.end()) {
+    std::lock_guard<std::mutex> lock(g_counter_mutex);
+    auto it = g_counter_bufs.find(key);
+    if (it == g_counter_bufs.end()) {
         void *p = nullptr;
-        const size_t bytes = 64;  // one counter, on a cache line of its own
-        SMHIP_TRY(hipMalloc(&p, bytes));
-        SMHIP_TRY(hipMemset(p, 0, bytes));
+        SMHIP_TRY(hipMalloc(&p, kCounterBytes));
+        SMHIP_TRY(hipMemset(p, 0, kCounterBytes));
         SMHIP_TRY(hipDeviceSynchronize());
-        it = buffers.emplace(key, static_cast<uint32_t *>(p)).first;
+        it = g_counter_bufs.emplace(key, CounterBuf{static_cast<uint32_t *>(p), false}).first;
     }
-    *out = it->second;
+    if (it->second.suspect) {
+        SMHIP_TRY(hipMemsetAsync(it->second.p, 0, kCounterBytes, s));
+        it->second.suspect = false;
+    }
+    *out = it->second.p;
     return SMHIP_OK;
+}
+
+void reduce_counters_suspect(hipStream_t s) {
+    const std::pair<int, hipStream_t> key(current_device(), s);
+    std::lock_guard<std::mutex> lock(g_counter_mutex);
+    auto it = g_counter_bufs.find(key);
+    if (it != g_counter_bufs.end()) it->second.suspect = true;
 }
 
 }  // namespace

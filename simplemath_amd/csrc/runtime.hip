@@ -351,11 +351,37 @@ int refine_policy(int policy, std::initializer_list<Span> reads, Span write) {
     return policy;
 }
 
+namespace {
+// Orders stream `to` after everything queued on `from` so far (both on device `dev`); best effort, nothing blocks on the host.
+void order_stream_after(int dev, hipStream_t from, hipStream_t to) {
+    if (!from || !to || from == to) return;
+    hipEvent_t e = take_event(dev);
+    if (!e) { (void)hipStreamSynchronize(from); return; }
+    if (hipEventRecord(e, from) == hipSuccess) (void)hipStreamWaitEvent(to, e, 0);
+    (void)hipGetLastError();
+    give_event(dev, e);
+}
+}  // namespace
+
+// The sharded entry points run on the per-device LIBRARY streams.  A caller that brought its own stream (smhip_set_stream:
+// torch's current stream, say) has queued the producers of its buffers there, and will queue their consumers there: on
+// the caller's own device the library stream is therefore ordered after the caller's stream on entry and the caller's
+// stream after the library stream on exit (without this the sharded kernels could read a[g] before the
+// caller's kernel had written it).  Buffers on OTHER devices were not produced on this thread's stream; their producers
+// are the caller's to order (smhip_sharded_synchronize, or per-device streams of its own).
 ThreadDeviceScope::ThreadDeviceScope(int device) : prev_device_(tls.device), prev_use_user_(tls.use_user_stream) {
     tls.device = device;
     tls.use_user_stream = false;
+    if (prev_use_user_ && tls.user_stream && device == prev_device_) {
+        hipStream_t lib = nullptr;
+        if (acquire(&lib) == SMHIP_OK) {
+            order_stream_after(device, tls.user_stream, lib);
+            bridged_ = lib;
+        }
+    }
 }
 ThreadDeviceScope::~ThreadDeviceScope() {
+    if (bridged_) order_stream_after(tls.device, static_cast<hipStream_t>(bridged_), tls.user_stream);
     tls.device = prev_device_;
     tls.use_user_stream = prev_use_user_;
     if (prev_device_ >= 0) (void)hipSetDevice(prev_device_);
@@ -558,6 +584,8 @@ int smhip_free(void *dptr) {
     if (b.stream == g_streams[b.device]) tag.lib = true;
     else if (b.stream == cur) tag_stream(tag, b.device, cur);
     else if (b.owner != std::this_thread::get_id()) tag.unknown = true;
+    else if (here != b.device) tag.unknown = true;  // this thread's own stream on ANOTHER device than the one it is on now:
+                                                    // which of its streams that was cannot be said from here
     if (cur && cur != b.stream) tag_stream(tag, b.device, cur);
     std::lock_guard<std::mutex> lock(g_mutex);
     if (b.arena) release(b.arena, b.off, b.cls, std::move(tag));

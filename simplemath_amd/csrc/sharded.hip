@@ -404,6 +404,7 @@ int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, 
     if (!dst || !src) return fail(SMHIP_ERR_INVALID, "copy_peer: null");
     int have = 0;
     smhip_device_count(&have);
+    if (have < 1) return fail(SMHIP_ERR_NO_DEVICE, "copy_peer: no HIP device available; libsmhip has no CPU fallback");
     if (dst_device < 0 || src_device < 0 || dst_device >= have || src_device >= have)
         return fail(SMHIP_ERR_INVALID, "copy_peer: device %d -> %d, %d present", src_device, dst_device, have);
     if (src_device == dst_device) {

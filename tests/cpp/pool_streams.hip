@@ -3,7 +3,9 @@
 //   1. a block used on thread A's own stream, freed and reallocated by thread B on the library stream;
 //   2. one thread switching streams between the last use and the free;
 //   3. a caller-owned stream destroyed before the block it was handed to is freed;
-//   4. two asynchronous reductions queued from one thread on two streams (their partials must not share a buffer).
+//   4. two asynchronous reductions queued from one thread on two streams (their partials must not share a buffer);
+//   5. a sharded entry point (library streams) called by a thread that is on its OWN stream: it must see what that stream
+//      has queued before it and the stream must see its results.
 // The reference has nothing like this (new[]/delete[] per operator, SMArray.h:219,342-346).  Exit code 0 = all held.
 #include <hip/hip_runtime.h>
 #include <smhip.h>
@@ -151,6 +153,28 @@ int main() {
         OK(smhip_free(a));
         OK(smhip_free(b));
         OK(smhip_free(r));
+    }
+    std::printf("case 5\n");
+    {  // 5. producer on the caller's stream -> sharded kernel on the library stream -> consumer on the caller's stream
+        OK(smhip_set_stream(nullptr));
+        OK(smhip_set_devices(1));
+        OK(smhip_set_stream(s1));
+        void *x = nullptr, *y = nullptr;
+        OK(smhip_alloc(&x, N * sizeof(float)));
+        OK(smhip_alloc(&y, N * sizeof(float)));
+        OK(smhip_fill(SMHIP_F32, x, &zero, N));
+        busy(static_cast<float *>(x), 40);  // ~3 ms of x += 1 queued on s1
+        const void *pa[1] = {x};
+        void *po[1] = {y};
+        const size_t pn[1] = {N};
+        const float two = 2.0f;
+        OK(smhip_sharded_array_scalar(SMHIP_OP_MUL, SMHIP_F32, pa, &two, pn, po));  // y = 2 x on the device's library stream
+        busy(static_cast<float *>(y), 1);                                            // y += 1 back on s1
+        CHECK(all_equal(static_cast<float *>(y), 81.0f));                            // (0 + 40) * 2 + 1
+        OK(smhip_free(x));
+        OK(smhip_free(y));
+        OK(smhip_set_stream(nullptr));
+        OK(smhip_set_devices(0));
     }
     OK(smhip_synchronize());
     hipStreamDestroy(s1);

@@ -132,6 +132,28 @@ int main(int argc, char **argv) {
         CHECK(same_bits((sm::Sharded<std::int64_t>::scatter(i) - sm::Sharded<std::int64_t>::scatter(i) * (std::int64_t)3).gather(),
                         i - i * (std::int64_t)3));
     }
+    {  // scatter / replicate / gather move DEVICE-resident arrays device to device (smhip_copy_peer), host-born ones from their mirror
+        auto a = random_array<float>({1031, 517}, -1, 1), b = random_array<float>({1031, 517}, -1, 1);
+        auto dev = a + b;  // born on the device: no host mirror exists
+        CHECK(same_bits(sm::Sharded<float>::scatter(dev).gather(), a + b));
+        auto turned = dev.transpose();  // a strided view of a device array
+        CHECK(same_bits(sm::Sharded<float>::scatter(turned).gather(), turned.contiguous()));
+        auto rep = sm::Sharded<float>::replicate(dev);
+        for (int g = 0; g < n; ++g) {
+            CHECK(rep.part(g).device() == g);
+            CHECK(same_bits(rep.part(g), dev));
+        }
+        CHECK(same_bits(rep.gather(), dev));
+        auto fresh = random_array<float>({64, 33}, -1, 1);  // exists only in host memory, and strided
+        auto hv = fresh.transpose();
+        auto shv = sm::Sharded<float>::scatter(hv);
+        auto fresh2 = random_array<float>({33, 64}, 0, 0);
+        CHECK(same_bits(shv.gather(), hv.contiguous()));
+        // a result gathered on this GPU feeds the next operator at once (the copies ran on this device's stream)
+        auto sum_back = sm::Sharded<float>::scatter(dev).gather() + dev;
+        CHECK(same_bits(sum_back, dev + dev));
+        (void)fresh2;
+    }
     {  // fewer rows than GPUs: trailing GPUs hold empty blocks
         auto a = random_array<double>({1, 77}, -1, 1);
         auto sa = sm::Sharded<double>::scatter(a);

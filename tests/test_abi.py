@@ -87,6 +87,7 @@ def test_no_cpu_fallback(lib):
                  lambda: lib.binary_inline(sma.OP_ADD, host, host),   # operands in HOST memory: still no host arithmetic
                  lambda: lib.set_devices(1),
                  lambda: lib.comm_init_rank(1, 0, bytes(128)),
+                 lambda: lib.copy_peer(16, 0, 32, 0, 16),
                  lambda: lib.synchronize()):
         with pytest.raises(sma.SmhipError) as e:
             call()

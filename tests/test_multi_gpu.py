@@ -145,3 +145,82 @@ def test_sharded_cpp_surface():
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failures" in r.stdout
+
+
+@pytest.mark.gpu
+def test_group_reports_what_rccl_built(group1):
+    """smhip_group_info / smhip_rccl_version: RCCL's own answers (ncclCommCount, ncclCommUserRank, ncclCommCuDevice,
+    ncclGetVersion) -- what bench.py prints as "rccl" so that an N-GPU line shows the collective saw N ranks."""
+    lib = group1
+    assert lib.group_info(0) == (1, 0, 0)
+    assert lib.rccl_version() >= 20000
+    with pytest.raises(sma.SmhipError, match="outside the group"):
+        lib.group_info(1)
+
+
+@pytest.mark.gpu
+def test_failed_group_setup_leaves_nothing_behind(smhip, monkeypatch):
+    """a failing ncclCommInitAll used to leave the per-device slots allocated and no way to free
+    them.  SMHIP_TEST_FAIL_COMM_INIT makes the call fail after the slots exist: they must be back in the pool, no group
+    must exist, and a later smhip_set_devices must work."""
+    lib = smhip
+    lib.set_device(0)
+    lib.synchronize()
+    in_use_before, _ = lib.pool_stats()
+    monkeypatch.setenv("SMHIP_TEST_FAIL_COMM_INIT", "1")
+    with pytest.raises(sma.SmhipError, match="ncclCommInitAll"):
+        lib.set_devices(1)
+    assert lib.get_devices() == 0
+    assert lib.pool_stats()[0] == in_use_before
+    monkeypatch.delenv("SMHIP_TEST_FAIL_COMM_INIT")
+    lib.set_devices(1)
+    try:
+        x = lib.to_device(np.arange(1000, dtype=np.float32))
+        assert lib.sharded_sum(np.float32, [x.ptr], [1000]) == 499500.0
+    finally:
+        lib.set_devices(0)
+    del x
+    assert lib.pool_stats()[0] == in_use_before
+
+
+@pytest.mark.gpu
+def test_partly_issued_collective_dissolves_the_group(smhip, monkeypatch):
+    """A failing ncclAllReduce inside ncclGroupStart/End must not leave other devices' streams with half a collective:
+    the group is closed, its communicators aborted, no group is left; forming a new one works and computes."""
+    lib = smhip
+    lib.set_device(0)
+    lib.set_devices(1)
+    x = lib.to_device(np.arange(1000, dtype=np.float32))
+    monkeypatch.setenv("SMHIP_TEST_FAIL_ALLREDUCE", "0")
+    with pytest.raises(sma.SmhipError, match="the device group was dissolved"):
+        lib.sharded_sum(np.float32, [x.ptr], [1000])
+    assert lib.get_devices() == 0
+    monkeypatch.delenv("SMHIP_TEST_FAIL_ALLREDUCE")
+    with pytest.raises(sma.SmhipError, match="smhip_set_devices"):
+        lib.sharded_sum(np.float32, [x.ptr], [1000])
+    lib.set_devices(1)
+    try:
+        assert lib.sharded_sum(np.float32, [x.ptr], [1000]) == 499500.0
+    finally:
+        lib.set_devices(0)
+
+
+@pytest.mark.gpu
+def test_copy_peer_is_ordered_on_both_sides(smhip):
+    """smhip_copy_peer with source and destination on the one GPU present (the self-peer case): ordered after the kernel
+    that produces the source, before the kernel that consumes the destination, and before the source is overwritten."""
+    lib = smhip
+    lib.set_device(0)
+    n = (1 << 22) + 5
+    a = lib.uniform_f32(n, 21, -1.0, 1.0)
+    src = lib.array_scalar(sma.OP_MUL, a, np.float32(3.0))          # producer, still queued
+    dst = lib.empty((n,), np.float32)
+    lib.copy_peer(dst.ptr, 0, src.ptr, 0, n * 4)
+    lib.array_scalar(sma.OP_MUL, a, np.float32(-1.0), out=src)       # overwrites the source right behind the copy
+    twice = lib.array_scalar(sma.OP_ADD, dst, np.float32(1.0))       # consumer of the destination
+    ha = a.numpy()
+    assert np.array_equal(dst.numpy(), ha * np.float32(3.0))
+    assert np.array_equal(twice.numpy(), ha * np.float32(3.0) + np.float32(1.0))
+    assert np.array_equal(src.numpy(), ha * np.float32(-1.0))
+    with pytest.raises(sma.SmhipError, match="copy_peer"):
+        lib.copy_peer(dst.ptr, 0, src.ptr, 99, 16)

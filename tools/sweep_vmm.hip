@@ -71,6 +71,7 @@ static void slab_free(Slab &s) {
 
 int main(int argc, char **argv) {
     const bool big = argc > 1 && !strcmp(argv[1], "big");
+    const bool pmc = argc > 1 && !strcmp(argv[1], "pmc");  // under rocprofv3 --pmc: exactly 4 launches of add_k per variant, in the order printed
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -107,6 +108,14 @@ int main(int argc, char **argv) {
             init_k<<<4096, 256>>>(a, 2 * n);
             CK(hipDeviceSynchronize());
             const unsigned grid = (unsigned)(n / 4 / 1024);
+            if (pmc) {
+                for (int i = 0; i < 4; ++i) add_k<<<grid, 1024>>>((const f4 *)a, (const f4 *)b, (f4 *)o);
+                CK(hipDeviceSynchronize());
+                printf("2^%d %-30s 4 launches\n", lg, h.name);
+                fflush(stdout);
+                slab_free(s);
+                continue;
+            }
             for (int i = 0; i < 5; ++i) add_k<<<grid, 1024>>>((const f4 *)a, (const f4 *)b, (f4 *)o);
             std::vector<float> ms(5);
             const int reps = lg >= 30 ? 10 : 30;
