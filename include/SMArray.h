@@ -220,7 +220,7 @@ public:
     // destination (`a = a.transpose()`) is made dense first.
     SMArray &operator=(const SMArray &&other) {
         if (_shape != other._shape) throw std::runtime_error("Shape mismatch in assignment");
-        if constexpr (hip::dtype_of<T>::id >= 0) {
+        if (hip::transport_of<T>::id >= 0 && _shape.size() + (hip::transport_of<T>::lanes > 1 ? 1 : 0) <= MAX_NDIM) {
             if (totalSize == 0) return *this;
             hip::DeviceGuard on(common_device(*this, other));
             std::unique_ptr<SMArray> holder;
@@ -231,8 +231,9 @@ public:
             }
             auto sh = hip::to_i64(_shape), ss = hip::to_i64(src->_strides), sd = hip::to_i64(_strides);
             if (sh.empty()) { sh = {1}; ss = {1}; sd = {1}; }  // a 0-d array is one element
+            lane_axis(sh, ss, &sd);
             const T *from = src->device_data();
-            hip::check(smhip_copy_strided(hip::dtype_of<T>::id, from, ss.data(), data.storage()->dev_rw() + data.offset(), sd.data(),
+            hip::check(smhip_copy_strided(hip::transport_of<T>::id, from, ss.data(), data.storage()->dev_rw() + data.offset(), sd.data(),
                                           sh.data(), static_cast<int>(sh.size())));
         } else {
             std::vector<T> tmp(other.totalSize ? other.totalSize : 1);
@@ -277,7 +278,7 @@ public:
     SMArray repeat(int numberOfRepeats) const {
         assert(numberOfRepeats >= 1);
         const std::size_t r = static_cast<std::size_t>(numberOfRepeats);
-        if constexpr (hip::dtype_of<T>::id >= 0) {
+        if constexpr (hip::transport_of<T>::id >= 0) {
             if (!is_dense()) return contiguous().repeat(numberOfRepeats);
             return gather({totalSize, r}, {1, 0}, {totalSize * r});  // a dense array seen as (N, r) with strides (1, 0)
         } else {  // element types without kernels (std::complex): plain host data movement
@@ -300,7 +301,7 @@ public:
         std::size_t inner = 1, outer = 1;
         for (std::size_t i = axis + 1; i < ndim; ++i) inner *= _shape[i];
         for (int i = 0; i < axis; ++i) outer *= _shape[i];
-        if constexpr (hip::dtype_of<T>::id >= 0) {
+        if constexpr (hip::transport_of<T>::id >= 0) {
             if (!is_dense()) return contiguous().repeat(numberOfRepeats, axis);
             // dense: (outer, d, inner) seen as (outer, d, r, inner) with strides (d*inner, inner, 0, 1) -- rank 4 whatever ndim is
             return gather({outer, _shape[axis], r, inner}, {_shape[axis] * inner, inner, 0, 1}, std::move(newShape));
@@ -322,19 +323,20 @@ public:
     // Dot product over all elements (reference SMArray.h:213-215 -> dot_product<T>).
     T operator%(const SMArray &arr) const {
         if (totalSize != arr.totalSize) throw std::runtime_error("dot product: element counts differ");
-        if constexpr (hip::dtype_of<T>::id >= 0) {
+        if constexpr (hip::dot_dtype_of<T>::id >= 0) {  // the four kernel types and the generic template's other integer types
             hip::DeviceGuard on(common_device(*this, arr));
             std::unique_ptr<SMArray> lhs_holder, rhs_holder;
             const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
             return hip::dot_device<T>(pa, pb, totalSize);
         } else if constexpr (std::is_same_v<T, std::complex<double>>) {
-            std::vector<T> fa(totalSize ? totalSize : 1), fb(totalSize ? totalSize : 1);
-            copy_dense_to(fa.data());
-            arr.copy_dense_to(fb.data());
-            return dot_product<T>(fa.data(), fb.data(), totalSize);  // staged: complex arrays have no resident form yet
+            // complex arrays are as resident as any other (16-byte elements in the same Storage): device pointers in, no host staging
+            hip::DeviceGuard on(common_device(*this, arr));
+            std::unique_ptr<SMArray> lhs_holder, rhs_holder;
+            const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
+            return hip::dot_device_c64(pa, pb, totalSize);
         } else {
-            static_assert(dependent_false<T>::value, "operator%: this element type has no gfx950 dot-product kernel (float, double, "
-                                                     "signed 32/64-bit integers and std::complex<double> do)");
+            static_assert(dependent_false<T>::value, "operator%: this element type has no gfx950 dot-product kernel (float, double, every "
+                                                     "8- to 64-bit integer type and std::complex<double> do)");
         }
     }
 
@@ -499,7 +501,7 @@ public:
     }
     // Dense copy of a (possibly strided) array, made on the device.
     SMArray contiguous() const {
-        if constexpr (hip::dtype_of<T>::id >= 0) {
+        if (hip::transport_of<T>::id >= 0 && _shape.size() + (hip::transport_of<T>::lanes > 1 ? 1 : 0) <= MAX_NDIM) {
             return gather(_shape, _strides, std::vector<std::size_t>(_shape));
         } else {
             T *out = new T[totalSize ? totalSize : 1];
@@ -570,12 +572,28 @@ private:
                    std::vector<std::size_t> &&outShape) const {
         hip::DeviceGuard on(device());
         SMArray out = device_empty(std::move(outShape));
-        const auto sh = hip::to_i64(vshape), st = hip::to_i64(vstrides);
+        auto sh = hip::to_i64(vshape), st = hip::to_i64(vstrides);
+        lane_axis(sh, st, nullptr);
         const std::vector<std::int64_t> zeros(sh.size(), 0);
         const T *src = device_data();
-        hip::check(smhip_elementwise(SMHIP_OP_LEFT, hip::dtype_of<T>::id, src, st.data(), src, zeros.data(), sh.data(),
+        hip::check(smhip_elementwise(SMHIP_OP_LEFT, hip::transport_of<T>::id, src, st.data(), src, zeros.data(), sh.data(),
                                      static_cast<int>(sh.size()), out.device_data_mut()));
         return out;
+    }
+
+    // An element type that moves as `lanes` elements of a kernel type (std::complex: {re, im}) gets an innermost axis of
+    // extent `lanes`, stride 1, and its element strides counted in lanes (math/ops.h: transport_of).
+    static void lane_axis(std::vector<std::int64_t> &shape, std::vector<std::int64_t> &strides, std::vector<std::int64_t> *strides2) {
+        constexpr int lanes = hip::transport_of<T>::lanes;
+        if constexpr (lanes > 1) {
+            for (auto &x : strides) x *= lanes;
+            if (strides2) for (auto &x : *strides2) x *= lanes;
+            shape.push_back(lanes);
+            strides.push_back(1);
+            if (strides2) strides2->push_back(1);
+        } else {
+            (void)shape; (void)strides; (void)strides2;
+        }
     }
 
     // Bytes from this array's first element to the end of its storage when the elements exist ONLY in host memory and

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <cstdlib>
 #include <stdexcept>
@@ -64,6 +65,33 @@ template <typename T> struct dtype_of {
                               : (std::is_integral_v<T> && std::is_signed_v<T> && sizeof(T) == 8) ? static_cast<int>(SMHIP_I64)
                                                                                                  : -1;
 };
+
+// Element types SMArray<T>::operator% has a kernel for: the four above plus the other integer types the reference's GENERIC
+// dot_product<T> (product.h:8-20) serves -- 8- / 16-bit and unsigned 32- / 64-bit integers (bool excepted: its `sum += a * b`
+// is a logical OR, not arithmetic).
+template <typename T> struct dot_dtype_of {
+    static constexpr int id = dtype_of<T>::id >= 0 ? dtype_of<T>::id
+                              : (!std::is_integral_v<T> || std::is_same_v<T, bool>) ? -1
+                              : sizeof(T) == 1 ? static_cast<int>(std::is_signed_v<T> ? SMHIP_I8 : SMHIP_U8)
+                              : sizeof(T) == 2 ? static_cast<int>(std::is_signed_v<T> ? SMHIP_I16 : SMHIP_U16)
+                              : sizeof(T) == 4 ? static_cast<int>(SMHIP_U32)
+                              : sizeof(T) == 8 ? static_cast<int>(SMHIP_U64)
+                                               : -1;
+};
+
+// How an element type MOVES on the device -- dense copies of views, repeat(), assignment into views: no arithmetic --
+// as `lanes` consecutive elements of a type the copy kernels know: the kernel types as themselves, unsigned 32- / 64-bit
+// integers as their signed twins, std::complex<float | double> as pairs of floats / doubles (an extra innermost axis of
+// extent 2).  id < 0: the type has no device copy kernels (8- and 16-bit integers: their views are gathered on the host).
+template <typename T> struct transport_of {
+    static constexpr int id = dtype_of<T>::id >= 0 ? dtype_of<T>::id
+                              : (std::is_integral_v<T> && !std::is_same_v<T, bool> && sizeof(T) == 4) ? static_cast<int>(SMHIP_I32)
+                              : (std::is_integral_v<T> && sizeof(T) == 8) ? static_cast<int>(SMHIP_I64)
+                                                                          : -1;
+    static constexpr int lanes = 1;
+};
+template <> struct transport_of<std::complex<double>> { static constexpr int id = SMHIP_F64, lanes = 2; };
+template <> struct transport_of<std::complex<float>> { static constexpr int id = SMHIP_F32, lanes = 2; };
 
 // Op -> device functor.  `available` says whether the Op can run on the GPU, `id()` names the
 // functor: a constant for the five built-ins (AOT kernels in libsmhip), a registered id for a user

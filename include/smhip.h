@@ -69,7 +69,11 @@ int smhip_register_op(const char *hip_expression, int *op_id);
 /* Element types: the SimdTraits<T> specialisations (helpers.h:23-119) plus
  * int64 (declared TODO at helpers.h:122-127). */
 typedef enum smhip_dtype {
-    SMHIP_F32 = 0, SMHIP_F64 = 1, SMHIP_I32 = 2, SMHIP_I64 = 3
+    SMHIP_F32 = 0, SMHIP_F64 = 1, SMHIP_I32 = 2, SMHIP_I64 = 3,
+    /* Accepted by smhip_dot / smhip_dot_async ONLY: the other integer element types the reference's generic
+     * dot_product<T> (product.h:8-20) is instantiated with through SMArray<T>::operator% (SMArray.h:22-27 admits any
+     * arithmetic T).  They have no elementwise kernels -- the reference cannot compile those either (no SimdTraits). */
+    SMHIP_I8 = 4, SMHIP_U8 = 5, SMHIP_I16 = 6, SMHIP_U16 = 7, SMHIP_U32 = 8, SMHIP_U64 = 9
 } smhip_dtype;
 
 /* ------------------------------------------------------------- context */
@@ -159,7 +163,9 @@ int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out,
 int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host, size_t n, void *out);
 /* dot_product<T> (product.h:8-224 via SMArray.h:213-215): one T to *out_host.
  * f32/f64 accumulate in fp64 (the reference's f32 lane accumulators saturate,
- * SURVEY section 0); i32/i64 wrap exactly like the reference. Synchronous. */
+ * SURVEY section 0); integer types -- i32/i64 and SMHIP_I8 ... SMHIP_U64, the generic
+ * template's `T sum; sum += a[i] * b[i]` -- wrap exactly like the reference (the sum of
+ * products modulo 2^(8 sizeof T)). Synchronous. */
 int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host);
 /* dot_product<std::complex<double>> (product.h:168-224): a, b hold n {re, im} pairs of doubles (16-byte
  * aligned); writes {re, im} of sum a[i]*b[i] (unconjugated, as the reference's scalar tail computes

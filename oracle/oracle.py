@@ -23,6 +23,9 @@ OPS = {"add": ADD, "sub": SUB, "mul": MUL, "div": DIV, "pow": POW}
 F32, F64, I32, I64 = range(4)
 DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
           np.dtype(np.int32): I32, np.dtype(np.int64): I64}
+# the generic dot_product<T>'s extra integer element types (smhip.h: SMHIP_I8 ... SMHIP_U64)
+INT_KINDS = {np.dtype(np.int8): 4, np.dtype(np.uint8): 5, np.dtype(np.int16): 6, np.dtype(np.uint16): 7,
+             np.dtype(np.uint32): 8, np.dtype(np.uint64): 9}
 MAX_NDIM = 6
 
 _szp = C.POINTER(C.c_size_t)
@@ -149,6 +152,27 @@ class Oracle(_Lib):
     def powi32(self, base, exponent):
         return int(self.lib.smo_powi32(int(base), int(exponent)))
 
+    def dot_c64(self, a, b, avx_body=False):
+        """dot_product<std::complex<double>> restated: the definition (every element through the scalar statement), or as
+        shipped (avx_body: the AVX body's doubled sums first).  a, b: complex128 arrays."""
+        a, b = np.ascontiguousarray(a, dtype=np.complex128), np.ascontiguousarray(b, dtype=np.complex128)
+        out = np.zeros(2, dtype=np.float64)
+        self.lib.smo_dot_c64.restype = C.c_int
+        rc = self.lib.smo_dot_c64(_ptr(a), _ptr(b), C.c_size_t(a.size), _ptr(out), C.c_int(1 if avx_body else 0))
+        if rc:
+            raise ValueError(f"smo_dot_c64 rc={rc}")
+        return complex(out[0], out[1])
+
+    def dot_int(self, a, b):
+        """The generic dot_product<T> for int8/uint8/int16/uint16/uint32/uint64 arrays."""
+        kind = INT_KINDS[a.dtype]
+        out = np.zeros(1, dtype=a.dtype)
+        self.lib.smo_dot_int.restype = C.c_int
+        rc = self.lib.smo_dot_int(C.c_int(kind), _ptr(a), _ptr(b), C.c_size_t(a.size), _ptr(out))
+        if rc:
+            raise ValueError(f"smo_dot_int rc={rc}")
+        return out[0]
+
     def dot(self, a, b, lane_order=False):
         dt = DTYPES[a.dtype]
         out = np.zeros(1, dtype=a.dtype)
@@ -252,6 +276,23 @@ class Reference(_Lib):
         if rc:
             raise ValueError(f"ref_pow_apply rc={rc}")
         return out
+
+    def dot_c64(self, a, b):
+        a, b = np.ascontiguousarray(a, dtype=np.complex128), np.ascontiguousarray(b, dtype=np.complex128)
+        out = np.zeros(2, dtype=np.float64)
+        self.lib.ref_dot_c64.restype = C.c_int
+        rc = self.lib.ref_dot_c64(_ptr(a), _ptr(b), C.c_size_t(a.size), _ptr(out))
+        if rc:
+            raise ValueError(f"ref_dot_c64 rc={rc}")
+        return complex(out[0], out[1])
+
+    def dot_int(self, a, b):
+        out = np.zeros(1, dtype=a.dtype)
+        self.lib.ref_dot_int.restype = C.c_int
+        rc = self.lib.ref_dot_int(C.c_int(INT_KINDS[a.dtype]), _ptr(a), _ptr(b), C.c_size_t(a.size), _ptr(out))
+        if rc:
+            raise ValueError(f"ref_dot_int rc={rc}")
+        return out[0]
 
     def dot(self, a, b):
         out = np.zeros(1, dtype=a.dtype)

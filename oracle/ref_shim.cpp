@@ -167,6 +167,29 @@ int ref_dot(int dtype, const void *a, const void *b, size_t n, void *out) {
     return -1;
 }
 
+// dot_product<std::complex<double>> (product.h:168-224): n {re, im} pairs
+int ref_dot_c64(const double *a, const double *b, size_t n, double *out2) {
+    const std::complex<double> r = dot_product<std::complex<double>>(reinterpret_cast<const std::complex<double> *>(a),
+                                                                     reinterpret_cast<const std::complex<double> *>(b), n);
+    out2[0] = r.real();
+    out2[1] = r.imag();
+    return 0;
+}
+
+// the generic dot_product<T> (product.h:8-20); kind as libsmhip's extended element types: 4 int8, 5 uint8, 6 int16,
+// 7 uint16, 8 uint32, 9 uint64
+int ref_dot_int(int kind, const void *a, const void *b, size_t n, void *out) {
+    switch (kind) {
+        case 4: *(signed char *)out = dot_product<signed char>((const signed char *)a, (const signed char *)b, n); return 0;
+        case 5: *(unsigned char *)out = dot_product<unsigned char>((const unsigned char *)a, (const unsigned char *)b, n); return 0;
+        case 6: *(short *)out = dot_product<short>((const short *)a, (const short *)b, n); return 0;
+        case 7: *(unsigned short *)out = dot_product<unsigned short>((const unsigned short *)a, (const unsigned short *)b, n); return 0;
+        case 8: *(unsigned int *)out = dot_product<unsigned int>((const unsigned int *)a, (const unsigned int *)b, n); return 0;
+        case 9: *(unsigned long long *)out = dot_product<unsigned long long>((const unsigned long long *)a, (const unsigned long long *)b, n); return 0;
+    }
+    return -1;
+}
+
 // SMArray<T>::operator+,-,*,/ on dense owning arrays, each optionally viewed
 // through transpose() (include/SMArray.h:121-136, 217-305).  Returns -1 if
 // broadcast threw.

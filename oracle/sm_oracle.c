@@ -386,6 +386,74 @@ int smo_dot(int dtype, const void *a, const void *b, size_t n, void *out, int la
     return -1;
 }
 
+/* dot_product<std::complex<double>>, include/math/product.h:168-224.  a, b: n {re, im} pairs.
+ *   avx_body == 0: the DEFINITION -- the scalar statement `result += a[i] * b[i]` (:221-222) for every i.  With the only
+ *     flags the reference compiles under (g++ -O3 -mavx2 -mfma) GCC expands the complex product inline and
+ *     contracts it: re = fma(ar, br, -(ai * bi)), im = fma(ar, bi, ai * br) (checked bit for bit against the compiled
+ *     reference at n = 1, tests/test_oracle.py::test_golden_dot_extra); the sums are plain additions.
+ *   avx_body != 0: the function as shipped -- for i + 1 < n the AVX body (:175-199) handles two elements per iteration:
+ *     _mm256_permute_pd(va, 0x0) / (va, 0xF) DUPLICATE the real / imaginary part into both slots of each 128-bit lane, so
+ *     all four lanes of `real` / `imag` carry products and rbuf[0] + rbuf[1] + rbuf[2] + rbuf[3] counts every product
+ *     TWICE; then the scalar tail.  Kept as data:
+ *     it is what the reference returns, and it is not what a dot product is. */
+int smo_dot_c64(const double *a, const double *b, size_t n, double *out2, int avx_body) {
+    double re = 0.0, im = 0.0;
+    size_t i = 0;
+    if (avx_body) {
+        double vr[4] = {0, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
+        for (; i + 1 < n; i += 2) {
+            for (int l = 0; l < 4; ++l) {
+                const size_t e = i + (size_t)(l >> 1);  /* lanes 0,1: element i; lanes 2,3: element i + 1 */
+                const double ar = a[2 * e], ai = a[2 * e + 1], br = b[2 * e], bi = b[2 * e + 1];
+                /* GCC's _mm256_mul_pd / _mm256_sub_pd are plain vector operators, so -mfma contracts them: here it rounds
+                 * the a_r products first and fuses the a_i ones (vmulpd, vmulpd, vfnmadd231pd, vfmadd132pd in the compiled
+                 * reference) -- the scalar tail below came out the other way round */
+                vr[l] += fma(-ai, bi, ar * br);
+                vi[l] += fma(ai, br, ar * bi);
+            }
+        }
+        re = ((vr[0] + vr[1]) + vr[2]) + vr[3];
+        im = ((vi[0] + vi[1]) + vi[2]) + vi[3];
+    }
+    for (; i < n; ++i) {
+        const double ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+        re += fma(ar, br, -(ai * bi));
+        im += fma(ar, bi, ai * br);
+    }
+    out2[0] = re;
+    out2[1] = im;
+    return 0;
+}
+
+/* The generic dot_product<T> (product.h:8-20) for the integer types the specialisations do not cover: `T sum = 0; sum +=
+ * a[i] * b[i]` -- the product is formed in the promoted type and the sum is cut back to T every step, i.e. the exact sum
+ * of products modulo 2^(8 sizeof T) (unsigned int is routed to the int32 kernel, :10-15: the same value).
+ * kind: 4 = int8, 5 = uint8, 6 = int16, 7 = uint16, 8 = uint32, 9 = uint64 (smhip.h's SMHIP_I8 ... SMHIP_U64); `out`
+ * receives one T. */
+int smo_dot_int(int kind, const void *a, const void *b, size_t n, void *out) {
+    uint64_t s = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t x, y;
+        switch (kind) {
+            case 4: x = (uint64_t)(int64_t)((const int8_t *)a)[i]; y = (uint64_t)(int64_t)((const int8_t *)b)[i]; break;
+            case 5: x = ((const uint8_t *)a)[i]; y = ((const uint8_t *)b)[i]; break;
+            case 6: x = (uint64_t)(int64_t)((const int16_t *)a)[i]; y = (uint64_t)(int64_t)((const int16_t *)b)[i]; break;
+            case 7: x = ((const uint16_t *)a)[i]; y = ((const uint16_t *)b)[i]; break;
+            case 8: x = ((const uint32_t *)a)[i]; y = ((const uint32_t *)b)[i]; break;
+            case 9: x = ((const uint64_t *)a)[i]; y = ((const uint64_t *)b)[i]; break;
+            default: return -1;
+        }
+        s += x * y;
+    }
+    switch (kind) {
+        case 4: case 5: *(uint8_t *)out = (uint8_t)s; break;
+        case 6: case 7: *(uint16_t *)out = (uint16_t)s; break;
+        case 8: *(uint32_t *)out = (uint32_t)s; break;
+        default: *(uint64_t *)out = s; break;
+    }
+    return 0;
+}
+
 double smo_sum_f64acc(int dtype, const void *a, size_t n) {
     ksum_t k = {0, 0};
     switch (dtype) {

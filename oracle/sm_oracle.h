@@ -82,6 +82,14 @@ int32_t smo_powi32(int32_t base, int32_t exponent);
 int smo_dot(int dtype, const void *a, const void *b, size_t n, void *out,
             int lane_order);
 
+/* dot_product<std::complex<double>> (product.h:168-224): n {re, im} pairs each; {re, im} to out2.  avx_body == 0: the
+ * scalar statement `result += a[i] * b[i]` for every element (the definition); != 0: as shipped, AVX body first (its
+ * permutes count every product twice), scalar tail after. */
+int smo_dot_c64(const double *a, const double *b, size_t n, double *out2, int avx_body);
+/* The generic dot_product<T> (product.h:8-20) for int8/uint8/int16/uint16/uint32/uint64 (kind 4..9): the sum of products
+ * modulo 2^(8 sizeof T); one T to `out`. */
+int smo_dot_int(int kind, const void *a, const void *b, size_t n, void *out);
+
 /* Whole-array sum in fp64 (Neumaier-compensated).  No reference counterpart
  * (SURVEY 8c "Oracle for global sum"). */
 double smo_sum_f64acc(int dtype, const void *a, size_t n);

@@ -23,6 +23,10 @@ OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_POW, OP_LEFT = range(6)
 OPS = {"add": OP_ADD, "sub": OP_SUB, "mul": OP_MUL, "div": OP_DIV, "pow": OP_POW, "left": OP_LEFT}
 F32, F64, I32, I64 = range(4)
 DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int32): I32, np.dtype(np.int64): I64}
+# smhip_dot also takes the generic dot_product<T>'s other integer element types (smhip.h: SMHIP_I8 ... SMHIP_U64)
+I8, U8, I16, U16, U32, U64 = range(4, 10)
+DOT_DTYPES = {**DTYPES, np.dtype(np.int8): I8, np.dtype(np.uint8): U8, np.dtype(np.int16): I16, np.dtype(np.uint16): U16,
+              np.dtype(np.uint32): U32, np.dtype(np.uint64): U64}
 MAX_NDIM = 6
 
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_BROADCAST = -1, -2, -3, -4, -5
@@ -326,7 +330,7 @@ class Smhip:
 
     def dot(self, a: DeviceArray, b: DeviceArray):
         out = np.zeros(1, dtype=a.dtype)
-        self._ck(self.c.smhip_dot(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),
+        self._ck(self.c.smhip_dot(C.c_int(DOT_DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_size_t(a.size),
                                   out.ctypes.data_as(C.c_void_p)))
         return out[0]
 

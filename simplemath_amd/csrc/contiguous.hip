@@ -276,6 +276,26 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
     return SMHIP_OK;
 }
 
+// Very large arrays go out as several launches.  The f32 add holds 81-82 % of HBM peak up to N = 2^28 and sagged to 78 % at
+// 2^30 / 77 % at 2^31 as ONE launch.  Round 2 blamed address translation (UTCL1 misses per 2 MiB page); round 3 disproved it:
+// memory mapped through hipMemCreate / hipMemMap shows 24 x the UTCL1 misses and a UTCL2 that is busy 55 % of the kernel
+// instead of 2 % -- and runs 2 % FASTER (tools/sweep_vmm.hip, tools/pmc_vmm.sh -> profiles/r03_pmc_vmm.txt); the distance
+// between the three streams does nothing either (tools/sweep_distance.hip).  What matters is the launch's LENGTH: the same
+// 12 GiB, same placement, as four launches of 2^28 run at 79.9 %, as sixteen of 2^26 at 80.7 % (one launch: 78.0 %).  A
+// launch's workgroups are dealt to the eight XCDs in order and each XCD works through its share at its own pace; over
+// hundreds of thousands of workgroups their fronts drift apart and the DRAM pages they share stop being open for each
+// other; a kernel boundary lines them up again.  So: pieces of 2^24 vectors (256 MiB per operand) once an operand
+// exceeds 1 GiB.  SMHIP_PIECE_LOG2VEC=<k> moves the piece size (0: never split).
+inline size_t piece_vectors() {
+    static const size_t v = [] {
+        const char *e = getenv("SMHIP_PIECE_LOG2VEC");
+        const int k = e ? atoi(e) : 24;
+        return k <= 0 ? (size_t)0 : (size_t)1 << (k < 16 ? 16 : k);
+    }();
+    return v;
+}
+constexpr size_t kSplitAboveVectors = (size_t)1 << 26;  // 1 GiB per operand
+
 inline int grid_for(size_t threads, int block, unsigned *grid) {
     const size_t g = (threads + block - 1) / block;
     if (g > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch (%zu workgroups)", g);
@@ -295,6 +315,17 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     if constexpr (IsHeavy<Op>::value) {
         if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
+    } else if (n_vec > kSplitAboveVectors && piece_vectors()) {
+        const int pol = stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)});  // above the cache: nt both ways
+        const size_t piece = piece_vectors();
+        for (size_t v0 = 0; v0 < n_vec || (v0 == n_vec && tail); v0 += piece) {
+            const bool last = v0 + piece >= n_vec;
+            const size_t nv = last ? n_vec - v0 : piece;
+            if (int rc = grid_for(nv + (last && tail ? 1 : 0), kBlockBig, &grid)) return rc;
+            hipLaunchKernelGGL((contiguous_vec_kernel<T, Op, kBlockBig, false>), dim3(grid), dim3(kBlockBig), 0, s, pa + v0 * W, pb + v0 * W, po + v0 * W, nv,
+                               last ? tail : 0, pol & ~kStoreKeep);
+            if (last) break;
+        }
     } else if (n_vec >= kBigThreshold) {
         if (int rc = grid_for(threads, kBlockBig, &grid)) return rc;
         const int pol = stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)});
@@ -354,8 +385,22 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
     } else {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
+        const int pol = stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)});
+        if (n_vec > kSplitAboveVectors && piece_vectors()) {  // very large: several launches (see piece_vectors)
+            const size_t piece = piece_vectors();
+            for (size_t v0 = 0;; v0 += piece) {
+                const bool last = v0 + piece >= n_vec;
+                const size_t nv = last ? n_vec - v0 : piece;
+                if (int rc = grid_for(nv + (last && tail ? 1 : 0), kBlockSmall, &grid)) return rc;
+                hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa + v0 * W, value, po + v0 * W, nv,
+                                   last ? tail : 0, pol);
+                if (last) break;
+            }
+            SMHIP_LAUNCH_CHECK("array_scalar");
+            return SMHIP_OK;
+        }
         if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
+        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, pol);
     }
     SMHIP_LAUNCH_CHECK("array_scalar");
     return SMHIP_OK;

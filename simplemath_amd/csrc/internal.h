@@ -98,8 +98,16 @@ int stream_policy(std::initializer_list<Span> reads, Span write);
 // run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
 int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
 
-inline size_t dtype_size(int dtype) { return (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 8 : 4; }
+inline size_t dtype_size(int dtype) {
+    switch (dtype) {
+        case SMHIP_F64: case SMHIP_I64: case SMHIP_U64: return 8;
+        case SMHIP_I8: case SMHIP_U8: return 1;
+        case SMHIP_I16: case SMHIP_U16: return 2;
+        default: return 4;
+    }
+}
 inline bool valid_dtype(int dtype) { return dtype >= SMHIP_F32 && dtype <= SMHIP_I64; }
+inline bool valid_dot_dtype(int dtype) { return dtype >= SMHIP_F32 && dtype <= SMHIP_U64; }  // + the generic dot's integer types
 inline bool valid_op(int op) { return op >= SMHIP_OP_ADD && op <= SMHIP_OP_LEFT; }
 
 // Kernel launchers (one translation unit each).

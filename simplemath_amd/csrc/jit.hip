@@ -178,6 +178,14 @@ extern "C" __global__ __launch_bounds__(BLOCK) void smhip_user_expr(Operands in,
 // accumulator per workgroup -- fp64 for float types, wrapping 64-bit for integer types, like the built-in reductions.
 typedef ACC A;
 __device__ __forceinline__ A smhip_widen(T x) { return WIDEN; }
+// lane exchange by DPP moves, as reduce.hip's wave_reduce (the wave's total ends up in lane 63; __shfl_down would be a
+// ds_bpermute round trip per 32-bit half and stage)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ A smhip_dpp(A v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(A, ((unsigned long long)hi << 32) | lo);
+}
 extern "C" __global__ __launch_bounds__(BLOCK) void smhip_user_expr_sum(Operands in, Scalars sc, T* __restrict__ out, int store,
                                                                        unsigned long long n_vec, unsigned long long n,
                                                                        A* __restrict__ partials, int pol) {
@@ -212,10 +220,14 @@ extern "C" __global__ __launch_bounds__(BLOCK) void smhip_user_expr_sum(Operands
             acc += smhip_widen(r);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    acc += smhip_dpp<0x111, 0xf>(acc);  // row_shr:1, 2, 4, 8, then row_bcast:15 and :31
+    acc += smhip_dpp<0x112, 0xf>(acc);
+    acc += smhip_dpp<0x114, 0xf>(acc);
+    acc += smhip_dpp<0x118, 0xf>(acc);
+    acc += smhip_dpp<0x142, 0xa>(acc);
+    acc += smhip_dpp<0x143, 0xc>(acc);
     __shared__ A lds[BLOCK / 64];
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 63) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         A total = lds[0];

@@ -40,12 +40,21 @@ template <typename T> struct VecTraits;
         static constexpr int width = N;                                       \
         static __device__ __forceinline__ full_t join(half_full_t lo, half_full_t hi) { return __builtin_shufflevector(lo, hi, SMHIP_JOIN_##N); } \
     };
+#define SMHIP_JOIN_16 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+#define SMHIP_JOIN_8 0, 1, 2, 3, 4, 5, 6, 7
 #define SMHIP_JOIN_4 0, 1, 2, 3
 #define SMHIP_JOIN_2 0, 1
 SMHIP_VEC(float, 4)
 SMHIP_VEC(int32_t, 4)
 SMHIP_VEC(double, 2)
 SMHIP_VEC(int64_t, 2)
+// the generic dot_product<T>'s other integer element types (reduce.hip): 16 bytes per lane all the same
+SMHIP_VEC(int8_t, 16)
+SMHIP_VEC(uint8_t, 16)
+SMHIP_VEC(int16_t, 8)
+SMHIP_VEC(uint16_t, 8)
+SMHIP_VEC(uint32_t, 4)
+SMHIP_VEC(uint64_t, 2)
 #undef SMHIP_VEC
 
 // Streaming accesses carry the `nt` (non-temporal) policy: every byte of the

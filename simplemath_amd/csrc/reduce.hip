@@ -45,48 +45,71 @@ constexpr int kBlock = 256;  // also for the fused op+sum, although it is a 2R+1
 constexpr int kSumVectors = SMHIP_SUM_VECTORS, kDotVectors = SMHIP_DOT_VECTORS;
 constexpr int vec_per_thread(int mode) { return mode == 0 /* kSum */ ? kSumVectors : mode == 1 /* kDot */ ? kDotVectors : SMHIP_FUSED_VECTORS; }
 
-template <typename T> struct AccOf { typedef double type; };
-template <> struct AccOf<int32_t> { typedef uint64_t type; };
-template <> struct AccOf<int64_t> { typedef uint64_t type; };
+template <typename T, bool INTEGER = std::is_integral<T>::value> struct AccOf { typedef double type; };
+template <typename T> struct AccOf<T, true> { typedef uint64_t type; };  // wrapping: exact modulo 2^64, hence modulo 2^(8 sizeof T)
 
-template <typename A> __device__ __forceinline__ A wave_reduce(A v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+// Wave total through DPP moves (v_mov_b32 row_shr / row_bcast: VALU-speed lane exchange inside the SIMD) instead of
+// __shfl_down, which the compiler lowers to ds_bpermute_b32 -- an LDS-crossbar round trip per 32-bit half and stage, with a
+// full lgkmcnt wait behind each: 6 stages x 2 halves for the wave, and round 2 ran the same 6 stages AGAIN in wave 0 to add
+// four numbers.  Every wave of the fused op+sum kernel carried ~1000 cycles of that behind its last store, holding its slot
+// (the kernel ran 2 % behind the plain add: 496-498 us against 486 on one box, tools/sweep_fused2.hip).
+// The scan: row_shr 1, 2, 4, 8 leave each row of 16 lanes' running sum in its lane 15; row_bcast:15 adds it to the next
+// row (rows 1 and 3), row_bcast:31 adds lane 31 to rows 2 and 3: lane 63 holds the wave's total.  Lanes without a source
+// receive `old` = 0, the sum's identity.  The order of the additions is fixed, so the bits are the same on every run
+// (they differ from round 2's tree order in the last place, as any reassociation does).
+constexpr int kWaveTotalLane = 63;
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int off) {
-    const uint32_t lo = __shfl_down((uint32_t)v, off, 64), hi = __shfl_down((uint32_t)(v >> 32), off, 64);
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint64_t dpp_move(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
 }
-template <> __device__ __forceinline__ uint64_t wave_reduce<uint64_t>(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += shfl_down_u64(v, off);
+// the wave's total, valid in lane kWaveTotalLane
+template <typename A> __device__ __forceinline__ A wave_reduce(A v) {
+    v += dpp_move<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_move<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_move<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_move<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_move<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
-// Workgroup total in thread 0.
+// Workgroup total in thread 0: the waves' totals meet in LDS and thread 0 adds them in wave order.
 template <typename A, int BLOCK> __device__ __forceinline__ A block_reduce(A v) {
     __shared__ A lds[BLOCK / 64];
     v = wave_reduce(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) lds[wave] = v;
+    if (lane == kWaveTotalLane) lds[wave] = v;
     __syncthreads();
-    if (wave == 0) {
-        v = lane < BLOCK / 64 ? lds[lane] : A(0);
-        v = wave_reduce(v);
+    if (threadIdx.x == 0) {
+        v = lds[0];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) v += lds[w];
     }
     return v;
 }
 
-template <typename T, typename A> __device__ __forceinline__ A widen(T x) { return (A)x; }
-template <> __device__ __forceinline__ uint64_t widen<int32_t, uint64_t>(int32_t x) { return (uint64_t)(int64_t)x; }
-template <> __device__ __forceinline__ uint64_t widen<int64_t, uint64_t>(int64_t x) { return (uint64_t)x; }
+template <typename T, typename A> __device__ __forceinline__ A widen(T x) {
+    if constexpr (std::is_integral<T>::value && std::is_signed<T>::value) return (A)(int64_t)x;  // sign-extended
+    else return (A)x;
+}
 
 // acc += x*y.  f32: the product of two 24-bit significands is exact in fp64, so the
 // whole dot is an fp64 fma chain (the reference's -mfma build fuses too, but into f32
 // lanes).  f64: fused, one rounding per term.  i32/i64: product wraps in T like
 // _mm256_mullo_epi32, then accumulates mod 2^64.
-template <typename T, typename A> __device__ __forceinline__ void add_prod(A &acc, T x, T y) { acc += widen<T, A>(MultiplyOp<T>::apply(x, y)); }
+// The generic dot_product<T> (product.h:8-20: `T sum = 0; sum += a[i] * b[i]`) for 8- / 16-bit and unsigned types: the product
+// is formed in the promoted type and the sum cut back to T every step -- the exact sum of products modulo 2^(8 sizeof T).
+// Here: widened operands, 64-bit wrapping product and sum, cut to T once at the end (the same residue).
+template <typename T, typename A> __device__ __forceinline__ void add_prod(A &acc, T x, T y) {
+    if constexpr (std::is_same<T, int32_t>::value || std::is_same<T, int64_t>::value) acc += widen<T, A>(MultiplyOp<T>::apply(x, y));
+    else acc += widen<T, A>(x) * widen<T, A>(y);
+}
 template <> __device__ __forceinline__ void add_prod<float, double>(double &acc, float x, float y) { acc = __builtin_fma((double)x, (double)y, acc); }
 template <> __device__ __forceinline__ void add_prod<double, double>(double &acc, double x, double y) { acc = __builtin_fma(x, y, acc); }
 
@@ -177,20 +200,14 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
     A acc = A(0);
     if ((size_t)blockIdx.x * kTile + kTile <= n_vec) {
         V va[kVecPerThread], vb[kVecPerThread];
-        if (nt & kLoadNt) {  // ONE branch around the tile's loads (ops.hip.h: a branch per load parks a full wait at every join)
+        // a branch per load, as round 2 had it: grouped under one branch this kernel measured 2 us SLOWER (497.5-498.5 against
+        // 495.6-496.5 us, tools/sweep_fused2.hip -> profiles/r03_sweep_fused2.txt) -- the opposite of the strided-row kernel's
+        // experience (ops.hip.h); what this kernel waits for is its one pair of loads either way
 #pragma unroll
-            for (int u = 0; u < kVecPerThread; ++u) {
-                va[u] = load_stream_as(T, av + tile0 + (size_t)u * kBlock, true);
-                if constexpr (MODE != kSum) vb[u] = load_stream_as(T, bv + tile0 + (size_t)u * kBlock, true);
-                else vb[u] = va[u];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < kVecPerThread; ++u) {
-                va[u] = load_stream_as(T, av + tile0 + (size_t)u * kBlock, false);
-                if constexpr (MODE != kSum) vb[u] = load_stream_as(T, bv + tile0 + (size_t)u * kBlock, false);
-                else vb[u] = va[u];
-            }
+        for (int u = 0; u < kVecPerThread; ++u) {
+            va[u] = load_stream_if(T, av + tile0 + (size_t)u * kBlock, nt);
+            if constexpr (MODE != kSum) vb[u] = load_stream_if(T, bv + tile0 + (size_t)u * kBlock, nt);
+            else vb[u] = va[u];
         }
 #pragma unroll
         for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, KEEP, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock);
@@ -255,9 +272,13 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     if (threadIdx.x == 0) {
         __hip_atomic_store(&fin.level2[blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ACQUIRE on the ticket: the last arriver's reads of level2[] below may not be hoisted above it or served
-        // from a stale line -- an invalidate behind the atomic, not the L2 write-back a release would cost
-        last = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        // The ticket stays RELAXED.  ADVICE r02 asked for an agent-scope ACQUIRE here; measured, its invalidate costs every
+        // reduction 1.2 us (504.6 -> 505.8 us per fused add+sum step, tools/sweep_fused2.hip), 17 % of this kernel.  What the
+        // acquire would guarantee is already enforced by construction: the level2[] reads below are agent-scope atomic loads
+        // (performed past the per-XCD caches, never served from a stale line), they sit behind the workgroup barrier that
+        // publishes `last` -- no compiler moves a load across s_barrier, and `last` itself is the RETURNED value of this
+        // atomic, so the barrier is not reached before the ticket has been answered by the memory side.
+        last = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last) return;
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
     re = wave_reduce(re);
     im = wave_reduce(im);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { lds[0][wave] = re; lds[1][wave] = im; }
+    if (lane == kWaveTotalLane) { lds[0][wave] = re; lds[1][wave] = im; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double r = 0.0, m = 0.0;
@@ -418,6 +439,13 @@ int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out8_d
         case SMHIP_F64: return run_reduce<double, AddOp<double>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
         case SMHIP_I32: return run_reduce<int32_t, AddOp<int32_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
         case SMHIP_I64: return run_reduce<int64_t, AddOp<int64_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        // the generic dot_product<T>'s other integer element types (product.h:8-20)
+        case SMHIP_I8: return run_reduce<int8_t, AddOp<int8_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_U8: return run_reduce<uint8_t, AddOp<uint8_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_I16: return run_reduce<int16_t, AddOp<int16_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_U16: return run_reduce<uint16_t, AddOp<uint16_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_U32: return run_reduce<uint32_t, AddOp<uint32_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
+        case SMHIP_U64: return run_reduce<uint64_t, AddOp<uint64_t>, kDot>(a, b, nullptr, n, out8_dev, out_native_dev, s);
     }
     return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
 }

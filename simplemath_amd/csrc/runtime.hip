@@ -880,7 +880,7 @@ int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev) {
 }
 
 int smhip_dot_async(int dtype, const void *a, const void *b, size_t n, double *out_dev) {
-    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
+    if (!valid_dot_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
     if (!out_dev || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot: null buffer");
     SMHIP_ACQUIRE(s);
     return launch_dot(dtype, a, b, n, out_dev, nullptr, s);
@@ -904,7 +904,7 @@ int smhip_sum(int dtype, const void *a, size_t n, double *out_host) {
 }
 
 int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host) {
-    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
+    if (!valid_dot_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
     if (!out_host || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot: null buffer");
     void *d = nullptr;
     if (int rc = smhip_alloc(&d, 16)) return rc;

@@ -195,6 +195,42 @@ def dot_inputs(c):
     return a, b
 
 
+# complex and generic-integer dot (product.h:168-224, :8-20) -> tests/golden/dot_extra.npz
+CDOT_N = [1, 2, 3, 4, 5, 8, 33, 1000]
+GDOT_N = [1, 7, 8, 9, 100, 4099]
+GDOT_DTYPES = ["int8", "uint8", "int16", "uint16", "uint32", "uint64"]
+
+
+def cdot_cases():
+    return [{"id": f"cdot-{n}", "n": n, "seed": 16000 + i} for i, n in enumerate(CDOT_N)]
+
+
+def cdot_inputs(c):
+    import numpy as np
+    ar, ai = gen.gen(np.float64, c["n"], c["seed"], "uniform"), gen.gen(np.float64, c["n"], c["seed"] + 1, "uniform")
+    br, bi = gen.gen(np.float64, c["n"], c["seed"] + 2, "uniform"), gen.gen(np.float64, c["n"], c["seed"] + 3, "uniform")
+    return (ar + 1j * ai).astype(np.complex128), (br + 1j * bi).astype(np.complex128)
+
+
+def gdot_cases():
+    out, seed = [], 17000
+    for dt in GDOT_DTYPES:
+        for n in GDOT_N:
+            seed += 1
+            out.append({"id": f"gdot-{dt}-{n}", "dtype": dt, "n": n, "seed": seed})
+    return out
+
+
+def gdot_inputs(c):
+    import numpy as np
+    dt = np.dtype(c["dtype"])
+    rng = np.random.default_rng(c["seed"])
+    info = np.iinfo(dt)
+    a = rng.integers(info.min, info.max, size=c["n"], dtype=dt, endpoint=True)
+    b = rng.integers(info.min, info.max, size=c["n"], dtype=dt, endpoint=True)
+    return a, b
+
+
 # ----------------------------------------------------------------- float pow
 POWF_EXPS = [2.5, 2.0, 3.0, 0.5, -1.0, -2.5, 0.0, 1.0, 1.5, 7.0, -3.0, 0.3333333432674408, 10.25, 100.0, -100.0,
              1e-3, float("inf"), float("-inf"), float("nan")]

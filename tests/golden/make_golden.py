@@ -14,6 +14,7 @@ through oracle/_ref/libsmref.so (oracle/ref_shim.cpp).  Outputs:
     tests/golden/scalar.npz       array_scalar_op            (calculate.h:137-169)
     tests/golden/ipow.npz         PowOp<int> via array_scalar_op (pow.h:70-81, crafted_pow.h:54-103)
     tests/golden/dot.npz          dot_product<T>             (product.h)
+    tests/golden/dot_extra.npz    dot_product<std::complex<double>> and the generic dot_product<T> (product.h:168-224, :8-20)
     tests/golden/powf.npz         PowOp<float>::apply = glibc powf (pow.h:8-10) AND the
                                   correctly-rounded value computed in fp64 (the parity target;
                                   the reference itself pins no float pow -- SURVEY 8c)
@@ -52,8 +53,24 @@ def _put(store, cid, out, ins, big=False):
         store[f"{cid}/out"] = flat
 
 
+def make_dot_extra(ref):
+    st = {}
+    for c in cases.cdot_cases():  # what the compiled reference returns, n = 1 (scalar tail only) .. 1000 (AVX body: doubled sums)
+        a, b = cases.cdot_inputs(c)
+        r = ref.dot_c64(a, b)
+        _put(st, c["id"], np.array([r.real, r.imag], dtype=np.float64), (a.view(np.float64), b.view(np.float64)))
+    for c in cases.gdot_cases():
+        a, b = cases.gdot_inputs(c)
+        _put(st, c["id"], np.array([ref.dot_int(a, b)], dtype=a.dtype), (a, b))
+    np.savez_compressed(os.path.join(HERE, "dot_extra.npz"), **st)
+    print("dot_extra:", len(st) // 4, "cases")
+
+
 def main():
     ref = orc.Reference()
+    if sys.argv[1:] == ["dot_extra"]:  # only the file added in round 3 (the others stay byte-identical in git)
+        make_dot_extra(ref)
+        return
     OPS = orc.OPS
 
     st = {}
@@ -104,6 +121,8 @@ def main():
         _put(st, c["id"], out, (a, b))
     np.savez_compressed(os.path.join(HERE, "dot.npz"), **st)
     print("dot:", len(st) // 4, "cases")
+
+    make_dot_extra(ref)
 
     st = {}
     for c in cases.powf_cases():

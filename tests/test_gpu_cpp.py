@@ -65,3 +65,12 @@ def test_readme_plugin_recipe_on_the_gpu():
     """The reference's plugin recipe (README.md:86-133) plus SM_DEVICE_OP: element_wise_op<T, MyOp<T>> runs on the GPU."""
     r = subprocess.run([_exe("readme_recipe")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "device form" in r.stdout and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+def test_dot_for_every_element_type_of_the_reference():
+    """tests/cpp/test_dot_types.cpp: operator% for the generic dot_product<T>'s 8- / 16-bit and unsigned integer types (bit
+    exact against the statement as written) and for std::complex<double> arrays that stay resident (views, contiguous(),
+    repeat(), assignment into views on the device)."""
+    r = subprocess.run([_exe("test_dot_types")], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -461,6 +461,53 @@ def test_complex_dot(smhip):
         assert np.array_equal(res.numpy(), first), n
 
 
+def test_complex_dot_against_the_oracle_and_the_recorded_reference(smhip, oracle):
+    """the complex dot pinned to what the reference holds.  The oracle's `definition` (the scalar statement
+    of product.h:221-222 for every element) is bit-identical to the compiled reference at n = 1 (tests/test_oracle.py); the
+    GPU result must agree with it within the fp64 accumulation bound at every n, and at n = 1 -- one product, no
+    accumulation -- within one rounding of each part (the kernel's fma chain rounds the two products of a part in the
+    other order than GCC's contraction does).  The reference's own answers for n >= 2 (tests/golden/dot_extra.npz) count
+    every paired product twice: the GPU result is checked to be what that doubling was applied to."""
+    st = util.load_npz("dot_extra.npz")
+    for c in cases.cdot_cases():
+        a, b = cases.cdot_inputs(c)
+        n = c["n"]
+        got = smhip.dot_c64(smhip.to_device(a.view(np.float64)).ptr, smhip.to_device(b.view(np.float64)).ptr, n)
+        definition = oracle.dot_c64(a, b)
+        scale = float(np.sum(np.abs(a) * np.abs(b)))
+        assert abs(got - definition) <= 4 * n * 2.0 ** -53 * scale, n
+        recorded = complex(*st[f"{c['id']}/out"])
+        if n == 1:
+            assert recorded == definition
+            assert abs(got.real - recorded.real) <= 2.0 ** -52 * scale and abs(got.imag - recorded.imag) <= 2.0 ** -52 * scale
+        else:
+            paired = n - n % 2
+            head = smhip.dot_c64(smhip.to_device(a[:paired].view(np.float64)).ptr, smhip.to_device(b[:paired].view(np.float64)).ptr, paired)
+            tail = complex(a[-1] * b[-1]) if n % 2 else 0
+            assert abs(recorded - (2 * head + tail)) <= 16 * n * 2.0 ** -53 * scale, n  # the AVX body's doubled sums, as data
+
+
+def test_generic_integer_dot(smhip, oracle):
+    """The generic dot_product<T> (product.h:8-20) for int8 / uint8 / int16 / uint16 / uint32 / uint64: bit-exact against
+    the reference-recorded fixtures and the oracle -- the sum of products modulo 2^(8 sizeof T), in any order."""
+    st = util.load_npz("dot_extra.npz")
+    for c in cases.gdot_cases():
+        a, b = cases.gdot_inputs(c)
+        got = smhip.dot(smhip.to_device(a), smhip.to_device(b))
+        assert got.dtype == a.dtype and got == st[f"{c['id']}/out"][0] == oracle.dot_int(a, b), c["id"]
+    rng = np.random.default_rng(31)
+    for dt in cases.GDOT_DTYPES:  # sizes that cross tiles and finish in several groups; unaligned starts
+        info = np.iinfo(dt)
+        for n in (0, 3, 4096 * 2 + 5, 1024 * 512 * (16 // np.dtype(dt).itemsize) + 77):
+            a = rng.integers(info.min, info.max, size=n + 3, dtype=dt, endpoint=True)
+            b = rng.integers(info.min, info.max, size=n + 3, dtype=dt, endpoint=True)
+            da, db = smhip.to_device(a), smhip.to_device(b)
+            for off in (0, 1, 3):
+                va, vb = da.view_like(a[off:off + n], a), db.view_like(b[off:off + n], b)
+                want = oracle.dot_int(np.ascontiguousarray(a[off:off + n]), np.ascontiguousarray(b[off:off + n])) if n else np.zeros(1, dt)[0]
+                assert smhip.dot(va, vb) == want, (dt, n, off)
+
+
 def test_user_op_via_hiprtc(smhip):
     """The plugin contract on the device: an Op registered as a HIP expression runs through the same
     entry points as the built-ins (contiguous, scalar, broadcast), for every element type."""
