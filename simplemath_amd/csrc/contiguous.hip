@@ -121,9 +121,11 @@ constexpr int kTileBlock = 256;
 // wants the same few KiB), resp. the single element b[i / cv].  Through the row kernel this shape paid ~35 vector
 // instructions per wave of index arithmetic on top of pow's 257 and staged the tables before its loads: 23.9 us at
 // 4096 x 4096 against 20.2 us here (profiles/r02_pow_shapes.txt; 21.1-21.8 us under the profiler, r02_pmc_sq_pow_shapes.txt).
-template <typename T, typename Op, int KIND, int U, bool KEEP_STORES>
-__global__ __launch_bounds__(kTileBlock) void flat_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
-                                                                T *__restrict__ out, size_t n_vec, int tail, int nt, FastDiv cv) {
+// BLOCK: 256 threads, except for the bank-private double pow (ops.hip.h: PowBanked), whose 80 KiB of tables want 1024.
+template <typename T, typename Op, int KIND, int U, bool KEEP_STORES, int BLOCK = kTileBlock>
+__global__ __launch_bounds__(BLOCK) void flat_tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T s,
+                                                           T *__restrict__ out, size_t n_vec, int tail, int nt, FastDiv cv) {
+    constexpr int kTileBlock = BLOCK;  // shadows the file-scope default inside this kernel
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     OpCtx<Op> ctx;
@@ -212,6 +214,63 @@ __global__ __launch_bounds__(kTileBlock) void flat_tile_kernel(const T *__restri
     }
 }
 
+// double pow with bank-private tables (ops.hip.h: PowBanked), PERSISTENT: two 1024-thread workgroups per CU stage the 80 KiB
+// of replicas once and walk the tiles grid-stride.  As a one-shot launch (one tile per workgroup) the staging alone moved
+// 874 MB through the L2 for a 1 GiB array and the kernel LOST to round 2's (245.9 against 197.5 us, N = 2^26,
+// profiles/r03_pow64_rate.txt); arithmetic-bound as this Op is, eight resident waves per SIMD cover each other's loads
+// without a software pipeline.  KIND 0: a op b, 1: a op s, 2: s op a.
+template <int KIND, int U, bool KEEP_STORES>
+__global__ __launch_bounds__(1024, 8) void pow64_banked_kernel(const double *__restrict__ a, const double *__restrict__ b, double s,
+                                                                double *__restrict__ out, size_t n_vec, int tail, int nt) {
+    typedef double T;
+    typedef VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width, BLOCK = 1024;
+    OpCtx<PowBanked> ctx;
+    ctx.init();
+    const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
+    V *ov = reinterpret_cast<V *>(out);
+    auto eval = [&](const V &xa, const V &xb) {
+        if constexpr (KIND == 0) return apply_vec<PowBanked, T>(ctx, xa, xb);
+        else return apply_vec_scalar<PowBanked, T, KIND == 2>(ctx, xa, s);
+    };
+    constexpr size_t kTile = (size_t)BLOCK * U;
+    const size_t full_tiles = n_vec / kTile;
+    for (size_t t = blockIdx.x; t < full_tiles; t += gridDim.x) {  // every wave's trip count is finite: t only grows
+        const size_t base = t * kTile + threadIdx.x;
+        V va[U], vb[U];
+        if (nt & kLoadNt) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                va[u] = load_stream_as(T, av + base + (size_t)u * BLOCK, true);
+                if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * BLOCK, true);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                va[u] = load_stream_as(T, av + base + (size_t)u * BLOCK, false);
+                if constexpr (KIND == 0) vb[u] = load_stream_as(T, bv + base + (size_t)u * BLOCK, false);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) store_stream_as(T, ov + base + (size_t)u * BLOCK, eval(va[u], KIND == 0 ? vb[u] : va[u]), !KEEP_STORES);
+    }
+    if (blockIdx.x == full_tiles % gridDim.x) {  // the partial tile and the n % W tail: the workgroup whose turn it would be
+        for (size_t i = full_tiles * kTile + threadIdx.x; i < n_vec; i += BLOCK) {
+            const V va = load_stream(av + i);
+            V vb = va;
+            if constexpr (KIND == 0) vb = load_stream(bv + i);
+            store_stream(ov + i, eval(va, vb));
+        }
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < tail; ++k) {
+                const T x = a[n_vec * W + k];
+                const T y = KIND == 0 ? b[n_vec * W + k] : s;
+                out[n_vec * W + k] = KIND == 2 ? PowBanked::apply(y, x) : PowBanked::apply(x, y);
+            }
+        }
+    }
+}
+
 template <typename Op> struct IsHeavy : std::false_type {};
 // float / double pow only: integer pow is a short square-and-multiply loop, and the plain launch beats the pipelined one on
 // it for every exponent distribution tried (tools/ipow_exp.py: 80 % vs 64 % of peak for exponents < 32, 42 % vs 40 % for
@@ -235,15 +294,69 @@ template <typename T> struct IsHeavy<PowOp<T>> : std::integral_constant<bool, st
 template <typename T, int KIND> struct HeavyTile { static constexpr int value = KIND == 0 ? SMHIP_HEAVY_F32_TILE_ARRAY : SMHIP_HEAVY_F32_TILE_SCALAR; };
 template <int KIND> struct HeavyTile<double, KIND> { static constexpr int value = KIND == 0 ? SMHIP_HEAVY_F64_TILE_ARRAY : SMHIP_HEAVY_F64_TILE_SCALAR; };
 
+// Very large arrays go out as several launches.  The f32 add holds 81-82 % of HBM peak up to N = 2^28 and sagged to 78 % at
+// 2^30 / 77 % at 2^31 as ONE launch.  Round 2 blamed address translation (UTCL1 misses per 2 MiB page); round 3 disproved it:
+// memory mapped through hipMemCreate / hipMemMap shows 24 x the UTCL1 misses and a UTCL2 that is busy 55 % of the kernel
+// instead of 2 % -- and runs 2 % FASTER (tools/sweep_vmm.hip, tools/pmc_vmm.sh -> profiles/r03_pmc_vmm.txt); the distance
+// between the three streams does nothing either (tools/sweep_distance.hip).  What matters is the launch's LENGTH: the same
+// 12 GiB, same placement, as four launches of 2^28 run at 79.9 %, as sixteen of 2^26 at 80.7 % (one launch: 78.0 %).  A
+// launch's workgroups are dealt to the eight XCDs in order and each XCD works through its share at its own pace; over
+// hundreds of thousands of workgroups their fronts drift apart and the DRAM pages they share stop being open for each
+// other; a kernel boundary lines them up again.  So: pieces of 2^24 vectors (256 MiB per operand) once an operand
+// exceeds 1 GiB.  SMHIP_PIECE_LOG2VEC=<k> moves the piece size (0: never split).
+inline size_t piece_vectors() {
+    static const size_t v = [] {
+        const char *e = getenv("SMHIP_PIECE_LOG2VEC");
+        const int k = e ? atoi(e) : 24;
+        return k <= 0 ? (size_t)0 : (size_t)1 << (k < 16 ? 16 : k);
+    }();
+    return v;
+}
+constexpr size_t kSplitAboveVectors = (size_t)1 << 26;  // 1 GiB per operand
+
 // Launches the heavy form of `Op` (KIND 0: a op b, 1: a op s, 2: s op a).
 template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s);
 
+#ifndef SMHIP_POW64_BANKED
+#define SMHIP_POW64_BANKED 1
+#endif
+#ifndef SMHIP_POW64_BANKED_U
+#define SMHIP_POW64_BANKED_U 2
+#endif
+constexpr int kBankedBlock = 1024;
+template <typename T, typename Op, int KIND>
+void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, int nt, hipStream_t s);
+
 template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const int nt = KIND == 0 ? stream_policy({{pa, n_vec * 16}, {pb, n_vec * 16}}, {po, n_vec * 16}) : stream_policy({{pa, n_vec * 16}}, {po, n_vec * 16});
+    if (n_vec > kSplitAboveVectors && piece_vectors()) {  // very large: several launches (piece_vectors)
+        const size_t piece = piece_vectors();
+        for (size_t v0 = 0;; v0 += piece) {
+            const bool last = v0 + piece >= n_vec;
+            launch_heavy_piece<T, Op, KIND>(pa + v0 * W, KIND == 0 ? pb + v0 * W : pb, value, po + v0 * W, last ? n_vec - v0 : piece, last ? tail : 0, nt, s);
+            if (last) return;
+        }
+    }
+    launch_heavy_piece<T, Op, KIND>(pa, pb, value, po, n_vec, tail, nt, s);
+}
+
+template <typename T, typename Op, int KIND>
+void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, int nt, hipStream_t s) {
+    if constexpr (SMHIP_POW64_BANKED && std::is_same<Op, PowOp<double>>::value) {
+        // double pow reads its tables from bank-private replicas: no lookup of a wave can collide with another (ops.hip.h: PowBanked)
+        constexpr int U = SMHIP_POW64_BANKED_U;
+        const size_t tiles = n_vec / ((size_t)kBankedBlock * U) + 1;
+        const size_t resident = (size_t)compute_units() * 2;  // two 1024-thread workgroups per CU: 80 KiB of LDS and 64 VGPRs each
+        const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+        if (nt & kStoreKeep) hipLaunchKernelGGL((pow64_banked_kernel<KIND, U, true>), dim3(grid), dim3(kBankedBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
+        else hipLaunchKernelGGL((pow64_banked_kernel<KIND, U, false>), dim3(grid), dim3(kBankedBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
+        return;
+    }
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
-    const int nt = KIND == 0 ? stream_policy({{pa, n_vec * 16}, {pb, n_vec * 16}}, {po, n_vec * 16}) : stream_policy({{pa, n_vec * 16}}, {po, n_vec * 16});
     if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
     else hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
 }
@@ -275,26 +388,6 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
     SMHIP_LAUNCH_CHECK("heavy rows");
     return SMHIP_OK;
 }
-
-// Very large arrays go out as several launches.  The f32 add holds 81-82 % of HBM peak up to N = 2^28 and sagged to 78 % at
-// 2^30 / 77 % at 2^31 as ONE launch.  Round 2 blamed address translation (UTCL1 misses per 2 MiB page); round 3 disproved it:
-// memory mapped through hipMemCreate / hipMemMap shows 24 x the UTCL1 misses and a UTCL2 that is busy 55 % of the kernel
-// instead of 2 % -- and runs 2 % FASTER (tools/sweep_vmm.hip, tools/pmc_vmm.sh -> profiles/r03_pmc_vmm.txt); the distance
-// between the three streams does nothing either (tools/sweep_distance.hip).  What matters is the launch's LENGTH: the same
-// 12 GiB, same placement, as four launches of 2^28 run at 79.9 %, as sixteen of 2^26 at 80.7 % (one launch: 78.0 %).  A
-// launch's workgroups are dealt to the eight XCDs in order and each XCD works through its share at its own pace; over
-// hundreds of thousands of workgroups their fronts drift apart and the DRAM pages they share stop being open for each
-// other; a kernel boundary lines them up again.  So: pieces of 2^24 vectors (256 MiB per operand) once an operand
-// exceeds 1 GiB.  SMHIP_PIECE_LOG2VEC=<k> moves the piece size (0: never split).
-inline size_t piece_vectors() {
-    static const size_t v = [] {
-        const char *e = getenv("SMHIP_PIECE_LOG2VEC");
-        const int k = e ? atoi(e) : 24;
-        return k <= 0 ? (size_t)0 : (size_t)1 << (k < 16 ? 16 : k);
-    }();
-    return v;
-}
-constexpr size_t kSplitAboveVectors = (size_t)1 << 26;  // 1 GiB per operand
 
 inline int grid_for(size_t threads, int block, unsigned *grid) {
     const size_t g = (threads + block - 1) / block;

@@ -298,6 +298,44 @@ template <> struct OpCtx<PowOp<double>> {
     }
 };
 
+// PowOp<double> for the flat tile kernel: the same arithmetic reading its tables from BANK-PRIVATE replicas (sm_pow64.h:
+// TabBanked), so that a wave's scattered lookups never collide.  Round 2's scalar-exponent kernel spent 43 % of its
+// LDS-active cycles in bank conflicts and ran at 68 % of HBM peak on random bases against 78 % when every lane hit the same
+// entry.  Sixteen replicas of the five table arrays are 80 KiB of LDS: the kernel runs 1024-thread workgroups (two per
+// CU, 64 VGPRs: full occupancy) and each thread stages ten doubles.  Only launched by contiguous.hip's heavy form; every
+// other kernel keeps PowOp<double> and its 5 KiB copy.
+struct PowBanked {
+    static __device__ __forceinline__ double apply(double a, double b) { return PowOp<double>::apply(a, b); }
+};
+template <> struct OpCtx<PowBanked> {
+    static constexpr int kDoubles = smpow64::kBankedDoubles;
+    smpow64::TabBanked tab;
+    template <int BLOCK> struct Stage { double v[kDoubles / BLOCK]; };
+    __device__ __forceinline__ void init() {  // (the tile kernel uses fetch / commit)
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+        for (int f = threadIdx.x; f < kDoubles; f += blockDim.x) lds_tab[f] = smpow64::table_value((f >> 4) / smpow64::kN, (f >> 4) % smpow64::kN);
+        __syncthreads();
+        tab.mine = lds_tab + (threadIdx.x & (smpow64::kBankedReplicas - 1));
+    }
+    // flat slot f = (array * 128 + entry) * 16 + replica: thread t stages slots t, t + BLOCK, ... -- consecutive lanes write
+    // consecutive doubles (conflict-free), and the sixteen lanes that share a source value read it as one broadcast
+    template <int BLOCK> __device__ __forceinline__ void fetch(Stage<BLOCK> &st) const {
+        static_assert(kDoubles % BLOCK == 0, "the replicas are staged in whole rounds");
+#pragma unroll
+        for (int k = 0; k < kDoubles / BLOCK; ++k) {
+            const int f = (int)threadIdx.x + k * BLOCK;
+            st.v[k] = smpow64::table_value((f >> 4) / smpow64::kN, (f >> 4) % smpow64::kN);
+        }
+    }
+    template <int BLOCK> __device__ __forceinline__ void commit(const Stage<BLOCK> &st) {
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+#pragma unroll
+        for (int k = 0; k < kDoubles / BLOCK; ++k) lds_tab[(int)threadIdx.x + k * BLOCK] = st.v[k];
+        __syncthreads();
+        tab.mine = lds_tab + (threadIdx.x & (smpow64::kBankedReplicas - 1));
+    }
+};
+
 // apply_simd's role: the Op across W independent elements held in registers.
 // PowOp<float> evaluates them side by side (one constant per polynomial step,
 // no branches); every other Op is one instruction per element.
@@ -307,6 +345,8 @@ __device__ __forceinline__ void apply_n(const OpCtx<Op> &ctx, const T (&a)[W], c
         smpow::pow_n<W>(a, b, r, ctx.tab);
     } else if constexpr (std::is_same<Op, PowOp<double>>::value) {
         smpow64::pow_n<W>(a, b, r, ctx.logtab, ctx.exptab);
+    } else if constexpr (std::is_same<Op, PowBanked>::value) {
+        smpow64::pow_n<W, smpow64::TabBanked>(a, b, r, ctx.tab);
     } else {
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);

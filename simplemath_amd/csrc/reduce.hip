@@ -27,8 +27,7 @@ namespace {
 
 using namespace dev;
 
-constexpr int kBlock = 256;  // also for the fused op+sum, although it is a 2R+1W stream like the add (whose kernel takes 1024): 507 us with
-                             // 256-thread workgroups, 510 with 512, 514 with 1024 (round 2)
+constexpr int kBlock = 256;  // sum, dot, the finishing launch (the fused op+sum: SMHIP_FUSED_BLOCK below)
 // 16-byte vectors per lane and operand (tools/reduce_rates.py, profiles/r01_reduce_rates.txt).  Read-only streams want
 // more loads in flight than the 2R+1W streams do: a plain sum runs at 86 % of peak with two vectors per lane (65-69 %
 // with one, 82-84 % with four or eight), a dot at 84 % with two per operand (79 % with one).  The fused op+sum writes as
@@ -183,15 +182,23 @@ constexpr uint32_t kMaxGroups = 1024, kGroupTarget = 1024;
 // before the first use, so kVecPerThread (x2 operands) 16-byte loads are in flight
 // per lane.  (Per-vector bounds guards made the compiler wait on each load pair
 // in turn -- 2.6 TB/s instead of 6.)
-template <typename T, typename Op, int MODE, bool KEEP>
-__global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+// The fused op+sum's workgroup: 1024 threads since round 3.  With ds_bpermute reductions 256 was the fastest (507 us per step
+// against 510 / 514 with 512 / 1024); with the DPP scan and thread 0 adding the sixteen wave totals the order turned round --
+// 505.3 (256), 510.8 (512), 501.8 us (1024) per step including the finishing launch, which also has a quarter of the
+// partials to add (profiles/r03_reduce_variants.txt).
+#ifndef SMHIP_FUSED_BLOCK
+#define SMHIP_FUSED_BLOCK 1024
+#endif
+constexpr int block_of(int mode) { return mode == 2 /* kFused */ ? SMHIP_FUSED_BLOCK : kBlock; }
+template <typename T, typename Op, int MODE, bool KEEP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                            size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials,
                                                            void *__restrict__ out8, T *__restrict__ out_native, int nt) {
     typedef typename AccOf<T>::type A;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
     constexpr int kVecPerThread = vec_per_thread(MODE);
-    constexpr size_t kTile = (size_t)kBlock * kVecPerThread;
+    constexpr size_t kTile = (size_t)BLOCK * kVecPerThread;
     const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
     V *ov = reinterpret_cast<V *>(out);
     const size_t tile0 = (size_t)blockIdx.x * kTile + threadIdx.x;
@@ -205,15 +212,15 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
         // experience (ops.hip.h); what this kernel waits for is its one pair of loads either way
 #pragma unroll
         for (int u = 0; u < kVecPerThread; ++u) {
-            va[u] = load_stream_if(T, av + tile0 + (size_t)u * kBlock, nt);
-            if constexpr (MODE != kSum) vb[u] = load_stream_if(T, bv + tile0 + (size_t)u * kBlock, nt);
+            va[u] = load_stream_if(T, av + tile0 + (size_t)u * BLOCK, nt);
+            if constexpr (MODE != kSum) vb[u] = load_stream_if(T, bv + tile0 + (size_t)u * BLOCK, nt);
             else vb[u] = va[u];
         }
 #pragma unroll
-        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, KEEP, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * kBlock);
+        for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, KEEP, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * BLOCK);
     } else {
         for (int u = 0; u < kVecPerThread; ++u) {
-            const size_t i = tile0 + (size_t)u * kBlock;
+            const size_t i = tile0 + (size_t)u * BLOCK;
             if (i < n_vec) {
                 const V va = load_stream(av + i);
                 const V vb = MODE != kSum ? load_stream(bv + i) : va;
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(kBlock, 8) void reduce_kernel(const T *__restrict__
             }
         }
     }
-    acc = block_reduce<A, kBlock>(acc);
+    acc = block_reduce<A, BLOCK>(acc);
     if (threadIdx.x == 0) {
         if (gridDim.x == 1) write_result<T, MODE != kDot>(acc, out8, out_native);  // a small array: no second launch
         else partials[blockIdx.x] = acc;
@@ -257,8 +264,22 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     if (out8) out8 = static_cast<double *>(out8) + blockIdx.y;
     const uint32_t first = blockIdx.x * fin.gsize;
     const uint32_t members = first + fin.gsize <= count ? fin.gsize : count - first;
+    // a thread's share of the group (<= kGroupTarget / kBlock values), every load issued before the first addition: as a
+    // loop with a run-time trip count these were four dependent round trips to the memory side, most of this kernel's 7 us
+    constexpr uint32_t kShare = kGroupTarget / kBlock;
     A acc = A(0);
-    for (uint32_t i = threadIdx.x; i < members; i += kBlock) acc += partials[first + i];
+    if (fin.gsize <= kGroupTarget) {
+        A v[kShare];
+#pragma unroll
+        for (uint32_t u = 0; u < kShare; ++u) {
+            const uint32_t i = threadIdx.x + u * kBlock;
+            v[u] = i < members ? partials[first + i] : A(0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kShare; ++u) acc += v[u];  // the loop's order: the same bits
+    } else {
+        for (uint32_t i = threadIdx.x; i < members; i += kBlock) acc += partials[first + i];
+    }
     acc = block_reduce<A, kBlock>(acc);
     if (gridDim.x == 1) {
         if (threadIdx.x == 0) write_result<T, AS_DOUBLE>(acc, out8, out_native);
@@ -283,7 +304,17 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     __syncthreads();
     if (!last) return;
     acc = A(0);
-    for (uint32_t i = threadIdx.x; i < gridDim.x; i += kBlock) acc += __hip_atomic_load(&fin.level2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        constexpr uint32_t kShare2 = kMaxGroups / kBlock;  // the group totals: again every load in flight before the first use
+        A v[kShare2];
+#pragma unroll
+        for (uint32_t u = 0; u < kShare2; ++u) {
+            const uint32_t i = threadIdx.x + u * kBlock;
+            v[u] = i < gridDim.x ? __hip_atomic_load(&fin.level2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A(0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kShare2; ++u) acc += v[u];
+    }
     __syncthreads();  // block_reduce's LDS slots are reused
     acc = block_reduce<A, kBlock>(acc);
     if (threadIdx.x == 0) {
@@ -368,7 +399,8 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     const T *a = static_cast<const T *>(a_), *b = static_cast<const T *>(b_);
     T *out = static_cast<T *>(out_);
     const size_t n_vec = n / W;
-    const size_t tile = (size_t)kBlock * vec_per_thread(MODE);
+    constexpr int BLOCK = block_of(MODE);
+    const size_t tile = (size_t)BLOCK * vec_per_thread(MODE);
     size_t blocks;
     blocks = n_vec / tile + 1;  // the last workgroup takes the partial tile and the n % W tail (maybe empty)
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "reduction too large (%zu workgroups)", blocks);
@@ -380,10 +412,10 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     const int pol = MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
                                  : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0});
     if (MODE == kFused && (pol & kStoreKeep))
-        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, MODE == kFused>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
+        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, MODE == kFused, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, a, b, out, n_vec, n, partials, out8,
                            static_cast<T *>(out_native), pol);
     else
-        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a, b, out, n_vec, n, partials, out8,
+        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, false, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, a, b, out, n_vec, n, partials, out8,
                            static_cast<T *>(out_native), pol);
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself

@@ -350,10 +350,43 @@ SM_POW_FN double fma4_c(double r, double c) {
 #define SM_POW_FMIN(a, b) fmin((a), (b))
 #endif
 
-// ax finite > 0, y finite.  logtab / exptab: kLogTab / kExpTab layout (LDS copies on the device).
-// SUB = false: ax is known to be normal (the callers route subnormal bases through the general path).
-template <bool SUB>
-SM_POW_FN double pow_core_t(double ax, double y, const double *logtab, const double *exptab) {
+// Where the evaluation finds its table entries.
+//   TabAoS     the tables as generated: {invc, logc_hi, logc_lo} / {T, tail} per entry (kLogTab / kExpTab, or an LDS copy
+//              of them): three LDS reads per element, and across a wave's scattered indices they collide -- entry i starts
+//              in bank 6 i mod 32, so 64 random lookups share 16 starting banks (43 % of the LDS-active cycles of the
+//              scalar-exponent kernel were bank conflicts, profiles/r02_pow64_rate.txt).
+//   TabBanked  sixteen replicas of every value, one per PAIR OF BANKS: value (array a, entry i) for replica c lives at
+//              double index (a * 128 + i) * 16 + c, lane l reads replica l mod 16 -- whatever the indices, sixteen
+//              neighbouring lanes hit sixteen different bank pairs: no lookup can conflict.  80 KiB of LDS, so the kernel
+//              that uses it runs 1024-thread workgroups, two per CU (ops.hip.h: PowBanked).
+#if defined(__HIPCC__)
+#define SM_POW_MEMFN __host__ __device__ __forceinline__
+#else
+#define SM_POW_MEMFN inline
+#endif
+struct TabAoS {
+    const double *logtab, *exptab;
+    SM_POW_MEMFN double invc(int i) const { return logtab[3 * i]; }
+    SM_POW_MEMFN double logc(int i) const { return logtab[3 * i + 1]; }
+    SM_POW_MEMFN double logctail(int i) const { return logtab[3 * i + 2]; }
+    SM_POW_MEMFN double th(int j) const { return exptab[2 * j]; }
+    SM_POW_MEMFN double trel(int j) const { return exptab[2 * j + 1]; }
+};
+constexpr int kBankedReplicas = 16, kBankedArrays = 5, kBankedDoubles = kBankedArrays * kN * kBankedReplicas;
+struct TabBanked {
+    const double *mine;  // the LDS copy + (lane & 15)
+    SM_POW_MEMFN double invc(int i) const { return mine[(0 * kN + i) * kBankedReplicas]; }
+    SM_POW_MEMFN double logc(int i) const { return mine[(1 * kN + i) * kBankedReplicas]; }
+    SM_POW_MEMFN double logctail(int i) const { return mine[(2 * kN + i) * kBankedReplicas]; }
+    SM_POW_MEMFN double th(int j) const { return mine[(3 * kN + j) * kBankedReplicas]; }
+    SM_POW_MEMFN double trel(int j) const { return mine[(4 * kN + j) * kBankedReplicas]; }
+};
+// value `a` (0 invc, 1 logc_hi, 2 logc_lo, 3 T, 4 tail) of entry i, from the generated tables
+SM_POW_FN double table_value(int a, int i) { return a < 3 ? kLogTab[3 * i + a] : kExpTab[2 * i + (a - 3)]; }
+
+// ax finite > 0, y finite.  SUB = false: ax is known to be normal (the callers route subnormal bases through the general path).
+template <bool SUB, typename TAB>
+SM_POW_FN double pow_core_t(double ax, double y, const TAB &tab) {
     uint32_t hi = (uint32_t)(f64_bits(ax) >> 32), lw = (uint32_t)f64_bits(ax);
     int sub = 0;
     if constexpr (SUB) {
@@ -369,7 +402,7 @@ SM_POW_FN double pow_core_t(double ax, double y, const double *logtab, const dou
     const int i = (int)((tmp >> (20 - 7)) & (kN - 1));
     const int k = ((int32_t)tmp >> 20) - sub;
     const double z = smpow::make_f64(hi - (tmp & 0xfff00000u), lw);
-    const double invc = logtab[3 * i], logc = logtab[3 * i + 1], logctail = logtab[3 * i + 2];
+    const double invc = tab.invc(i), logc = tab.logc(i), logctail = tab.logctail(i);
     const double kd = (double)k;
     const double Ln2hi = 0x1.62e42f8000000p-1, Ln2lo = 0x1.be8e7bcd5e4f2p-27;
     // r = z*invc - 1 needs up to 54 bits (53 + 9 - the ~8 that cancel): carry the last one as rlo
@@ -408,7 +441,7 @@ SM_POW_FN double pow_core_t(double ax, double y, const double *logtab, const dou
     rr = SM_POW_FMA(-kd2, Ln2loN, rr);
     rr += elo;
     const int j = ki & (kN - 1), e = ki >> 7;  // arithmetic shift: floor
-    const double th = exptab[2 * j], trel = exptab[2 * j + 1];
+    const double th = tab.th(j), trel = tab.trel(j);
     const double r2 = rr * rr;
     // trel + rr + rr^2 (1/2 + rr (1/6 + rr (1/24 + rr/120))); the innermost step as (rr + 5)/120: one constant per instruction
     double u = (rr + 5.0) * 0x1.1111111111111p-7;
@@ -419,13 +452,14 @@ SM_POW_FN double pow_core_t(double ax, double y, const double *logtab, const dou
 }
 
 // Every operand class: the core on stand-in operands, then the C99 F.9.4.4 lattice.
-SM_POW_FN double pow_general(double x, double y, const double *logtab, const double *exptab) {
+template <typename TAB>
+SM_POW_FN double pow_general(double x, double y, const TAB &tab) {
     const uint64_t ONE = 0x3ff0000000000000ULL, INF = 0x7ff0000000000000ULL, QNAN = 0x7ff8000000000000ULL;
     const uint64_t ix = f64_bits(x), iy = f64_bits(y);
     const uint64_t ax = ix & 0x7fffffffffffffffULL, ay = iy & 0x7fffffffffffffffULL;
     const double axc = bits_f64((ax == 0 || ax >= INF) ? ONE : ax);
     const double yc_d = ay >= INF ? 1.0 : y;
-    const double core = pow_core_t<true>(axc, yc_d, logtab, exptab);
+    const double core = pow_core_t<true>(axc, yc_d, tab);
     const bool x_neg = (ix >> 63) != 0, y_neg = (iy >> 63) != 0;
     const bool x_nan = ax > INF, y_nan = ay > INF;
     const bool x_one = ix == ONE, y_zero = ay == 0;
@@ -454,13 +488,14 @@ SM_POW_FN uint32_t oddness(double x, double y) {
 }
 
 SM_POW_FN double pow(double x, double y, const double *logtab, const double *exptab) {
-    if (!smpow::any_lane(oddness(x, y) >= kOrdinarySpan)) return pow_core_t<false>(x, y, logtab, exptab);
-    return pow_general(x, y, logtab, exptab);
+    const TabAoS tab{logtab, exptab};
+    if (!smpow::any_lane(oddness(x, y) >= kOrdinarySpan)) return pow_core_t<false>(x, y, tab);
+    return pow_general(x, y, tab);
 }
 
 // x^y for W independent pairs held in registers: one test (and one branch) for the group.
-template <int W>
-SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W], const double *logtab, const double *exptab) {
+template <int W, typename TAB>
+SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W], const TAB &tab) {
     uint32_t worst = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -469,7 +504,7 @@ SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W
     }
     if (!smpow::any_lane(worst >= kOrdinarySpan)) {
 #pragma unroll
-        for (int k = 0; k < W; ++k) out[k] = pow_core_t<false>(x[k], y[k], logtab, exptab);
+        for (int k = 0; k < W; ++k) out[k] = pow_core_t<false>(x[k], y[k], tab);
         return;
     }
     // operands opaque from here on, so that nothing of the lattice is hoisted above the branch (sm_pow.h: pow_n)
@@ -479,8 +514,12 @@ SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(xs), "+v"(ys));
 #endif
-        out[k] = pow_general(xs, ys, logtab, exptab);
+        out[k] = pow_general(xs, ys, tab);
     }
+}
+template <int W>
+SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W], const double *logtab, const double *exptab) {
+    pow_n<W, TabAoS>(x, y, out, TabAoS{logtab, exptab});
 }
 
 }  // namespace smpow64
