@@ -214,6 +214,18 @@ __global__ __launch_bounds__(BLOCK) void flat_tile_kernel(const T *__restrict__ 
     }
 }
 
+// Measured and NOT adopted (round 3): -DSMHIP_POW64_BANKED=1 builds it for experiments.  N = 2^26, random
+// bases, scalar exponent: round 2's kernel 197.5-198.2 us (68 %; 172 us when every lane reads the same entry); bank-private
+// replicas as a one-shot launch 245.9 us (LDS bank conflicts 43 -> 12.7 % of the LDS-active cycles, but 80 KiB staged per
+// tile); persistent 213.7 us with two vectors per lane, 210.1 with three -- and 207 us even when every lane reads the same
+// entry: what the 1024-thread persistent form costs exceeds what the conflicts cost (profiles/r03_pow64_rate.txt).
+#ifndef SMHIP_POW64_BANKED
+#define SMHIP_POW64_BANKED 0
+#endif
+#ifndef SMHIP_POW64_BANKED_U
+#define SMHIP_POW64_BANKED_U 2
+#endif
+#if SMHIP_POW64_BANKED
 // double pow with bank-private tables (ops.hip.h: PowBanked), PERSISTENT: two 1024-thread workgroups per CU stage the 80 KiB
 // of replicas once and walk the tiles grid-stride.  As a one-shot launch (one tile per workgroup) the staging alone moved
 // 874 MB through the L2 for a 1 GiB array and the kernel LOST to round 2's (245.9 against 197.5 us, N = 2^26,
@@ -271,6 +283,8 @@ __global__ __launch_bounds__(1024, 8) void pow64_banked_kernel(const double *__r
     }
 }
 
+#endif  // SMHIP_POW64_BANKED
+
 template <typename Op> struct IsHeavy : std::false_type {};
 // float / double pow only: integer pow is a short square-and-multiply loop, and the plain launch beats the pipelined one on
 // it for every exponent distribution tried (tools/ipow_exp.py: 80 % vs 64 % of peak for exponents < 32, 42 % vs 40 % for
@@ -318,12 +332,6 @@ constexpr size_t kSplitAboveVectors = (size_t)1 << 26;  // 1 GiB per operand
 template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s);
 
-#ifndef SMHIP_POW64_BANKED
-#define SMHIP_POW64_BANKED 1
-#endif
-#ifndef SMHIP_POW64_BANKED_U
-#define SMHIP_POW64_BANKED_U 2
-#endif
 constexpr int kBankedBlock = 1024;
 template <typename T, typename Op, int KIND>
 void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, int nt, hipStream_t s);
@@ -345,7 +353,8 @@ void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int ta
 
 template <typename T, typename Op, int KIND>
 void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, int nt, hipStream_t s) {
-    if constexpr (SMHIP_POW64_BANKED && std::is_same<Op, PowOp<double>>::value) {
+#if SMHIP_POW64_BANKED
+    if constexpr (std::is_same<Op, PowOp<double>>::value) {
         // double pow reads its tables from bank-private replicas: no lookup of a wave can collide with another (ops.hip.h: PowBanked)
         constexpr int U = SMHIP_POW64_BANKED_U;
         const size_t tiles = n_vec / ((size_t)kBankedBlock * U) + 1;
@@ -355,6 +364,7 @@ void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, 
         else hipLaunchKernelGGL((pow64_banked_kernel<KIND, U, false>), dim3(grid), dim3(kBankedBlock), 0, s, pa, pb, value, po, n_vec, tail, nt);
         return;
     }
+#endif
     constexpr int U = HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
     if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));

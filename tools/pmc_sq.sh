@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 for wl in "$@"; do
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/pmc_sq_$wl -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $out/pmc_sq_$wl.log 2>&1
+    python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --configs none > $out/pmc_sq_$wl.log 2>&1
   echo "pmc sq $wl rc=$?"
   f=$(find $out/pmc_sq_$wl -name "*counter_collection.csv" | head -1)
   python3 - "$f" $wl <<'PY'

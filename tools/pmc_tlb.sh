@@ -11,7 +11,7 @@ pass() {  # name, counters...
   name=$1; shift
   for lg in 28 30 31; do
     timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_${name}_$lg -- \
-      python3 $GRAFT_REPO_ROOT/bench.py --log2n $lg --steps 5 --warmup 2 --no-cpu-baseline --prewarm 0.05 > $out/pmc_${name}_$lg.log 2>&1
+      python3 $GRAFT_REPO_ROOT/bench.py --log2n $lg --steps 5 --warmup 2 --no-cpu-baseline --configs none --prewarm 0.05 > $out/pmc_${name}_$lg.log 2>&1
     echo "pmc $name 2^$lg rc=$?"
   done
 }

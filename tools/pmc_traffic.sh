@@ -10,7 +10,7 @@ cd /tmp
 for wl in "$@"; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${wl}_$ctr -- \
-      python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $out/pmc_${wl}_$ctr.log 2>&1
+      python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --configs none > $out/pmc_${wl}_$ctr.log 2>&1
     echo "pmc $wl $ctr rc=$?"
   done
 done
