@@ -486,7 +486,7 @@ def time_steps(lib, steps, n_steps, warmup, barrier=None):
 def config_legs(lib, sma, np, C, args, bound):
     """BASELINE configs 3, 4 and 5's per-GPU step, each replayed and cold, on the current device (rank 0, N = 1)."""
     legs = {}
-    for key, wl, n_steps in (("c3", "bcast_mul", 200), ("c4", "pow", 100), ("c5_shard", "add_sum", 30)):
+    for key, wl, n_steps in (("c3", "bcast_mul", 200), ("c4", "pow", 100), ("c5_shard", "add_sum", 60)):
         leg = None
         for setting in ("replay", "cold"):
             steps, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, 0, bound, setting, log2n=0)

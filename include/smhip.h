@@ -265,6 +265,14 @@ int smhip_comm_destroy(void);
  * 2^64).  Asynchronous. */
 int smhip_allreduce_sum_async(int dtype, void *inout_dev, size_t count);
 
+/* --------------------------------------------------------- diagnostics */
+/* The stream-policy word the library would give a launch that reads [a, a + a_bytes) and [b, b + b_bytes) (either may be
+ * NULL / 0) and writes [out, out + out_bytes) on the calling thread's device: bit 0 = its reads carry the non-temporal
+ * hint, bit 1 = its results are stored to stay in the Infinity Cache (read side, write side, cold
+ * operands).  Like a launch it records the spans as touched.  Host-only arithmetic on the pointer VALUES (nothing is
+ * dereferenced, no device is needed): the residency rule's test hook. */
+int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy);
+
 /* -------------------------------------------------------------- timing */
 /* HIP events on the calling thread's stream (what bench.py brackets the
  * timed region with). */

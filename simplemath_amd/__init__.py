@@ -469,6 +469,13 @@ class Smhip:
     def allreduce_sum_async(self, dtype, ptr, count=1):
         self._ck(self.c.smhip_allreduce_sum_async(C.c_int(DTYPES[np.dtype(dtype)]), C.c_void_p(ptr), C.c_size_t(count)))
 
+    def policy_probe(self, a=0, a_bytes=0, b=0, b_bytes=0, out=0, out_bytes=0):
+        """The stream-policy word for a launch with these operand spans (bit 0: nt reads, bit 1: keep-stores); records the touches."""
+        pol = C.c_int(0)
+        self._ck(self.c.smhip_policy_probe(C.c_void_p(a), C.c_size_t(a_bytes), C.c_void_p(b), C.c_size_t(b_bytes), C.c_void_p(out),
+                                           C.c_size_t(out_bytes), C.byref(pol)))
+        return pol.value
+
     # -- timing -----------------------------------------------------------------
     def event(self):
         e = C.c_void_p(0)

@@ -471,6 +471,19 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
     const size_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
     int pol = stream_policy({{a, n * dtype_size(dtype)}, {b, n * dtype_size(dtype)}}, {out, n * dtype_size(dtype)});
+    constexpr unsigned long long kPiece = 1ull << 24, kSplitAbove = 1ull << 26;  // vectors: very large arrays go out in pieces (contiguous.hip)
+    if (n_vec > kSplitAbove) {
+        const size_t esz = dtype_size(dtype);
+        for (unsigned long long v0 = 0;; v0 += kPiece) {
+            const bool last = v0 + kPiece >= n_vec;
+            const void *pa = static_cast<const char *>(a) + v0 * w * esz, *pb = static_cast<const char *>(b) + v0 * w * esz;
+            void *po = static_cast<char *>(out) + v0 * w * esz;
+            unsigned long long nv = last ? n_vec - v0 : kPiece, ne = last ? n - v0 * w : kPiece * w;
+            void *pargs[] = {&pa, &pb, &po, &nv, &ne, &vec, &pol};
+            SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)((nv + 1 + 255) / 256), 1, 1, 256, 1, 1, 0, s, pargs, nullptr));
+            if (last) return SMHIP_OK;
+        }
+    }
     void *args[] = {&a, &b, &out, &n_vec, &nn, &vec, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;
@@ -487,6 +500,19 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
     unsigned char scalar[8];
     memcpy(scalar, value_host, dtype_size(dtype));
     int pol = stream_policy({{a, n * dtype_size(dtype)}}, {out, n * dtype_size(dtype)});
+    constexpr unsigned long long kPiece = 1ull << 24, kSplitAbove = 1ull << 26;
+    if (n_vec > kSplitAbove) {
+        const size_t esz = dtype_size(dtype);
+        for (unsigned long long v0 = 0;; v0 += kPiece) {
+            const bool last = v0 + kPiece >= n_vec;
+            const void *pa = static_cast<const char *>(a) + v0 * w * esz;
+            void *po = static_cast<char *>(out) + v0 * w * esz;
+            unsigned long long nv = last ? n_vec - v0 : kPiece, ne = last ? n - v0 * w : kPiece * w;
+            void *pargs[] = {&pa, scalar, &po, &nv, &ne, &swapped, &pol};
+            SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)((nv + 1 + 255) / 256), 1, 1, 256, 1, 1, 0, s, pargs, nullptr));
+            if (last) return SMHIP_OK;
+        }
+    }
     void *args[] = {&a, scalar, &out, &n_vec, &nn, &swapped, &pol};
     SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return SMHIP_OK;

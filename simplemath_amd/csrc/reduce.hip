@@ -193,7 +193,7 @@ constexpr int block_of(int mode) { return mode == 2 /* kFused */ ? SMHIP_FUSED_B
 template <typename T, typename Op, int MODE, bool KEEP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                            size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ partials,
-                                                           void *__restrict__ out8, T *__restrict__ out_native, int nt) {
+                                                           void *__restrict__ out8, T *__restrict__ out_native, int nt, int single) {
     typedef typename AccOf<T>::type A;
     typedef typename VecTraits<T>::vec_t V;
     constexpr int W = VecTraits<T>::width;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_kernel(const T *__restrict__ a, 
     }
     acc = block_reduce<A, BLOCK>(acc);
     if (threadIdx.x == 0) {
-        if (gridDim.x == 1) write_result<T, MODE != kDot>(acc, out8, out_native);  // a small array: no second launch
+        if (single) write_result<T, MODE != kDot>(acc, out8, out_native);  // a small array (one workgroup in all): no second launch
         else partials[blockIdx.x] = acc;
     }
 }
@@ -411,12 +411,29 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     A *partials = reinterpret_cast<A *>(scratch);
     const int pol = MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
                                  : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0});
-    if (MODE == kFused && (pol & kStoreKeep))
-        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, MODE == kFused, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, a, b, out, n_vec, n, partials, out8,
-                           static_cast<T *>(out_native), pol);
-    else
-        hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, false, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, a, b, out, n_vec, n, partials, out8,
-                           static_cast<T *>(out_native), pol);
+    const bool keep = MODE == kFused && (pol & kStoreKeep);
+    // Very large operands go out as several launches, like the streaming kernels (contiguous.hip: a launch of hundreds of
+    // thousands of workgroups loses 3-6 % to its own length): pieces of whole tiles, each writing its workgroups' partials
+    // behind the previous piece's; ONE finishing launch adds them all.  The partials and their order are the same as for a
+    // single launch, so the bits do not depend on the piece size.
+    constexpr size_t kPieceVec = (size_t)1 << 24, kSplitAbove = (size_t)1 << 26;
+    const size_t piece_tiles = kPieceVec / tile;
+    for (size_t b0 = 0; b0 < blocks; b0 += (n_vec > kSplitAbove ? piece_tiles : blocks)) {
+        const size_t nb = n_vec > kSplitAbove ? (b0 + piece_tiles < blocks ? piece_tiles : blocks - b0) : blocks;
+        const bool last = b0 + nb == blocks;
+        const size_t v0 = b0 * tile;                                     // first vector of this piece
+        const size_t nv = last ? n_vec - v0 : nb * tile;                  // its vectors (the last piece: the partial tile too)
+        const size_t ne = last ? n - v0 * W : nv * W;                     // its elements (the last piece: the n % W tail too)
+        const T *pa = a + v0 * W, *pb = b ? b + v0 * W : b;
+        T *po = out ? out + v0 * W : out;
+        A *pp = partials ? partials + b0 : partials;
+        if (keep)
+            hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, MODE == kFused, BLOCK>), dim3((unsigned)nb), dim3(BLOCK), 0, s, pa, pb, po, nv, ne, pp, out8,
+                               static_cast<T *>(out_native), pol, blocks == 1 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, false, BLOCK>), dim3((unsigned)nb), dim3(BLOCK), 0, s, pa, pb, po, nv, ne, pp, out8,
+                               static_cast<T *>(out_native), pol, blocks == 1 ? 1 : 0);
+    }
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
     return launch_finish<T, MODE != kDot>(partials, blocks, out8, static_cast<T *>(out_native), s);

@@ -933,6 +933,14 @@ int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host) {
     return rc;
 }
 
+/* ----------------------------------------------------------- diagnostics */
+
+int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy) {
+    if (!policy) return fail(SMHIP_ERR_INVALID, "policy_probe: null");
+    *policy = stream_policy({{a, a ? a_bytes : 0}, {b, b ? b_bytes : 0}}, {out, out ? out_bytes : 0});
+    return SMHIP_OK;
+}
+
 /* ---------------------------------------------------------------- timing */
 
 int smhip_event_create(void **event) {

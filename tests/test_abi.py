@@ -4,6 +4,7 @@ sm::broadcast, and -- with no GPU in the container -- every compute entry
 point fails loudly instead of falling back to the CPU."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -108,3 +109,42 @@ def test_product_does_not_reference_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", sma.LIB_PATH], capture_output=True, text=True).stdout
     assert "smoracle" not in out and "smref" not in out
+
+
+def test_residency_rule_for_the_read_hint(lib):
+    """DESIGN.md section 3 'Cold operands': operands the library has not touched within the last 192 MiB of its own traffic are
+    read non-temporally at any size; operands that repeat, or were just written, are read through the caches (round 2's
+    rule for <= 256 MiB of reads); reads above the Infinity Cache are always non-temporal; results are kept (`sc1`) for
+    footprints of 40-256 MiB.  smhip_policy_probe does the host-side arithmetic on pointer values: no GPU involved."""
+    MiB = 1 << 20
+    NT, KEEP = 1, 2
+    base = 0x7000_0000_0000
+    a, out = base, base + 64 * MiB
+    assert lib.policy_probe(a, 64 * MiB, 0, 0, out, 64 * MiB) == NT | KEEP      # first call: cold operand, footprint 128 MiB
+    assert lib.policy_probe(a, 64 * MiB, 0, 0, out, 64 * MiB) == KEEP           # replayed: warm
+    assert lib.policy_probe(out, 64 * MiB, 0, 0, a, 64 * MiB) == KEEP           # a chain: reads what the previous launch wrote
+    # a view inside a warm array is warm; an array next to it is not
+    assert lib.policy_probe(a + 8 * MiB, 16 * MiB, 0, 0, base + 512 * MiB, 16 * MiB) & NT == 0
+    assert lib.policy_probe(base + 1024 * MiB, 16 * MiB, 0, 0, base + 1100 * MiB, 16 * MiB) & NT == NT
+    # other work passes (> 192 MiB of library traffic): the array has gone cold again
+    for k in range(4):
+        lib.policy_probe(base + (2048 + 200 * k) * MiB, 64 * MiB, 0, 0, base + (2048 + 200 * k + 100) * MiB, 64 * MiB)
+    assert lib.policy_probe(a, 64 * MiB, 0, 0, out, 64 * MiB) == NT | KEEP
+    # two read streams: the hint follows the majority of the read bytes
+    b = base + 4096 * MiB
+    assert lib.policy_probe(a, 64 * MiB, b, 64 * MiB, out, 64 * MiB) & NT == 0   # a warm (just touched), b cold: half -> plain
+    assert lib.policy_probe(a, 16 * MiB, base + 5000 * MiB, 64 * MiB, out, 16 * MiB) & NT == NT   # mostly cold
+    # above the Infinity Cache reads are non-temporal whatever their history; stores then too
+    big = base + 8192 * MiB
+    assert lib.policy_probe(big, 300 * MiB, 0, 0, big + 512 * MiB, 300 * MiB) == NT
+    assert lib.policy_probe(big, 300 * MiB, 0, 0, big + 512 * MiB, 300 * MiB) == NT
+    # small launches: below the keep-store floor, and operands under 2 MiB are not tracked (they live in the L2s)
+    assert lib.policy_probe(base + 9000 * MiB, 1 * MiB, 0, 0, base + 9100 * MiB, 1 * MiB) == 0
+
+
+def test_residency_rule_can_be_switched_off():
+    code = ("import simplemath_amd as s; l = s.load(); M = 1 << 20; "
+            "print(l.policy_probe(0x700000000000, 64 * M, 0, 0, 0x700010000000, 64 * M))")
+    env = dict(os.environ, SMHIP_RESIDENCY="off", PYTHONPATH=sma.ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "2", r.stdout + r.stderr   # round 2's size-only rule: plain reads, kept stores
