@@ -339,9 +339,14 @@ public:
             std::unique_ptr<SMArray> lhs_holder, rhs_holder;
             const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
             return hip::dot_device_c64(pa, pb, totalSize);
+        } else if constexpr (std::is_same_v<T, std::complex<float>>) {  // the generic template's instantiation, on resident arrays
+            hip::DeviceGuard on(common_device(*this, arr));
+            std::unique_ptr<SMArray> lhs_holder, rhs_holder;
+            const T *pa = dense_device(lhs_holder), *pb = arr.dense_device(rhs_holder);
+            return hip::dot_device_c32(pa, pb, totalSize);
         } else {
             static_assert(dependent_false<T>::value, "operator%: this element type has no gfx950 dot-product kernel (float, double, every "
-                                                     "8- to 64-bit integer type and std::complex<double> do)");
+                                                     "8- to 64-bit integer type, std::complex<float> and std::complex<double> do)");
         }
     }
 

@@ -31,12 +31,24 @@ inline std::complex<double> dot_device_c64(const std::complex<double> *a, const 
     check(smhip_dot_c64(a, b, n, out));
     return {out[0], out[1]};
 }
+// std::complex<float> (the generic template's instantiation): device pointers to n {re, im} float pairs
+inline std::complex<float> dot_device_c32(const std::complex<float> *a, const std::complex<float> *b, std::size_t n) {
+    float out[2] = {0, 0};
+    check(smhip_dot_c32(a, b, n, out));
+    return {out[0], out[1]};
+}
 }  // namespace sm::hip
 
 template <typename T>
 T dot_product(const T *a, const T *b, std::size_t n) {
     using namespace sm::hip;
-    if constexpr (std::is_same_v<T, std::complex<double>>) {
+    if constexpr (std::is_same_v<T, std::complex<float>>) {
+        if (n == 0) return T{};
+        DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T));
+        check(smhip_upload(da.get(), a, n * sizeof(T)));
+        check(smhip_upload(db.get(), b, n * sizeof(T)));
+        return dot_device_c32(da.template as<T>(), db.template as<T>(), n);
+    } else if constexpr (std::is_same_v<T, std::complex<double>>) {
         if (n == 0) return T{};
         DeviceBuffer da(n * sizeof(T)), db(n * sizeof(T));
         check(smhip_upload(da.get(), a, n * sizeof(T)));

@@ -171,6 +171,11 @@ int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host)
  * aligned); writes {re, im} of sum a[i]*b[i] (unconjugated, as the reference's scalar tail computes
  * it) to out2_host.  Synchronous. */
 int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host);
+/* The generic dot_product<T> (product.h:8-20) with T = std::complex<float>: a, b hold n {re, im} pairs of floats (8-byte
+ * aligned); {re, im} of sum a[i]*b[i] to out2_host.  Accumulated in fp64 (the reference adds in float, sequentially), rounded
+ * to float once.  Synchronous; the _async form leaves the fp64 {re, im} in device memory (out2_dev: 2 doubles). */
+int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host);
+int smhip_dot_c32_async(const void *a, const void *b, size_t n, double *out2_dev);
 /* Whole-array sum in fp64 (no reference counterpart; BASELINE config 5). Synchronous. */
 int smhip_sum(int dtype, const void *a, size_t n, double *out_host);
 /* Asynchronous forms leaving the fp64 result in device memory so a multi-GPU

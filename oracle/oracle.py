@@ -163,6 +163,16 @@ class Oracle(_Lib):
             raise ValueError(f"smo_dot_c64 rc={rc}")
         return complex(out[0], out[1])
 
+    def dot_c32(self, a, b, as_shipped=False):
+        """The generic dot_product<std::complex<float>>: the reference's bits (as_shipped) or exact products with fp64 sums."""
+        a, b = np.ascontiguousarray(a, dtype=np.complex64), np.ascontiguousarray(b, dtype=np.complex64)
+        out = np.zeros(2, dtype=np.float32)
+        self.lib.smo_dot_c32.restype = C.c_int
+        rc = self.lib.smo_dot_c32(_ptr(a), _ptr(b), C.c_size_t(a.size), _ptr(out), C.c_int(1 if as_shipped else 0))
+        if rc:
+            raise ValueError(f"smo_dot_c32 rc={rc}")
+        return np.complex64(complex(out[0], out[1]))
+
     def dot_int(self, a, b):
         """The generic dot_product<T> for int8/uint8/int16/uint16/uint32/uint64 arrays."""
         kind = INT_KINDS[a.dtype]
@@ -285,6 +295,15 @@ class Reference(_Lib):
         if rc:
             raise ValueError(f"ref_dot_c64 rc={rc}")
         return complex(out[0], out[1])
+
+    def dot_c32(self, a, b):
+        a, b = np.ascontiguousarray(a, dtype=np.complex64), np.ascontiguousarray(b, dtype=np.complex64)
+        out = np.zeros(2, dtype=np.float32)
+        self.lib.ref_dot_c32.restype = C.c_int
+        rc = self.lib.ref_dot_c32(_ptr(a), _ptr(b), C.c_size_t(a.size), _ptr(out))
+        if rc:
+            raise ValueError(f"ref_dot_c32 rc={rc}")
+        return np.complex64(complex(out[0], out[1]))
 
     def dot_int(self, a, b):
         out = np.zeros(1, dtype=a.dtype)

@@ -176,6 +176,15 @@ int ref_dot_c64(const double *a, const double *b, size_t n, double *out2) {
     return 0;
 }
 
+// the generic dot_product<T> (product.h:8-20) with T = std::complex<float>
+int ref_dot_c32(const float *a, const float *b, size_t n, float *out2) {
+    const std::complex<float> r = dot_product<std::complex<float>>(reinterpret_cast<const std::complex<float> *>(a),
+                                                                   reinterpret_cast<const std::complex<float> *>(b), n);
+    out2[0] = r.real();
+    out2[1] = r.imag();
+    return 0;
+}
+
 // the generic dot_product<T> (product.h:8-20); kind as libsmhip's extended element types: 4 int8, 5 uint8, 6 int16,
 // 7 uint16, 8 uint32, 9 uint64
 int ref_dot_int(int kind, const void *a, const void *b, size_t n, void *out) {

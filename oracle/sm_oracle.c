@@ -425,6 +425,37 @@ int smo_dot_c64(const double *a, const double *b, size_t n, double *out2, int av
     return 0;
 }
 
+/* The generic dot_product<T> (product.h:8-20) instantiated with std::complex<float>: `T sum = 0; sum += a[i] * b[i]`, n
+ * {re, im} pairs of floats.
+ *   as_shipped != 0: the reference's bits -- GCC (-O3 -mfma) expands the complex product inline and contracts it,
+ *     re = fmaf(ar, br, -(ai * bi)), im = fmaf(ar, bi, ai * br) (vmulss, vmulss, vfmsub231ss, vfmadd231ss in the compiled
+ *     reference), and the sums are sequential float additions.
+ *   as_shipped == 0: the numerically meaningful value the HIP kernel is compared with: exact products, compensated fp64 sums. */
+int smo_dot_c32(const float *a, const float *b, size_t n, float *out2, int as_shipped) {
+    if (as_shipped) {
+        float re = 0.0f, im = 0.0f;
+        for (size_t i = 0; i < n; ++i) {
+            const float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+            re += fmaf(ar, br, -(ai * bi));
+            im += fmaf(ar, bi, ai * br);
+        }
+        out2[0] = re;
+        out2[1] = im;
+        return 0;
+    }
+    ksum_t kr = {0, 0}, ki = {0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        const double ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+        ksum_add(&kr, ar * br);  /* products of two floats are exact in fp64 */
+        ksum_add(&kr, -(ai * bi));
+        ksum_add(&ki, ar * bi);
+        ksum_add(&ki, ai * br);
+    }
+    out2[0] = (float)(kr.s + kr.c);
+    out2[1] = (float)(ki.s + ki.c);
+    return 0;
+}
+
 /* The generic dot_product<T> (product.h:8-20) for the integer types the specialisations do not cover: `T sum = 0; sum +=
  * a[i] * b[i]` -- the product is formed in the promoted type and the sum is cut back to T every step, i.e. the exact sum
  * of products modulo 2^(8 sizeof T) (unsigned int is routed to the int32 kernel, :10-15: the same value).

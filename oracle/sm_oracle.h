@@ -86,6 +86,9 @@ int smo_dot(int dtype, const void *a, const void *b, size_t n, void *out,
  * scalar statement `result += a[i] * b[i]` for every element (the definition); != 0: as shipped, AVX body first (its
  * permutes count every product twice), scalar tail after. */
 int smo_dot_c64(const double *a, const double *b, size_t n, double *out2, int avx_body);
+/* The generic dot_product<T> (product.h:8-20) with T = std::complex<float>: n {re, im} float pairs; as_shipped != 0: the
+ * reference's bits (contracted products, sequential float sums); 0: exact products, compensated fp64 sums. */
+int smo_dot_c32(const float *a, const float *b, size_t n, float *out2, int as_shipped);
 /* The generic dot_product<T> (product.h:8-20) for int8/uint8/int16/uint16/uint32/uint64 (kind 4..9): the sum of products
  * modulo 2^(8 sizeof T); one T to `out`. */
 int smo_dot_int(int kind, const void *a, const void *b, size_t n, void *out);

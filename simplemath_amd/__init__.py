@@ -339,6 +339,11 @@ class Smhip:
         self._ck(self.c.smhip_dot_c64(C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
         return complex(out[0], out[1])
 
+    def dot_c32(self, a_ptr, b_ptr, n):
+        out = np.zeros(2, dtype=np.float32)
+        self._ck(self.c.smhip_dot_c32(C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return np.complex64(complex(out[0], out[1]))
+
     def sum(self, a: DeviceArray):
         out = C.c_double(0)
         self._ck(self.c.smhip_sum(C.c_int(DTYPES[a.dtype]), C.c_void_p(a.ptr), C.c_size_t(a.size), C.byref(out)))

@@ -140,6 +140,7 @@ int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first,
 int launch_sum(int dtype, const void *a, size_t n, double *out_dev, hipStream_t s);
 int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out_dev, void *out_native_dev, hipStream_t s);
 int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s);
+int launch_cdot32(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s);  // n {re, im} float pairs; fp64 {re, im} out
 int launch_contiguous_sum(int op, int dtype, const void *a, const void *b, void *out, size_t n, double *sum_dev,
                           hipStream_t s);
 

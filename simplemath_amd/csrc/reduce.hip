@@ -371,6 +371,51 @@ __global__ __launch_bounds__(kBlock) void cdot_kernel(const dbl2 *__restrict__ a
         partials[blocks + blockIdx.x] = m;
     }
 }
+// The generic dot_product<T> with T = std::complex<float> (product.h:8-20: `sum += a[i] * b[i]` in complex<float>): one 16-byte
+// vector = two {re, im} pairs; the products of two floats are exact in fp64, so each part is an fp64 fma chain -- more
+// accurate than the reference's sequential float sums, like the f32 dot.  Same one-shot shape and partial layout as cdot_kernel.
+__global__ __launch_bounds__(kBlock) void cdot32_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                        double *__restrict__ partials, size_t blocks, int nt) {
+    typedef VecTraits<float>::vec_t V;
+    const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
+    const size_t n_vec = n / 2;  // two complex numbers per vector
+    double re = 0.0, im = 0.0;
+    auto acc1 = [&](float ar, float ai, float br, float bi) {
+        re = __builtin_fma((double)ar, (double)br, re);
+        re = __builtin_fma(-(double)ai, (double)bi, re);
+        im = __builtin_fma((double)ar, (double)bi, im);
+        im = __builtin_fma((double)ai, (double)br, im);
+    };
+    auto acc = [&](V x, V y) { acc1(x[0], x[1], y[0], y[1]); acc1(x[2], x[3], y[2], y[3]); };
+    const size_t i0 = (size_t)blockIdx.x * (kBlock * 2) + threadIdx.x, i1 = i0 + kBlock;
+    if (i1 < n_vec) {
+        V x0, y0, x1, y1;
+        if (nt & kLoadNt) {
+            x0 = load_stream_as(float, av + i0, true), y0 = load_stream_as(float, bv + i0, true);
+            x1 = load_stream_as(float, av + i1, true), y1 = load_stream_as(float, bv + i1, true);
+        } else {
+            x0 = load_stream_as(float, av + i0, false), y0 = load_stream_as(float, bv + i0, false);
+            x1 = load_stream_as(float, av + i1, false), y1 = load_stream_as(float, bv + i1, false);
+        }
+        acc(x0, y0);
+        acc(x1, y1);
+    } else if (i0 < n_vec) {
+        acc(load_stream(av + i0), load_stream(bv + i0));
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && (n & 1)) acc1(a[2 * (n - 1)], a[2 * (n - 1) + 1], b[2 * (n - 1)], b[2 * (n - 1) + 1]);  // odd n: the last pair
+    __shared__ double lds[2][kBlock / 64];
+    re = wave_reduce(re);
+    im = wave_reduce(im);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == kWaveTotalLane) { lds[0][wave] = re; lds[1][wave] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0, m = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) { r += lds[0][w]; m += lds[1][w]; }
+        partials[blockIdx.x] = r;
+        partials[blocks + blockIdx.x] = m;
+    }
+}
 // Queues finish_kernel over `blocks` partials (blocks >= 1); `partials` has room for the group totals behind them
 // (blocks / kGroupTarget + 2 more accumulators are enough).
 template <typename T, bool AS_DOUBLE>
@@ -508,9 +553,22 @@ int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStr
     ScratchLease lease;
     if (int rc = lease.take(2 * span, &scratch)) return rc;
     hipLaunchKernelGGL(cdot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const dbl2 *>(a), static_cast<const dbl2 *>(b), n, scratch, span,
-                       stream_reads(2 * n * sizeof(dbl2)));
+                       stream_policy({{a, n * sizeof(dbl2)}, {b, n * sizeof(dbl2)}}, {nullptr, 0}));
     SMHIP_LAUNCH_CHECK("cdot");
     // one finishing launch for both sums (plane 0: real -> out2_dev[0], plane 1: imaginary -> out2_dev[1])
+    return launch_finish<double, true>(scratch, blocks, out2_dev, static_cast<double *>(nullptr), s, 2, span);
+}
+
+int launch_cdot32(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s) {
+    const size_t blocks = (n / 2) / (kBlock * 2) + 1;
+    if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "complex dot too large (%zu workgroups)", blocks);
+    const size_t span = blocks + blocks / kGroupTarget + 2;
+    double *scratch;
+    ScratchLease lease;
+    if (int rc = lease.take(2 * span, &scratch)) return rc;
+    hipLaunchKernelGGL(cdot32_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, static_cast<const float *>(a), static_cast<const float *>(b), n, scratch, span,
+                       stream_policy({{a, n * 8}, {b, n * 8}}, {nullptr, 0}));
+    SMHIP_LAUNCH_CHECK("cdot32");
     return launch_finish<double, true>(scratch, blocks, out2_dev, static_cast<double *>(nullptr), s, 2, span);
 }
 

@@ -933,6 +933,26 @@ int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host) {
     return rc;
 }
 
+int smhip_dot_c32_async(const void *a, const void *b, size_t n, double *out2_dev) {
+    if (!out2_dev || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot_c32: null buffer");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 7u) return fail(SMHIP_ERR_INVALID, "dot_c32: operands must be 8-byte aligned");
+    SMHIP_ACQUIRE(s);
+    return launch_cdot32(a, b, n, out2_dev, s);
+}
+
+int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host) {
+    if (!out2_host) return fail(SMHIP_ERR_INVALID, "dot_c32: null buffer");
+    void *d = nullptr;
+    if (int rc = smhip_alloc(&d, 16)) return rc;
+    double both[2] = {0, 0};
+    int rc = smhip_dot_c32_async(a, b, n, static_cast<double *>(d));
+    if (!rc) rc = smhip_download(both, d, 16);
+    smhip_free(d);
+    out2_host[0] = (float)both[0];
+    out2_host[1] = (float)both[1];
+    return rc;
+}
+
 /* ----------------------------------------------------------- diagnostics */
 
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy) {

@@ -96,6 +96,26 @@ int main() {
         sm::SMArray<C> x = {C(1.5, -2.0)}, y = {C(0.25, 4.0)};
         CHECK((x % y) == C(1.5 * 0.25 - (-2.0) * 4.0, 1.5 * 4.0 + (-2.0) * 0.25));
     }
+    {  // std::complex<float>: the generic template's instantiation, resident like the double form
+        typedef std::complex<float> CF;
+        const std::size_t R = 17, K = 300, n = R * K;
+        CF *pa = new CF[n], *pb = new CF[n];
+        auto unit = [] { return (float)((double)(rnd() >> 11) / 9007199254740992.0 * 2 - 1); };
+        for (std::size_t i = 0; i < n; ++i) { pa[i] = CF(unit(), unit()); pb[i] = CF(unit(), unit()); }
+        std::vector<CF> ha(pa, pa + n), hb(pb, pb + n);
+        sm::SMArray<CF> a(pa, {R, K}), b(pb, {R, K});
+        std::complex<double> want(0, 0);
+        double scale = 0;
+        for (std::size_t i = 0; i < n; ++i) {
+            want += std::complex<double>(ha[i]) * std::complex<double>(hb[i]);
+            scale += std::abs(std::complex<double>(ha[i])) * std::abs(std::complex<double>(hb[i]));
+        }
+        const CF got = a % b;
+        CHECK(std::abs(std::complex<double>(got) - want) <= 2.4e-7 * (std::abs(want) + 1e-3 * scale));
+        CHECK((a.transpose() % b.transpose()) == got || std::abs(std::complex<double>(a.transpose() % b.transpose()) - want) <= 2.4e-7 * (std::abs(want) + 1e-3 * scale));
+        sm::SMArray<CF> x = {CF(1.5f, -2.0f)}, y = {CF(0.25f, 4.0f)};
+        CHECK((x % y) == CF(1.5f * 0.25f + 2.0f * 4.0f, 1.5f * 4.0f - 2.0f * 0.25f));
+    }
     std::printf("test_dot_types: %d checks, %d failures\n", g_checks, g_failures);
     return g_failures ? 1 : 0;
 }

@@ -212,6 +212,20 @@ def cdot_inputs(c):
     return (ar + 1j * ai).astype(np.complex128), (br + 1j * bi).astype(np.complex128)
 
 
+CDOT32_N = [1, 2, 5, 100, 4099]
+
+
+def cdot32_cases():
+    return [{"id": f"cdot32-{n}", "n": n, "seed": 18000 + i} for i, n in enumerate(CDOT32_N)]
+
+
+def cdot32_inputs(c):
+    import numpy as np
+    ar, ai = gen.gen(np.float32, c["n"], c["seed"], "uniform"), gen.gen(np.float32, c["n"], c["seed"] + 1, "uniform")
+    br, bi = gen.gen(np.float32, c["n"], c["seed"] + 2, "uniform"), gen.gen(np.float32, c["n"], c["seed"] + 3, "uniform")
+    return (ar + 1j * ai).astype(np.complex64), (br + 1j * bi).astype(np.complex64)
+
+
 def gdot_cases():
     out, seed = [], 17000
     for dt in GDOT_DTYPES:

@@ -59,6 +59,10 @@ def make_dot_extra(ref):
         a, b = cases.cdot_inputs(c)
         r = ref.dot_c64(a, b)
         _put(st, c["id"], np.array([r.real, r.imag], dtype=np.float64), (a.view(np.float64), b.view(np.float64)))
+    for c in cases.cdot32_cases():
+        a, b = cases.cdot32_inputs(c)
+        r = ref.dot_c32(a, b)
+        _put(st, c["id"], np.array([r.real, r.imag], dtype=np.float32), (a.view(np.float32), b.view(np.float32)))
     for c in cases.gdot_cases():
         a, b = cases.gdot_inputs(c)
         _put(st, c["id"], np.array([ref.dot_int(a, b)], dtype=a.dtype), (a, b))

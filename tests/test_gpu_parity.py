@@ -488,6 +488,27 @@ def test_complex_dot_against_the_oracle_and_the_recorded_reference(smhip, oracle
             assert abs(recorded - (2 * head + tail)) <= 16 * n * 2.0 ** -53 * scale, n  # the AVX body's doubled sums, as data
 
 
+def test_complex_float_dot(smhip, oracle):
+    """The generic dot_product<T> with T = std::complex<float> (product.h:8-20).  The reference adds in float, sequentially;
+    the kernel accumulates in fp64 and rounds once: it must sit within float rounding of the exact value and be no further
+    from it than the reference's own recorded answer is (plus one rounding)."""
+    st = util.load_npz("dot_extra.npz")
+    rng = np.random.default_rng(17)
+    extra = [(n, (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64),
+              (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)) for n in (3, 1023, 1024, 1025, 1024 * 512 * 2 + 7)]
+    todo = [(c["n"], *cases.cdot32_inputs(c), complex(*st[f"{c['id']}/out"])) for c in cases.cdot32_cases()] + [(n, a, b, None) for n, a, b in extra]
+    for n, a, b, recorded in todo:
+        da, db = smhip.to_device(a.view(np.float32)), smhip.to_device(b.view(np.float32))
+        got = complex(smhip.dot_c32(da.ptr, db.ptr, n))
+        exact = complex(np.sum(a.astype(np.complex128) * b.astype(np.complex128)))
+        scale = float(np.sum(np.abs(a.astype(np.complex128)) * np.abs(b.astype(np.complex128))))
+        ulp = float(np.spacing(np.float32(max(abs(exact.real), abs(exact.imag), 1e-30))))
+        assert abs(got - exact) <= 2 * ulp + 4 * n * 2.0 ** -53 * scale, n          # fp64 accumulation, one rounding to float per part
+        assert complex(oracle.dot_c32(a, b)) == pytest.approx(got, abs=2 * ulp), n   # the oracle's exact form
+        if recorded is not None:
+            assert abs(got - exact) <= abs(recorded - exact) + 2 * ulp, n            # never worse than the reference's float sums
+
+
 def test_generic_integer_dot(smhip, oracle):
     """The generic dot_product<T> (product.h:8-20) for int8 / uint8 / int16 / uint16 / uint32 / uint64: bit-exact against
     the reference-recorded fixtures and the oracle -- the sum of products modulo 2^(8 sizeof T), in any order."""
