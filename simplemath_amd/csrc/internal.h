@@ -18,6 +18,10 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // stream its work goes to.  SMHIP_OK or SMHIP_ERR_NO_DEVICE / SMHIP_ERR_HIP.
 int acquire(hipStream_t *stream);
 
+// A recycled (or new) timing-disabled event of device `dev` (nullptr if none can be made) / its return to the pool.
+hipEvent_t pool_event_take(int dev);
+void pool_event_give(int dev, hipEvent_t e);
+
 // Compute units of the calling thread's current device (256 on MI355X); valid after acquire().
 int compute_units();
 

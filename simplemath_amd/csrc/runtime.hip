@@ -277,6 +277,9 @@ int acquire(hipStream_t *stream) {
     return SMHIP_OK;
 }
 
+hipEvent_t pool_event_take(int dev) { return take_event(dev); }
+void pool_event_give(int dev, hipEvent_t e) { give_event(dev, e); }
+
 int compute_units() {
     const int d = tls.device < 0 ? 0 : tls.device;
     return g_cus[d] > 0 ? g_cus[d] : 256;

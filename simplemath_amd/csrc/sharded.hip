@@ -418,9 +418,10 @@ int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, 
     {
         ThreadDeviceScope scope(src_device);
         if (int rc = acquire(&s_src)) return rc;
-        SMHIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        ready = pool_event_take(src_device);
+        if (!ready) return fail(SMHIP_ERR_HIP, "copy_peer: no event for device %d", src_device);
         const hipError_t e = hipEventRecord(ready, s_src);  // everything queued on the source's stream so far
-        if (e != hipSuccess) { (void)hipEventDestroy(ready); return fail(SMHIP_ERR_HIP, "copy_peer: hipEventRecord: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { pool_event_give(src_device, ready); return fail(SMHIP_ERR_HIP, "copy_peer: hipEventRecord: %s", hipGetErrorString(e)); }
     }
     int rc = SMHIP_OK;
     {
@@ -429,7 +430,7 @@ int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, 
         hipError_t e = hipSuccess;
         if (!rc) e = hipStreamWaitEvent(s_dst, ready, 0);
         if (!rc && e == hipSuccess) e = hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, s_dst);
-        if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (!rc && e == hipSuccess && !(done = pool_event_take(dst_device))) e = hipErrorOutOfMemory;
         if (!rc && e == hipSuccess) e = hipEventRecord(done, s_dst);
         if (!rc && e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "copy_peer %d -> %d: %s", src_device, dst_device, hipGetErrorString(e));
     }
@@ -439,8 +440,8 @@ int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, 
         const hipError_t e = hipStreamWaitEvent(s_src, done, 0);
         if (e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "copy_peer: hipStreamWaitEvent: %s", hipGetErrorString(e));
     }
-    (void)hipEventDestroy(ready);  // destruction is deferred by the runtime until the recorded work has passed
-    if (done) (void)hipEventDestroy(done);
+    pool_event_give(src_device, ready);  // recycled events: a later record simply supersedes this one (the waits are already queued)
+    if (done) pool_event_give(dst_device, done);
     return rc;
 }
 
