@@ -317,16 +317,8 @@ template <int KIND> struct HeavyTile<double, KIND> { static constexpr int value 
 // launch's workgroups are dealt to the eight XCDs in order and each XCD works through its share at its own pace; over
 // hundreds of thousands of workgroups their fronts drift apart and the DRAM pages they share stop being open for each
 // other; a kernel boundary lines them up again.  So: pieces of 2^24 vectors (256 MiB per operand) once an operand
-// exceeds 1 GiB.  SMHIP_PIECE_LOG2VEC=<k> moves the piece size (0: never split).
-inline size_t piece_vectors() {
-    static const size_t v = [] {
-        const char *e = getenv("SMHIP_PIECE_LOG2VEC");
-        const int k = e ? atoi(e) : 24;
-        return k <= 0 ? (size_t)0 : (size_t)1 << (k < 16 ? 16 : k);
-    }();
-    return v;
-}
-constexpr size_t kSplitAboveVectors = (size_t)1 << 26;  // 1 GiB per operand
+// exceeds 1 GiB (internal.h: piece_vectors / split_above_vectors).  SMHIP_PIECE_LOG2VEC=<k> moves the piece size (0: never
+// split) and, for tests, the size from which operands are split along with it.
 
 // Launches the heavy form of `Op` (KIND 0: a op b, 1: a op s, 2: s op a).
 template <typename T, typename Op, int KIND>
@@ -340,7 +332,7 @@ template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
     const int nt = KIND == 0 ? stream_policy({{pa, n_vec * 16}, {pb, n_vec * 16}}, {po, n_vec * 16}) : stream_policy({{pa, n_vec * 16}}, {po, n_vec * 16});
-    if (n_vec > kSplitAboveVectors && piece_vectors()) {  // very large: several launches (piece_vectors)
+    if (piece_vectors() && n_vec > split_above_vectors()) {  // very large: several launches (piece_vectors)
         const size_t piece = piece_vectors();
         for (size_t v0 = 0;; v0 += piece) {
             const bool last = v0 + piece >= n_vec;
@@ -418,7 +410,7 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     if constexpr (IsHeavy<Op>::value) {
         if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
-    } else if (n_vec > kSplitAboveVectors && piece_vectors()) {
+    } else if (piece_vectors() && n_vec > split_above_vectors()) {
         const int pol = stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)});  // above the cache: nt both ways
         const size_t piece = piece_vectors();
         for (size_t v0 = 0; v0 < n_vec || (v0 == n_vec && tail); v0 += piece) {
@@ -489,7 +481,7 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
         const int pol = stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)});
-        if (n_vec > kSplitAboveVectors && piece_vectors()) {  // very large: several launches (see piece_vectors)
+        if (piece_vectors() && n_vec > split_above_vectors()) {  // very large: several launches (see piece_vectors)
             const size_t piece = piece_vectors();
             for (size_t v0 = 0;; v0 += piece) {
                 const bool last = v0 + piece >= n_vec;

@@ -102,6 +102,13 @@ int stream_policy(std::initializer_list<Span> reads, Span write);
 // run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
 int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
 
+// Very large operands go out as several launches (contiguous.hip explains why): pieces of piece_vectors() 16-byte vectors
+// (2^24 = 256 MiB per operand; 0: never) once an operand has more than split_above_vectors() of them (2^26 = 1 GiB).
+// SMHIP_PIECE_LOG2VEC=<k> sets the piece size -- and, so that the piece loops can be exercised at test sizes, the split
+// threshold to the same value.
+size_t piece_vectors();
+size_t split_above_vectors();
+
 inline size_t dtype_size(int dtype) {
     switch (dtype) {
         case SMHIP_F64: case SMHIP_I64: case SMHIP_U64: return 8;

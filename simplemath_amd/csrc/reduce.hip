@@ -461,10 +461,10 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     // thousands of workgroups loses 3-6 % to its own length): pieces of whole tiles, each writing its workgroups' partials
     // behind the previous piece's; ONE finishing launch adds them all.  The partials and their order are the same as for a
     // single launch, so the bits do not depend on the piece size.
-    constexpr size_t kPieceVec = (size_t)1 << 24, kSplitAbove = (size_t)1 << 26;
-    const size_t piece_tiles = kPieceVec / tile;
-    for (size_t b0 = 0; b0 < blocks; b0 += (n_vec > kSplitAbove ? piece_tiles : blocks)) {
-        const size_t nb = n_vec > kSplitAbove ? (b0 + piece_tiles < blocks ? piece_tiles : blocks - b0) : blocks;
+    const bool split = piece_vectors() && n_vec > split_above_vectors();
+    const size_t piece_tiles = split ? (piece_vectors() / tile ? piece_vectors() / tile : 1) : blocks;
+    for (size_t b0 = 0; b0 < blocks; b0 += piece_tiles) {
+        const size_t nb = b0 + piece_tiles < blocks ? piece_tiles : blocks - b0;
         const bool last = b0 + nb == blocks;
         const size_t v0 = b0 * tile;                                     // first vector of this piece
         const size_t nv = last ? n_vec - v0 : nb * tile;                  // its vectors (the last piece: the partial tile too)

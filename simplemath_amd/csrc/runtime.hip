@@ -277,6 +277,23 @@ int acquire(hipStream_t *stream) {
     return SMHIP_OK;
 }
 
+namespace {
+struct PieceRule { size_t piece, above; };
+const PieceRule &piece_rule() {
+    static const PieceRule r = [] {
+        const char *e = getenv("SMHIP_PIECE_LOG2VEC");
+        if (!e) return PieceRule{(size_t)1 << 24, (size_t)1 << 26};
+        const int k = atoi(e);
+        if (k <= 0) return PieceRule{0, ~(size_t)0};
+        const size_t p = (size_t)1 << (k < 12 ? 12 : k);
+        return PieceRule{p, p};
+    }();
+    return r;
+}
+}  // namespace
+size_t piece_vectors() { return piece_rule().piece; }
+size_t split_above_vectors() { return piece_rule().above; }
+
 hipEvent_t pool_event_take(int dev) { return take_event(dev); }
 void pool_event_give(int dev, hipEvent_t e) { give_event(dev, e); }
 

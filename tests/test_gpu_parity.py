@@ -916,6 +916,27 @@ def test_unsharded_config5_size_2p31(smhip, oracle):
     smhip.pool_trim()
 
 
+def test_results_do_not_depend_on_the_piece_size(tmp_path):
+    """Very large operands go out as several launches (DESIGN.md section 3 'Very large arrays'): contiguous, scalar, pow, user-Op
+    and reduction forms.  With SMHIP_PIECE_LOG2VEC=14 the same piece loops run at test sizes (3-5 pieces, whole and ragged
+    last pieces, odd tails); every result -- the reductions' bits included -- must equal the single-launch result."""
+    import subprocess, sys, os
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "piece_probe.py")
+    files = {}
+    for name, env in (("whole", {}), ("pieces", {"SMHIP_PIECE_LOG2VEC": "14"})):
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, probe, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "piece_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        files[name] = np.load(out)
+    assert sorted(files["whole"].files) == sorted(files["pieces"].files) and len(files["whole"].files) >= 60
+    for k in files["whole"].files:
+        util.assert_same_bits(files["pieces"][k], files["whole"][k], k)
+    # and the single-launch results are the right ones (the rest of this file pins them; one spot check here)
+    n = (1 << 14) * 4 * 3 + 5
+    w = files["whole"]
+    assert np.array_equal(w[f"n{n}/fused_out"], w[f"n{n}/add"]) and abs(w[f"n{n}/fused_sum"][0] - w[f"n{n}/add"].astype(np.float64).sum()) < 1e-6 * n
+
+
 def test_broadcast_forms_past_2p31(smhip):
     """Broadcast problems of more than 2^31 elements: the library cuts them along the outermost dimension into
     launches of < 2^31 (row kernel, LDS-tile kernel for a transposed operand, gather kernel for a stride-2 view,
