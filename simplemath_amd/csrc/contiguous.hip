@@ -367,18 +367,9 @@ void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, 
 #define SMHIP_FLAT_ROWS_U 2
 #endif
 // a (rows x cols, dense) op one row / one column of b (KIND 3 / 4 of flat_tile_kernel), every built-in Op
-template <typename T, typename Op>
-int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
-    constexpr int W = VecTraits<T>::width;
-    // vectors per lane: the array form's tile for the heavy Ops (per-lane exponents); two for the others, like the row
-    // kernel's two rows per lane
-    constexpr int U = IsHeavy<Op>::value ? HeavyTile<T, 0>::value : SMHIP_FLAT_ROWS_U;
-    const size_t n_vec = rows * (cols / W);
+template <typename T, typename Op, int U>
+void launch_rows(const T *pa, const T *pb, T *po, size_t n_vec, bool b_is_row, int nt, FastDiv cv, hipStream_t s) {
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;
-    const T *pa = static_cast<const T *>(a), *pb = static_cast<const T *>(b);
-    T *po = static_cast<T *>(out);
-    const int nt = stream_policy({{pa, rows * cols * sizeof(T)}}, {po, rows * cols * sizeof(T)});
-    const FastDiv cv((uint32_t)(cols / W));
     const dim3 grid((unsigned)tiles), block(kTileBlock);
     if (b_is_row) {
         if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
@@ -387,6 +378,26 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
         if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 4, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
         else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 4, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
     }
+}
+template <typename T, typename Op>
+int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t cols, bool b_is_row, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    // vectors per lane: the array form's tile for the heavy Ops (per-lane exponents); two for the others, like the row
+    // kernel's two rows per lane
+    constexpr int U = IsHeavy<Op>::value ? HeavyTile<T, 0>::value : SMHIP_FLAT_ROWS_U;
+    const size_t n_vec = rows * (cols / W);
+    const T *pa = static_cast<const T *>(a), *pb = static_cast<const T *>(b);
+    T *po = static_cast<T *>(out);
+    const size_t bytes = rows * cols * sizeof(T);
+    const int nt = stream_policy({{pa, bytes}}, {po, bytes});
+    const FastDiv cv((uint32_t)(cols / W));
+    // A dense operand that fits the Infinity Cache and is read with `nt` all the same is COLD (internal.h: the residency rule).
+    // Cold, ONE vector per lane is the faster shape for the light Ops -- config 3's multiply 23.1 -> 22.5 us (72.6 -> 74.5 %),
+    // twice its size 44.2 -> 42.5 us (75.9 -> 79.0 %) -- while replayed and chained operands keep two (19.27 against 19.41 us;
+    // tools/cold_rates.py, profiles/r03_rows_u.txt): twice the workgroups retire, and free their slots, half a tile earlier.
+    const bool cold = (nt & kLoadNt) && bytes <= kInfinityCacheBytes;
+    if (!IsHeavy<Op>::value && U > 1 && cold) launch_rows<T, Op, 1>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
+    else launch_rows<T, Op, U>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
     SMHIP_LAUNCH_CHECK("heavy rows");
     return SMHIP_OK;
 }
