@@ -21,8 +21,10 @@ N GPUs   each GPU owns one outer-dimension shard of 2^28 elements of the N * 2^2
          by libsmhip itself: smhip_allreduce_sum_async / smhip_sharded_contiguous_sum) is timed after the headline
          region and reported under "c5" (operands: config 5's seeds 6/7 in [0,1)).
 roofline dominant kernel = contiguous_vec_kernel<float, AddOp<float>, 1024, false>; algorithmic bytes 12 B/elem (2 reads +
-         1 write) * 2^28 = 3 221 225 472 B per launch; duration = HIP events (smhip_event_*, recorded on the stream the
-         kernel runs on) over the timed region / launches; peak = 8000 GB/s (MI355X HBM3E spec).  `traffic` is NOT
+         1 write).  A step is ONE smhip_contiguous call over 2^28 elements, which the library issues as TWO launches of that
+         kernel over 2^27 elements each (operands above 512 MiB go out in pieces: 1 % faster): 12 B * 2^27 =
+         1 610 612 736 B per launch, `launches_per_step` 2; duration = HIP events (smhip_event_*, recorded on the stream the
+         kernel runs on) over the timed region / (steps * launches_per_step); peak = 8000 GB/s (MI355X HBM3E spec).  `traffic` is NOT
          measured by this run: it is the HBM byte count of the last committed rocprofv3 --pmc passes
          (tools/pmc_traffic.sh -> profiles/traffic_latest.json) and `traffic_source` says so; null if that file is absent.
 configs  the N = 1 line also carries BASELINE configs 3, 4 and 5's per-GPU step under "configs": {"c3", "c4", "c5_shard"}, each
@@ -434,10 +436,17 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound, setting="replay", log
             else:
                 steps.append(bound(lib.c.smhip_contiguous_sum_async, C.c_int(sma.OP_ADD), C.c_int(sma.F32), C.c_void_p(a.ptr),
                                    C.c_void_p(b.ptr), C.c_void_p(c.ptr), C.c_size_t(n), C.c_void_p(sum_ptr)))
+        pieces = lib.launch_pieces(4 * n)  # operands above 512 MiB go out as several launches (very large arrays)
         kernel = ("contiguous_vec_kernel<float, AddOp<float>, 1024, false>" if wl == "add"
                   else "reduce_kernel<float, AddOp<float>, kFused> (+ finish_kernel)")
         text = f"1D float32 {'add' if wl == 'add' else 'fused add+sum'}, N=2^{log2n} per GPU, contiguous, HBM-resident"
-        return steps, n, 12 * n, kernel, text, keep, {"log2n": log2n, "n": n, "sum_ptr": sum_ptr}
+        extras = {"log2n": log2n, "n": n, "sum_ptr": sum_ptr}
+        if wl == "add":
+            extras["launches_per_step"] = pieces
+        else:  # priced per STEP: its launches are two different kernels
+            extras["main_launches_per_step"] = pieces
+            extras["step_launches"] = f"{pieces} x reduce_kernel + 1 x finish_kernel; kernel_ms is their sum per step"
+        return steps, n, 12 * n, kernel, text, keep, extras
     if wl == "bcast_mul":
         rows = cols = 4096
         r = lib.uniform_f32(cols, 4, -1.0, 1.0)
@@ -518,6 +527,9 @@ def config_legs(lib, sma, np, C, args, bound):
             ms, _ = time_steps(lib, steps, n_steps, 20)
             if leg is None:
                 leg = {"workload": workload, "kernel": kernel, "algorithmic_bytes_per_launch": alg_bytes, "elements": units}
+                if "step_launches" in info:
+                    leg["step_launches"] = info["step_launches"]
+                    leg["algorithmic_bytes_per_step"] = leg.pop("algorithmic_bytes_per_launch")
             achieved = alg_bytes / (ms * 1e-3) / 1e9
             leg[setting] = {"bound": bound_reads(wl, setting, alg_bytes), "kernel_ms": ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "value": units / (ms * 1e-3) / 1e9, "value_unit": "Gelem/s",
@@ -576,9 +588,22 @@ def one_rank_rccl_leg(lib, sma, np, C, log2n=28):
         lib.set_devices(0)
 
 
-def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra, setting="replay"):
+def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra, setting="replay",
+         launches_per_step=1, step_launches=None, main_launches_per_step=1):
+    """kern_ms: HIP-event time of the timed region / steps.  A step of the headline is ONE smhip_contiguous call that the library
+    issues as `launches_per_step` launches of the same kernel (two for 1 GiB operands): the roofline is priced per launch --
+    algorithmic bytes per launch / average launch duration -- which is the same ratio, and is what a rocprofv3 kernel summary
+    of the same command shows (its average duration = kernel_ms, its call count = launches_per_step x steps)."""
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    step_kern_ms = kern_ms
+    alg_bytes_step = alg_bytes
+    if launches_per_step > 1:
+        kern_ms = kern_ms / launches_per_step
+        alg_bytes = alg_bytes // launches_per_step
+        singles = [x / launches_per_step for x in singles]
     traffic, traffic_source = traffic_from_profiles(wl)
+    if traffic is not None and step_launches:
+        traffic *= main_launches_per_step  # the PMC passes count per launch of the main kernel; this workload is priced per step
     line = {
         "metric": BASELINE_METRIC if wl == "add" else f"Gelem/s, {WORKLOADS[wl][1]}",
         "value": value, "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -591,10 +616,13 @@ def emit(args, wl, world, mode, value, ms_per_step, units, alg_bytes, kern_ms, s
         "roofline": {"bound": bound_reads(wl, setting, alg_bytes), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                     "launches_per_step": launches_per_step, "algorithmic_bytes_per_step": alg_bytes_step, "step_kernel_ms": step_kern_ms,
                      "kernel_ms_median_of_20_single_launches": singles[len(singles) // 2], "kernel_ms_min": singles[0],
                      "per_gpu": "slowest GPU's average launch" if world > 1 else "the GPU's average launch",
                      "peak_source": "MI355X HBM3E 8.0 TB/s spec (MI355X_MICROARCH.md); the guide's measured float4 copy is 6.29 TB/s"},
     }
+    if step_launches:
+        line["roofline"]["step_launches"] = step_launches
     if c5:
         line["c5"] = c5
     line.update(extra)
@@ -718,7 +746,8 @@ def run_rank(args):
         mine = torch.zeros(world, 2, dtype=torch.float64, device=coll_dev)  # every rank's own figures, for "per_gpu"
         mine[rank, 0], mine[rank, 1] = my_kern_ms, float(local_rank)
         dist.all_reduce(mine)
-        per_gpu = [{"rank": r, "device": int(mine[r, 1]), "kernel_ms": float(mine[r, 0]),
+        lps = info.get("launches_per_step", 1)  # kernel_ms per LAUNCH, like roofline.kernel_ms
+        per_gpu = [{"rank": r, "device": int(mine[r, 1]), "kernel_ms": float(mine[r, 0]) / lps,
                     "frac": alg_bytes / (float(mine[r, 0]) * 1e-3) / 1e9 / HBM_PEAK_GBS} for r in range(world)]
 
     # per-launch distribution (SURVEY 8d asks for median and min): 20 launches timed one by one, after the
@@ -820,7 +849,8 @@ def run_rank(args):
                     small()
                 lib.synchronize()
                 cb["config1_million_check"]["gpu_ns"] = (time.perf_counter() - tq) / 2000 * 1e9
-        emit(args, wl, world, "ranks", value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra, args.setting)
+        emit(args, wl, world, "ranks", value, ms_per_step, units, alg_bytes, kern_ms, singles, kernel, workload, c5, extra, args.setting,
+             info.get("launches_per_step", 1), info.get("step_launches"), info.get("main_launches_per_step", 1))
 
     if use_lib_comm:
         lib.synchronize()
@@ -943,14 +973,15 @@ def run_single(args):
     info = [lib.group_info(g) for g in range(G)]
     extra = {"rccl": {"nranks": info[0][0], "version": lib.rccl_version(), "communicators": [{"rank": r, "device": d, "nranks": nr} for nr, r, d in info],
                       "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion through libsmhip (smhip_group_info, smhip_rccl_version)"},
-             "per_gpu": [{"rank": g, "device": g, "kernel_ms": each_ms[g], "frac": 12 * n / (each_ms[g] * 1e-3) / 1e9 / HBM_PEAK_GBS} for g in range(G)]}
+             "per_gpu": [{"rank": g, "device": g, "kernel_ms": each_ms[g] / lib.launch_pieces(4 * n),
+                          "frac": 12 * n / (each_ms[g] * 1e-3) / 1e9 / HBM_PEAK_GBS} for g in range(G)]}
     if G == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline("add", args.cpu_log2n)
         if cb is not None:
             extra["cpu_baseline"] = cb
     emit(args, "add", G, "single", G * n / (wall / args.steps) / 1e9, wall / args.steps * 1e3, n, 12 * n, kern_ms, singles,
          "contiguous_vec_kernel<float, AddOp<float>, 1024, false>",
-         f"1D float32 add, N=2^{log2n} per GPU, contiguous, HBM-resident", c5, extra)
+         f"1D float32 add, N=2^{log2n} per GPU, contiguous, HBM-resident", c5, extra, "replay", lib.launch_pieces(4 * n))
     lib.set_devices(0)
     return 0
 

@@ -481,6 +481,12 @@ class Smhip:
                                            C.c_size_t(out_bytes), C.byref(pol)))
         return pol.value
 
+    def launch_pieces(self, bytes_per_operand):
+        """Kernel launches a dense streaming operator over operands of this size goes out as."""
+        k = C.c_int(0)
+        self._ck(self.c.smhip_launch_pieces(C.c_size_t(bytes_per_operand), C.byref(k)))
+        return k.value
+
     # -- timing -----------------------------------------------------------------
     def event(self):
         e = C.c_void_p(0)

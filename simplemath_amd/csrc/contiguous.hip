@@ -317,8 +317,8 @@ template <int KIND> struct HeavyTile<double, KIND> { static constexpr int value 
 // launch's workgroups are dealt to the eight XCDs in order and each XCD works through its share at its own pace; over
 // hundreds of thousands of workgroups their fronts drift apart and the DRAM pages they share stop being open for each
 // other; a kernel boundary lines them up again.  So: pieces of 2^24 vectors (256 MiB per operand) once an operand
-// exceeds 1 GiB (internal.h: piece_vectors / split_above_vectors).  SMHIP_PIECE_LOG2VEC=<k> moves the piece size (0: never
-// split) and, for tests, the size from which operands are split along with it.
+// exceeds 1 GiB -- and, found later, even the headline's 1 GiB operands gain 1 % from going out as TWO launches
+// (internal.h: piece_for has the rule and its numbers).
 
 // Launches the heavy form of `Op` (KIND 0: a op b, 1: a op s, 2: s op a).
 template <typename T, typename Op, int KIND>
@@ -332,8 +332,7 @@ template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
     const int nt = KIND == 0 ? stream_policy({{pa, n_vec * 16}, {pb, n_vec * 16}}, {po, n_vec * 16}) : stream_policy({{pa, n_vec * 16}}, {po, n_vec * 16});
-    if (piece_vectors() && n_vec > split_above_vectors()) {  // very large: several launches (piece_vectors)
-        const size_t piece = piece_vectors();
+    if (const size_t piece = piece_for(n_vec)) {  // large: several launches (internal.h: piece_for)
         for (size_t v0 = 0;; v0 += piece) {
             const bool last = v0 + piece >= n_vec;
             launch_heavy_piece<T, Op, KIND>(pa + v0 * W, KIND == 0 ? pb + v0 * W : pb, value, po + v0 * W, last ? n_vec - v0 : piece, last ? tail : 0, nt, s);
@@ -421,9 +420,8 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     if constexpr (IsHeavy<Op>::value) {
         if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
-    } else if (piece_vectors() && n_vec > split_above_vectors()) {
+    } else if (const size_t piece = piece_for(n_vec)) {
         const int pol = stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)});  // above the cache: nt both ways
-        const size_t piece = piece_vectors();
         for (size_t v0 = 0; v0 < n_vec || (v0 == n_vec && tail); v0 += piece) {
             const bool last = v0 + piece >= n_vec;
             const size_t nv = last ? n_vec - v0 : piece;
@@ -492,8 +490,7 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
         const int pol = stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)});
-        if (piece_vectors() && n_vec > split_above_vectors()) {  // very large: several launches (see piece_vectors)
-            const size_t piece = piece_vectors();
+        if (const size_t piece = piece_for(n_vec)) {  // large: several launches (internal.h: piece_for)
             for (size_t v0 = 0;; v0 += piece) {
                 const bool last = v0 + piece >= n_vec;
                 const size_t nv = last ? n_vec - v0 : piece;

@@ -102,12 +102,15 @@ int stream_policy(std::initializer_list<Span> reads, Span write);
 // run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
 int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
 
-// Very large operands go out as several launches (contiguous.hip explains why): pieces of piece_vectors() 16-byte vectors
-// (2^24 = 256 MiB per operand; 0: never) once an operand has more than split_above_vectors() of them (2^26 = 1 GiB).
-// SMHIP_PIECE_LOG2VEC=<k> sets the piece size -- and, so that the piece loops can be exercised at test sizes, the split
-// threshold to the same value.
-size_t piece_vectors();
-size_t split_above_vectors();
+// Large operands go out as several launches (contiguous.hip explains why).  piece_for(n_vec) = the piece size in 16-byte
+// vectors for an operand of n_vec of them, 0 for "one launch":
+//   n_vec <= 2^25 (512 MiB)          one launch
+//   2^25 < n_vec <= 2^26 (1 GiB)     pieces of 2^25: the headline's 2^28 floats as TWO launches, 496.6 -> 491.8 us (81.1 -> 81.9 %,
+//                                    five alternating rounds each within 0.1 %; four pieces 493.5, eight 499.0 us)
+//   larger                           pieces of 2^24 (256 MiB): 2^30 78.4 -> 81.5 %, 2^31 76-81 -> 82-83 %
+// SMHIP_PIECE_LOG2VEC=<k>: every operand above 2^k vectors in pieces of 2^k (tests run the piece loops at small sizes
+// with it); 0: never split.
+size_t piece_for(size_t n_vec);
 
 inline size_t dtype_size(int dtype) {
     switch (dtype) {

@@ -461,8 +461,8 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     // thousands of workgroups loses 3-6 % to its own length): pieces of whole tiles, each writing its workgroups' partials
     // behind the previous piece's; ONE finishing launch adds them all.  The partials and their order are the same as for a
     // single launch, so the bits do not depend on the piece size.
-    const bool split = piece_vectors() && n_vec > split_above_vectors();
-    const size_t piece_tiles = split ? (piece_vectors() / tile ? piece_vectors() / tile : 1) : blocks;
+    const size_t piece = piece_for(n_vec);
+    const size_t piece_tiles = piece ? (piece / tile ? piece / tile : 1) : blocks;
     for (size_t b0 = 0; b0 < blocks; b0 += piece_tiles) {
         const size_t nb = b0 + piece_tiles < blocks ? piece_tiles : blocks - b0;
         const bool last = b0 + nb == blocks;

@@ -277,22 +277,19 @@ int acquire(hipStream_t *stream) {
     return SMHIP_OK;
 }
 
-namespace {
-struct PieceRule { size_t piece, above; };
-const PieceRule &piece_rule() {
-    static const PieceRule r = [] {
+size_t piece_for(size_t n_vec) {
+    static const long forced = [] {  // -1: the built-in rule; 0: never split; k: pieces of 2^k above 2^k
         const char *e = getenv("SMHIP_PIECE_LOG2VEC");
-        if (!e) return PieceRule{(size_t)1 << 24, (size_t)1 << 26};
-        const int k = atoi(e);
-        if (k <= 0) return PieceRule{0, ~(size_t)0};
-        const size_t p = (size_t)1 << (k < 12 ? 12 : k);
-        return PieceRule{p, p};
+        if (!e) return -1L;
+        const long k = atol(e);
+        return k <= 0 ? 0L : (k < 12 ? 12L : k);
     }();
-    return r;
+    if (forced == 0) return 0;
+    if (forced > 0) return n_vec > ((size_t)1 << forced) ? (size_t)1 << forced : 0;
+    if (n_vec > ((size_t)1 << 26)) return (size_t)1 << 24;
+    if (n_vec > ((size_t)1 << 25)) return (size_t)1 << 25;
+    return 0;
 }
-}  // namespace
-size_t piece_vectors() { return piece_rule().piece; }
-size_t split_above_vectors() { return piece_rule().above; }
 
 hipEvent_t pool_event_take(int dev) { return take_event(dev); }
 void pool_event_give(int dev, hipEvent_t e) { give_event(dev, e); }
@@ -978,6 +975,13 @@ int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host) {
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy) {
     if (!policy) return fail(SMHIP_ERR_INVALID, "policy_probe: null");
     *policy = stream_policy({{a, a ? a_bytes : 0}, {b, b ? b_bytes : 0}}, {out, out ? out_bytes : 0});
+    return SMHIP_OK;
+}
+
+int smhip_launch_pieces(size_t bytes_per_operand, int *pieces) {
+    if (!pieces) return fail(SMHIP_ERR_INVALID, "launch_pieces: null");
+    const size_t n_vec = bytes_per_operand / 16, piece = piece_for(n_vec);
+    *pieces = piece ? (int)((n_vec + piece - 1) / piece) : 1;
     return SMHIP_OK;
 }
 
