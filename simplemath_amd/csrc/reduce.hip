@@ -463,9 +463,10 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     // single launch, so the bits do not depend on the piece size.
     const size_t piece = piece_for(n_vec);
     const size_t piece_tiles = piece ? (piece / tile ? piece / tile : 1) : blocks;
-    for (size_t b0 = 0; b0 < blocks; b0 += piece_tiles) {
-        const size_t nb = b0 + piece_tiles < blocks ? piece_tiles : blocks - b0;
-        const bool last = b0 + nb == blocks;
+    const size_t full_tiles = blocks - 1;  // the last workgroup of the whole array is the partial tile + tail: it rides with the last piece
+    for (size_t b0 = 0; b0 < blocks;) {
+        const bool last = b0 + piece_tiles >= full_tiles;
+        const size_t nb = last ? blocks - b0 : piece_tiles;
         const size_t v0 = b0 * tile;                                     // first vector of this piece
         const size_t nv = last ? n_vec - v0 : nb * tile;                  // its vectors (the last piece: the partial tile too)
         const size_t ne = last ? n - v0 * W : nv * W;                     // its elements (the last piece: the n % W tail too)
@@ -478,6 +479,7 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
         else
             hipLaunchKernelGGL((reduce_kernel<T, Op, MODE, false, BLOCK>), dim3((unsigned)nb), dim3(BLOCK), 0, s, pa, pb, po, nv, ne, pp, out8,
                                static_cast<T *>(out_native), pol, blocks == 1 ? 1 : 0);
+        b0 += nb;
     }
     SMHIP_LAUNCH_CHECK("reduce");
     if (blocks == 1) return SMHIP_OK;  // the single workgroup wrote the result itself
