@@ -5,11 +5,11 @@ set -e
 src=gpurun_out/$1; pre=profiles/$2
 for wl in add bcast_mul pow add_sum transpose_add; do
   cp $src/bench_$wl.json ${pre}_bench_$wl.json
-  f=$(find $src/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" ${pre}_${wl}_kernel_stats.csv
+  f=$(find $src/prof_$wl -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -rn | head -1 | cut -d" " -f2-); [ -n "$f" ] && cp "$f" ${pre}_${wl}_kernel_stats.csv
 done
 for wl in bcast_mul pow add_sum; do
   cp $src/bench_${wl}_cold.json ${pre}_bench_${wl}_cold.json
-  f=$(find $src/prof_${wl}_cold -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" ${pre}_${wl}_cold_kernel_stats.csv
+  f=$(find $src/prof_${wl}_cold -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -rn | head -1 | cut -d" " -f2-); [ -n "$f" ] && cp "$f" ${pre}_${wl}_cold_kernel_stats.csv
 done
 cp $src/bench_add_single.json ${pre}_bench_add_single.json
 cp $src/traffic.json ${pre}_pmc_traffic.json
