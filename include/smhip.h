@@ -277,10 +277,12 @@ int smhip_allreduce_sum_async(int dtype, void *inout_dev, size_t count);
  * operands).  Like a launch it records the spans as touched.  Host-only arithmetic on the pointer VALUES (nothing is
  * dereferenced, no device is needed): the residency rule's test hook. */
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy);
-/* How a dense streaming operator (smhip_contiguous, smhip_array_scalar, the reductions) over operands of `bytes_per_operand`
- * bytes is launched: *pieces = the number of kernel launches it goes out as (1, or several for operands above 512 MiB --
- * DESIGN.md section 3 "Very large arrays").  Host-only.  bench.py prices its roofline per LAUNCH with it. */
-int smhip_launch_pieces(size_t bytes_per_operand, int *pieces);
+/* How a dense streaming operator over operands of `bytes_per_operand` bytes is launched: *pieces = the number of kernel
+ * launches it goes out as.  `streams` = the full-size streams it moves: 3 for smhip_contiguous and the fused op+sum (two
+ * reads, one write), 2 for smhip_array_scalar and smhip_dot, 1 for smhip_sum.  Three-stream operators are cut above
+ * 512 MiB per operand, the others above 2 GiB (DESIGN.md section 3 "Very large arrays").  Host-only.  bench.py prices its
+ * roofline per LAUNCH with it. */
+int smhip_launch_pieces(size_t bytes_per_operand, int streams, int *pieces);
 
 /* -------------------------------------------------------------- timing */
 /* HIP events on the calling thread's stream (what bench.py brackets the

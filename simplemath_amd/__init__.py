@@ -481,10 +481,10 @@ class Smhip:
                                            C.c_size_t(out_bytes), C.byref(pol)))
         return pol.value
 
-    def launch_pieces(self, bytes_per_operand):
-        """Kernel launches a dense streaming operator over operands of this size goes out as."""
+    def launch_pieces(self, bytes_per_operand, streams=3):
+        """Kernel launches a dense streaming operator over operands of this size goes out as (streams: 3 a op b, 2 a op s / dot, 1 sum)."""
         k = C.c_int(0)
-        self._ck(self.c.smhip_launch_pieces(C.c_size_t(bytes_per_operand), C.byref(k)))
+        self._ck(self.c.smhip_launch_pieces(C.c_size_t(bytes_per_operand), C.c_int(streams), C.byref(k)))
         return k.value
 
     # -- timing -----------------------------------------------------------------

@@ -332,7 +332,7 @@ template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
     const int nt = KIND == 0 ? stream_policy({{pa, n_vec * 16}, {pb, n_vec * 16}}, {po, n_vec * 16}) : stream_policy({{pa, n_vec * 16}}, {po, n_vec * 16});
-    if (const size_t piece = piece_for(n_vec)) {  // large: several launches (internal.h: piece_for)
+    if (const size_t piece = piece_for(n_vec, KIND == 0 ? 3 : 2)) {  // large: several launches (internal.h: piece_for)
         for (size_t v0 = 0;; v0 += piece) {
             const bool last = v0 + piece >= n_vec;
             launch_heavy_piece<T, Op, KIND>(pa + v0 * W, KIND == 0 ? pb + v0 * W : pb, value, po + v0 * W, last ? n_vec - v0 : piece, last ? tail : 0, nt, s);
@@ -420,7 +420,7 @@ int run_contiguous(const void *a, const void *b, void *out, size_t n, hipStream_
     if constexpr (IsHeavy<Op>::value) {
         if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
         launch_heavy<T, Op, 0>(pa, pb, T{}, po, n_vec, tail, s);
-    } else if (const size_t piece = piece_for(n_vec)) {
+    } else if (const size_t piece = piece_for(n_vec, 3)) {
         const int pol = stream_policy({{pa, n * sizeof(T)}, {pb, n * sizeof(T)}}, {po, n * sizeof(T)});  // above the cache: nt both ways
         for (size_t v0 = 0; v0 < n_vec || (v0 == n_vec && tail); v0 += piece) {
             const bool last = v0 + piece >= n_vec;
@@ -490,7 +490,7 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
         // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
         const int pol = stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)});
-        if (const size_t piece = piece_for(n_vec)) {  // large: several launches (internal.h: piece_for)
+        if (const size_t piece = piece_for(n_vec, 2)) {  // large: several launches (internal.h: piece_for)
             for (size_t v0 = 0;; v0 += piece) {
                 const bool last = v0 + piece >= n_vec;
                 const size_t nv = last ? n_vec - v0 : piece;

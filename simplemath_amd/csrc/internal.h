@@ -102,15 +102,20 @@ int stream_policy(std::initializer_list<Span> reads, Span write);
 // run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
 int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
 
-// Large operands go out as several launches (contiguous.hip explains why).  piece_for(n_vec) = the piece size in 16-byte
-// vectors for an operand of n_vec of them, 0 for "one launch":
-//   n_vec <= 2^25 (512 MiB)          one launch
-//   2^25 < n_vec <= 2^26 (1 GiB)     pieces of 2^25: the headline's 2^28 floats as TWO launches, 496.6 -> 491.8 us (81.1 -> 81.9 %,
-//                                    five alternating rounds each within 0.1 %; four pieces 493.5, eight 499.0 us)
-//   larger                           pieces of 2^24 (256 MiB): 2^30 78.4 -> 81.5 %, 2^31 76-81 -> 82-83 %
-// SMHIP_PIECE_LOG2VEC=<k>: every operand above 2^k vectors in pieces of 2^k (tests run the piece loops at small sizes
-// with it); 0: never split.
-size_t piece_for(size_t n_vec);
+// Large operands go out as several launches (contiguous.hip explains why).  piece_for(n_vec, streams) = the piece size in
+// 16-byte vectors for operands of n_vec of them, 0 for "one launch"; `streams` = the full-size streams the kernel moves
+// (3: a op b -> out, the fused op+sum; 2: a op s -> out, dot; 1: sum).
+//   three streams   n_vec <= 2^25 (512 MiB)        one launch (256 MiB: 84.0 % whole, 82.5 % halved; 512 MiB: 82.8 / 82.6 %)
+//                   2^25 < n_vec <= 2^26 (1 GiB)   halves of 2^25: the headline's 2^28 floats as TWO launches, 496.6 -> 491.8 us
+//                                                  (81.1 -> 81.9 %, five alternating rounds each within 0.1 %; four pieces 81.6, eight 80.7 %)
+//                   larger                         pieces of 2^24 (256 MiB): 2^29 80.0 -> 82.6 %, 2^30 78.4 -> 81.5 %, 2^31 76-81 -> 82-83 %
+//   one / two       n_vec <= 2^27 (2 GiB)          one launch (pieces change nothing up to there: a*s 81.4 / 81.5 %, sum 83.2 / 83.4 %,
+//                                                  dot 83.3 / 82.0 % whole / in pieces at 2^28-2^29 elements)
+//                   larger                         pieces of 2^25: a*s 80.5 -> 81.2 %, sum 82.1 -> 83.7 %, dot 80.9 -> 82.7 % at 2^30
+//   (profiles/r03_headline_pieces.txt, r03_mid_pieces.txt, r03_big_add.txt, r03_mix_pieces.txt)
+// SMHIP_PIECE_LOG2VEC=<k>: every operand above 2^k vectors in pieces of 2^k, whatever the mix (tests run the piece loops at
+// small sizes with it); 0: never split.
+size_t piece_for(size_t n_vec, int streams);
 
 inline size_t dtype_size(int dtype) {
     switch (dtype) {

@@ -471,7 +471,7 @@ int jit_contiguous(int op, int dtype, const void *a, const void *b, void *out, s
     const size_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "user op: array too large for one launch");
     int pol = stream_policy({{a, n * dtype_size(dtype)}, {b, n * dtype_size(dtype)}}, {out, n * dtype_size(dtype)});
-    const unsigned long long kPiece = piece_for(n_vec);  // large arrays go out in pieces (contiguous.hip, internal.h)
+    const unsigned long long kPiece = piece_for(n_vec, 3);  // large arrays go out in pieces (contiguous.hip, internal.h)
     if (kPiece) {
         const size_t esz = dtype_size(dtype);
         for (unsigned long long v0 = 0;; v0 += kPiece) {
@@ -500,7 +500,7 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
     unsigned char scalar[8];
     memcpy(scalar, value_host, dtype_size(dtype));
     int pol = stream_policy({{a, n * dtype_size(dtype)}}, {out, n * dtype_size(dtype)});
-    const unsigned long long kPiece = piece_for(n_vec);
+    const unsigned long long kPiece = piece_for(n_vec, 2);
     if (kPiece) {
         const size_t esz = dtype_size(dtype);
         for (unsigned long long v0 = 0;; v0 += kPiece) {

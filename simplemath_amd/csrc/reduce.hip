@@ -461,7 +461,7 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     // thousands of workgroups loses 3-6 % to its own length): pieces of whole tiles, each writing its workgroups' partials
     // behind the previous piece's; ONE finishing launch adds them all.  The partials and their order are the same as for a
     // single launch, so the bits do not depend on the piece size.
-    const size_t piece = piece_for(n_vec);
+    const size_t piece = piece_for(n_vec, MODE == kSum ? 1 : MODE == kDot ? 2 : 3);
     const size_t piece_tiles = piece ? (piece / tile ? piece / tile : 1) : blocks;
     const size_t full_tiles = blocks - 1;  // the last workgroup of the whole array is the partial tile + tail: it rides with the last piece
     for (size_t b0 = 0; b0 < blocks;) {

@@ -277,7 +277,7 @@ int acquire(hipStream_t *stream) {
     return SMHIP_OK;
 }
 
-size_t piece_for(size_t n_vec) {
+size_t piece_for(size_t n_vec, int streams) {
     static const long forced = [] {  // -1: the built-in rule; 0: never split; k: pieces of 2^k above 2^k
         const char *e = getenv("SMHIP_PIECE_LOG2VEC");
         if (!e) return -1L;
@@ -286,9 +286,12 @@ size_t piece_for(size_t n_vec) {
     }();
     if (forced == 0) return 0;
     if (forced > 0) return n_vec > ((size_t)1 << forced) ? (size_t)1 << forced : 0;
-    if (n_vec > ((size_t)1 << 26)) return (size_t)1 << 24;
-    if (n_vec > ((size_t)1 << 25)) return (size_t)1 << 25;
-    return 0;
+    if (streams >= 3) {
+        if (n_vec > ((size_t)1 << 26)) return (size_t)1 << 24;
+        if (n_vec > ((size_t)1 << 25)) return (size_t)1 << 25;
+        return 0;
+    }
+    return n_vec > ((size_t)1 << 27) ? (size_t)1 << 25 : 0;
 }
 
 hipEvent_t pool_event_take(int dev) { return take_event(dev); }
@@ -978,9 +981,9 @@ int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_by
     return SMHIP_OK;
 }
 
-int smhip_launch_pieces(size_t bytes_per_operand, int *pieces) {
-    if (!pieces) return fail(SMHIP_ERR_INVALID, "launch_pieces: null");
-    const size_t n_vec = bytes_per_operand / 16, piece = piece_for(n_vec);
+int smhip_launch_pieces(size_t bytes_per_operand, int streams, int *pieces) {
+    if (!pieces || streams < 1) return fail(SMHIP_ERR_INVALID, "launch_pieces: bad arguments");
+    const size_t n_vec = bytes_per_operand / 16, piece = piece_for(n_vec, streams);
     *pieces = piece ? (int)((n_vec + piece - 1) / piece) : 1;
     return SMHIP_OK;
 }
