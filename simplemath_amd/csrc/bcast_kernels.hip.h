@@ -481,11 +481,11 @@ __device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T 
 #define SMHIP_TILE_BOTH_CHUNK 8
 #endif
 constexpr int kTileP = 64;
-template <typename T> constexpr int tile_q() { return 512 / (int)sizeof(T); }
+// Bytes of one patch row along q: 512 (`QB` default), or 1024 for the WIDE patch that launches over arrays beyond the
+// Infinity Cache take together with a row-major walk (TileParams::order 0) -- see plan_launch() and DESIGN.md section 3.
+constexpr int kTileQBytes = 512, kTileQBytesWide = 1024;
+template <typename T, int QB = kTileQBytes> constexpr int tile_q() { return QB / (int)sizeof(T); }
 
-#ifndef SMHIP_TILE_ORDER
-#define SMHIP_TILE_ORDER 1  // 0: row-major walk of the patches (round 1), 1: diagonal
-#endif
 struct TileParams {
     // plane axes: p (operand-contiguous axis), q (output inner axis)
     uint32_t np, nq;            // extents
@@ -498,6 +498,7 @@ struct TileParams {
     int64_t a_r[SMHIP_MAX_NDIM - 2], b_r[SMHIP_MAX_NDIM - 2], o_r[SMHIP_MAX_NDIM - 2];
     uint32_t tiles_p, tiles_q;
     uint32_t nt;                // streamed reads carry the non-temporal hint (the launch reads more than the Infinity Cache holds)
+    uint32_t order;             // walk of the patches: 1 diagonal, 0 row-major (q fastest, p unshifted)
 };
 
 // One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
@@ -507,17 +508,17 @@ struct TileParams {
 // operands are contiguous along p (a.T op b.T) phase 1 loads both coalesced, applies the Op there and
 // stages the RESULT, so phase 2 is a pure transposed write-out.  MA / MB are compile-time in the
 // vector form; the element form (odd extents, pitches, bases) keeps them as runtime values.
-template <typename T, typename Op, bool VEC, int MA, int MB>
+template <typename T, typename Op, bool VEC, int MA, int MB, int QB = kTileQBytes>
 __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
                                                    TileParams p) {
     constexpr int W = VEC ? VecTraits<T>::width : 1;
-    constexpr int TQ = tile_q<T>();
+    constexpr int TQ = tile_q<T, QB>();
     constexpr int VP = kTileP / W, VQ = TQ / W;  // vector slots per patch row, along p / along q
     // LDS layout of element (i, j): 4-byte types get a skewed layout (one pad word per 32 columns, two per 32 rows,
     // odd pitch) that makes both the 4-byte scatter of phase 1 and the stride-4 reads of phase 2 hit 32 distinct
     // banks per 32-lane group; 8-byte types keep the plain padded pitch.
     constexpr bool SKEW = sizeof(T) == 4;
-    constexpr int PITCH = SKEW ? TQ + 5 : TQ + 1;
+    constexpr int PITCH = SKEW ? TQ + TQ / 32 + 1 : TQ + 1;  // skewed: column j sits at j + j/32, rows 32.. two words further, and the pitch is odd
     auto at = [](uint32_t i, uint32_t j) -> uint32_t { return SKEW ? i * PITCH + j + (j >> 5) + ((i >> 5) << 1) : i * PITCH + j; };
     typedef typename VecTraits<T>::vec_t V;
     __shared__ T tile[kTileP * PITCH];
@@ -532,12 +533,12 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     // instead of 64 of them reading the same 256-byte column of 8192 rows at a power-of-two pitch.  (8192, 8192) f32,
     // tools/tile_modes.py -> profiles/r02_tile_order.txt: a.T + b.T 138.0 -> 130.5 us, and 169.9 -> 129.2 us when the
     // operands' pitch is 8256 elements; a.T + b at that pitch 119.6 -> 113.6 us.  Skewing q instead, walking p along the
-    // diagonal, and a skew of three were all slower.
+    // diagonal, and a skew of three were all slower.  That holds up to 256 MiB per array.  Beyond, the diagonal is what
+    // hurts: the workgroups in flight then write 512-byte pieces of a thousand different output rows, and the same kernel
+    // walking row-major (order 0) with 1024-byte patch rows is 6-10 points faster (a.T + b at 16384^2: 68 -> 78 %).
     const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;
     uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;
-#if SMHIP_TILE_ORDER == 1
-    tp = (tp + tq) % p.tiles_p;
-#endif
+    if (p.order == 1) tp = (tp + tq) % p.tiles_p;
     int64_t offA = 0, offB = 0, offO = 0;
     for (int k = 0; k < p.n_rest; ++k) {
         uint32_t qd, idx;

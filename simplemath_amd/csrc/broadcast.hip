@@ -77,9 +77,9 @@ template <typename T, typename Op, bool SWAPPED, int U>
 __global__ __launch_bounds__(256) void dense_lds_kernel(const T *__restrict__ x, const T *__restrict__ y, T *__restrict__ out, LdsParams p) {
     dense_lds_body<T, Op, SWAPPED, U>(x, y, out, p);
 }
-template <typename T, typename Op, bool VEC, int MA, int MB>
+template <typename T, typename Op, bool VEC, int MA, int MB, int QB>
 __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, TileParams p) {
-    tile_body<T, Op, VEC, MA, MB>(a, b, out, p);
+    tile_body<T, Op, VEC, MA, MB, QB>(a, b, out, p);
 }
 
 // ---------------------------------------------------------------------------- choosing a kernel
@@ -250,7 +250,13 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
         if (paxis >= 0) {
             TileParams &t = L->p.tile;
             t = TileParams{};
-            const int tq = 512 / esz;  // tile_q<T>()
+            const bool vec = pl.shape[paxis] % W == 0 && inner % W == 0;
+            // The patch and its walk.  Up to the Infinity Cache's size per array: 64 x 512 B patches along a diagonal.
+            // Beyond: 64 x 1024 B patches, row-major, so that the workgroups in flight together write (and read the
+            // direct operand in) whole rows of the output -- tools/tile_shapes.py, profiles/r03_tile_shapes.txt.
+            static const int forced = [] { const char *e = getenv("SMHIP_TILE_WIDE"); return e && *e ? atoi(e) : -1; }();
+            const bool wide = vec && (forced >= 0 ? forced != 0 : pl.n * (size_t)esz > kInfinityCacheBytes);
+            const int tq = (wide ? kTileQBytesWide : kTileQBytes) / esz;  // tile_q<T, QB>()
             t.np = (uint32_t)pl.shape[paxis];
             t.nq = (uint32_t)inner;
             t.a_p = pl.sa[paxis]; t.a_q = ia;
@@ -286,7 +292,9 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             if (blocks < 0x7fffffffull && pl.shape[paxis] < 0x7fffffffll && inner < 0x7fffffffll) {
                 // the 16-byte form needs whole vectors along both plane axes; bases and pitches may be anything
                 L->kind = Launch::kTile;
-                L->vec = t.np % W == 0 && t.nq % W == 0;
+                L->vec = vec;
+                L->wide = wide;
+                t.order = wide ? 0 : 1;
                 L->ma = L->vec ? t.mode_a : 0;
                 L->mb = L->vec ? t.mode_b : 0;
                 L->grid = (unsigned)blocks;
@@ -415,10 +423,14 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
             SMHIP_LAUNCH_CHECK("dense_lds_kernel");
             return SMHIP_OK;
         case Launch::kTile:
-            if (!L.vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0>), grid, block, 0, s, a, b, out, L.p.tile);
-            else if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1>), grid, block, 0, s, a, b, out, L.p.tile);
-            else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0>), grid, block, 0, s, a, b, out, L.p.tile);
-            else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1>), grid, block, 0, s, a, b, out, L.p.tile);
+            if (!L.vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
+            else if (L.wide) {
+                if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1, kTileQBytesWide>), grid, block, 0, s, a, b, out, L.p.tile);
+                else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0, kTileQBytesWide>), grid, block, 0, s, a, b, out, L.p.tile);
+                else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1, kTileQBytesWide>), grid, block, 0, s, a, b, out, L.p.tile);
+            } else if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
+            else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
+            else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
             SMHIP_LAUNCH_CHECK("tile_kernel");
             return SMHIP_OK;
         case Launch::kStrided: {
@@ -728,7 +740,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         if (!user && pl.sa[0] == 1 && pl.sb[0] == 0) return launch_array_devscalar(op, dtype, a, b, pl.n, out, false, s);
         if (!user && pl.sa[0] == 0 && pl.sb[0] == 1) return launch_array_devscalar(op, dtype, b, a, pl.n, out, true, s);
     }
-    if (pl.n >= kMaxLaunchElems) {
+    // experiment switch (tools/bcast_pieces.py): cut broadcast problems above 2^k elements along their outermost dimension too
+    static const size_t piece_elems = [] { const char *e = getenv("SMHIP_BCAST_PIECE_LOG2"); return e && atoi(e) > 0 ? (size_t)1 << atoi(e) : (size_t)0; }();
+    const size_t max_elems = piece_elems && piece_elems < kMaxLaunchElems && pl.ndim >= 2 && (size_t)pl.shape[0] > 1 ? piece_elems + 1 : kMaxLaunchElems;
+    if (pl.n >= max_elems) {
+        const size_t kMaxLaunchElems = max_elems;  // shadows the file-scope limit inside this block
         const size_t esz = dtype_size(dtype);
         const size_t slice = pl.n / (size_t)pl.shape[0];  // elements per index of the outermost dimension
         size_t per = slice >= kMaxLaunchElems ? 1 : (kMaxLaunchElems - 1) / slice;

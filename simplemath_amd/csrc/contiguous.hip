@@ -390,11 +390,11 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
     const size_t bytes = rows * cols * sizeof(T);
     const int nt = stream_policy({{pa, bytes}}, {po, bytes});
     const FastDiv cv((uint32_t)(cols / W));
-    // A dense operand that fits the Infinity Cache and is read with `nt` all the same is COLD (internal.h: the residency rule).
-    // Cold, ONE vector per lane is the faster shape for the light Ops -- config 3's multiply 23.1 -> 22.5 us (72.6 -> 74.5 %),
+    // A dense operand that is read with `nt` is not coming from the Infinity Cache: it is COLD (internal.h: the residency rule)
+    // or larger than the cache.  Then ONE vector per lane is the faster shape for the light Ops -- config 3's multiply 23.1 -> 22.5 us (72.6 -> 74.5 %),
     // twice its size 44.2 -> 42.5 us (75.9 -> 79.0 %) -- while replayed and chained operands keep two (19.27 against 19.41 us;
     // tools/cold_rates.py, profiles/r03_rows_u.txt): twice the workgroups retire, and free their slots, half a tile earlier.
-    const bool cold = (nt & kLoadNt) && bytes <= kInfinityCacheBytes;
+    const bool cold = (nt & kLoadNt) != 0;  // cold by the residency rule, or simply larger than the cache
     if (!IsHeavy<Op>::value && U > 1 && cold) launch_rows<T, Op, 1>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
     else launch_rows<T, Op, U>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
     SMHIP_LAUNCH_CHECK("heavy rows");

@@ -1367,6 +1367,18 @@ def test_large_view_shapes_vs_numpy(smhip):
             assert np.array_equal(got, f(va, vb)), (t, dtn, opn, dims, ka, kb)
 
 
+def test_tile_kernel_patch_shapes():
+    """The tile kernel has two patch shapes (64 x 512 B on a diagonal walk up to 256 MiB per array, 64 x 1024 B row-major
+    beyond: DESIGN.md section 3).  tests/tile_probe.py runs transposed / permuted views of every element type, + * and a user
+    Op, bit-exact against numpy, with each shape forced at test sizes; unforced, its 272 MiB case takes the wide patch."""
+    import subprocess, sys, os
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_probe.py")
+    for env, args in (({"SMHIP_TILE_WIDE": "1"}, []), ({"SMHIP_TILE_WIDE": "0"}, []), ({}, ["big"])):
+        clean = {k: v for k, v in os.environ.items() if k != "SMHIP_TILE_WIDE"}
+        r = subprocess.run([sys.executable, probe] + args, capture_output=True, text=True, timeout=600, env=dict(clean, **env))
+        assert r.returncode == 0 and "tile_probe ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-2000:])
+
+
 def test_user_ops_first_used_from_many_threads(smhip, tmp_path, monkeypatch):
     """hipRTC builds run with the cache mutex released: threads that need the SAME new kernel wait for one build, threads
     that need different ones compile side by side -- and every thread gets the right kernel."""

@@ -1,0 +1,56 @@
+"""The LDS tile kernel's two patch shapes against numpy.  SMHIP_TILE_WIDE=1 forces the 64 x 1024 B patch with its row-major
+walk at test sizes, =0 the 64 x 512 B patch on its diagonal; unset, the library chooses by size and the last case (one
+operand > 256 MiB) takes the wide patch by itself.  Transposed / permuted / offset views, one and two turned operands,
+f32 / f64 / i32, + and *, a user-defined Op (hipRTC compiles the same body), bit-exact (one correctly rounded operation
+per element).                    python tests/tile_probe.py [big]      -- prints "tile_probe ok <cases>".
+"""
+import os, sys
+sys.path.insert(0, "/root/repo")
+import numpy as np
+import simplemath_amd as sma
+from tests.golden import gen
+
+DT = {"f32": np.float32, "f64": np.float64, "i32": np.int32}
+smhip = sma.load()
+rng = np.random.default_rng(77)
+user = smhip.register_op("a * b + (T)3")
+cases = 0
+for t in range(36):
+    dtn = ("f32", "f64", "i32")[t % 3]
+    dt = DT[dtn]
+    nd = 2 if t % 4 else 3
+    # extents: whole patches (multiples of 256), ragged edges and extents that are not a multiple of the vector width
+    pick = lambda: int(rng.choice([256, 512, 768, int(rng.integers(130, 1500)), 4 * int(rng.integers(40, 300))]))
+    dims = [pick(), pick()] if nd == 2 else [int(rng.integers(2, 6)), pick() // 2 + 64, pick() // 2 + 64]
+    a = gen.gen(dt, int(np.prod(dims)), 700 + t, "uniform").reshape(dims)
+    b = gen.gen(dt, int(np.prod(dims)), 800 + t, "uniform").reshape(dims)
+    turn = lambda x: np.transpose(x, list(range(x.ndim - 2)) + [x.ndim - 1, x.ndim - 2])
+    kind = t % 5
+    if kind == 0: va, vb = turn(a), b.reshape(turn(a).shape)                  # one turned operand
+    elif kind == 1: va, vb = a.reshape(turn(b).shape), turn(b)                # ... the right-hand one
+    elif kind == 2: va, vb = turn(a), turn(b)                                 # both turned
+    elif kind == 3: va, vb = turn(a)[..., 4:-4, 8:-8], turn(b)[..., 4:-4, 8:-8]   # offset bases, ragged patches
+    else: va, vb = np.transpose(a), np.transpose(b).copy()                    # full reversal against a dense operand
+    if not vb.flags.c_contiguous and kind == 4: vb = np.ascontiguousarray(vb)
+    base_b = b if np.shares_memory(vb, b) else vb
+    da, db = smhip.to_device(a), smhip.to_device(base_b)
+    for opn, f in (("add", np.add), ("mul", np.multiply), (user, None)):
+        op = sma.OPS[opn] if isinstance(opn, str) else opn
+        got = smhip.binary(op, da.view_like(va, a), db.view_like(vb, base_b)).numpy()
+        want = f(va, vb) if f else va * vb + dt(3)
+        if not np.array_equal(got, want):
+            print("MISMATCH", t, dtn, opn, dims, kind, int((got != want).sum()))
+            sys.exit(1)
+        cases += 1
+if len(sys.argv) > 1 and sys.argv[1] == "big":
+    # 8704 x 8192 f32 = 272 MiB per array: past the Infinity Cache, so the unforced library takes the wide patch
+    P, Q = 8704, 8192
+    a = gen.gen(np.float32, P * Q, 1, "uniform").reshape(Q, P)
+    b = gen.gen(np.float32, P * Q, 2, "uniform").reshape(P, Q)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    got = smhip.binary(sma.OPS["add"], da.view_like(a.T, a), db).numpy()
+    if not np.array_equal(got, a.T + b):
+        print("MISMATCH big")
+        sys.exit(1)
+    cases += 1
+print("tile_probe ok", cases, "SMHIP_TILE_WIDE =", os.environ.get("SMHIP_TILE_WIDE", "(unset)"))

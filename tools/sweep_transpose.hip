@@ -16,7 +16,12 @@ __global__ __launch_bounds__(256) void tadd(const float* __restrict__ A, const f
     __shared__ float lds[TP][TQ + 1];  // [i][j]
     const int tiles_p = N / TP, tiles_q = N / TQ;
     int tp, tq;
-    if (ORDER == 0) { tq = blockIdx.x % tiles_q; tp = blockIdx.x / tiles_q; } else { tp = blockIdx.x % tiles_p; tq = blockIdx.x / tiles_p; }
+    if (ORDER == 0) { tq = blockIdx.x % tiles_q; tp = blockIdx.x / tiles_q; } else if (ORDER == 1) { tp = blockIdx.x % tiles_p; tq = blockIdx.x / tiles_p; }
+    else {  // ORDER >= 2: panels of ORDER q-patches; inside a panel q fastest, then p 
+        const int panel = blockIdx.x / (ORDER * tiles_p), r = blockIdx.x % (ORDER * tiles_p);
+        const int w = tiles_q - panel * ORDER < ORDER ? tiles_q - panel * ORDER : ORDER;  // the last panel may be narrower
+        tq = panel * ORDER + r % w; tp = r / w;
+    }
     const int i0 = tp * TP, j0 = tq * TQ;
     constexpr int VP = TP / 4, VQ = TQ / 4;
 #pragma unroll
@@ -77,7 +82,8 @@ __global__ void init_k(float* p, size_t n, float v) { for (size_t i = (size_t)bl
 struct V { std::string name; void (*fn)(const float*, const float*, float*, int); int tp, tq; std::vector<float> ms; };
 int main(int argc, char** argv) {
     const bool both = argc > 1 && std::string(argv[1]) == "both";
-    const int N = 8192; const size_t n = (size_t)N * N;
+    const int N = argc > 2 ? atoi(argv[2]) : 8192; const size_t n = (size_t)N * N;   // N: a multiple of 256
+    printf("N = %d\n", N);
     float *A, *B, *O; CK(hipMalloc(&A, n * 4)); CK(hipMalloc(&B, n * 4)); CK(hipMalloc(&O, n * 4));
     init_k<<<4096, 256>>>(A, n, 1.f); init_k<<<4096, 256>>>(B, n, 2.f); CK(hipDeviceSynchronize());
     std::vector<V> vs;
@@ -86,6 +92,9 @@ int main(int argc, char** argv) {
     T(128, 64, 0, false); T(128, 64, 1, false); T(64, 128, 0, false); T(64, 128, 1, false);
     T(128, 128, 0, false); T(128, 128, 1, false); T(128, 32, 0, false); T(128, 32, 1, false); T(32, 128, 0, false); T(32, 128, 1, false);
     T(256, 32, 1, false); T(32, 32, 0, false); T(128, 64, 1, true); T(128, 128, 1, true); T(256, 64, 1, false); T(256, 64, 0, false);
+    T(32, 256, 0, false); T(32, 256, 1, false); T(64, 256, 0, false); T(64, 256, 1, false); T(128, 128, 0, true); T(64, 128, 0, true); T(64, 256, 0, true);
+    T(64, 128, 4, false); T(64, 128, 8, false); T(64, 128, 16, false); T(64, 128, 32, false); T(64, 256, 4, false); T(64, 256, 8, false); T(64, 256, 16, false); T(64, 256, 32, false);
+    T(64, 128, 16, true); T(64, 256, 16, true); T(32, 256, 8, false); T(32, 256, 16, false); T(128, 128, 8, false); T(128, 128, 16, false);
     if (both) {
         vs.clear();
 #define T2(P, Q, O_, NT) vs.push_back({"both-T tile " #P "x" #Q " order" #O_ " nt" #NT, tadd2<P, Q, O_, NT>, P, Q, {}})
