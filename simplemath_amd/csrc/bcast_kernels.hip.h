@@ -584,10 +584,10 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
                         if constexpr (kBoth) {  // two turned streams and no reuse: the footprint decides the policy
                             va[s] = load_stream_as(T, reinterpret_cast<const V *>(a0 + ig * W + (int64_t)jl * p.a_q), NT);
                             vb[s] = load_stream_as(T, reinterpret_cast<const V *>(b0 + ig * W + (int64_t)jl * p.b_q), NT);
-                        } else if constexpr (MA == 1) {  // one turned stream: cached reads win (tools/sweep_transpose.hip)
-                            va[s] = *reinterpret_cast<const V *>(a0 + ig * W + (int64_t)jl * p.a_q);
+                        } else if constexpr (MA == 1) {  // one turned stream: cached reads win up to 256 MiB per array (tools/sweep_transpose.hip); the wide patch follows the policy
+                            va[s] = load_stream_as(T, reinterpret_cast<const V *>(a0 + ig * W + (int64_t)jl * p.a_q), NT && QB == kTileQBytesWide);
                         } else {
-                            va[s] = *reinterpret_cast<const V *>(b0 + ig * W + (int64_t)jl * p.b_q);
+                            va[s] = load_stream_as(T, reinterpret_cast<const V *>(b0 + ig * W + (int64_t)jl * p.b_q), NT && QB == kTileQBytesWide);
                         }
                     }
                     if constexpr (!kBoth) {

@@ -294,7 +294,8 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                 L->kind = Launch::kTile;
                 L->vec = vec;
                 L->wide = wide;
-                t.order = wide ? 0 : 1;
+                static const int forced_order = [] { const char *e = getenv("SMHIP_TILE_ORDER"); return e && *e ? atoi(e) : -1; }();
+                t.order = forced_order >= 0 ? (forced_order != 0) : wide ? 0 : 1;  // SMHIP_TILE_ORDER: for tools/tile_variants.sh
                 L->ma = L->vec ? t.mode_a : 0;
                 L->mb = L->vec ? t.mode_b : 0;
                 L->grid = (unsigned)blocks;

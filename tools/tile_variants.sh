@@ -1,15 +1,11 @@
 #!/bin/bash
-# Builds libsmhip variants that differ in the tile kernel's patch walk and q extent (tools/bin/tile_o<order>_q<bytes>.so);
-# tools/tile_sizes.py <lib> measures each.  Development tool: run here (hipcc cross-compiles), measure on the GPU box.
-set -e
-cd "$(dirname "$0")/.."
-python -c "from simplemath_amd.build import build_lib; build_lib()"
-mkdir -p tools/bin
-for o in 0 1; do for q in 512 1024; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Iinclude -Isimplemath_amd/csrc \
-      -DSMHIP_TILE_ORDER=$o -DSMHIP_TILE_Q_BYTES=$q -c simplemath_amd/csrc/broadcast.hip -o tools/bin/bcast_o${o}_q${q}.o &&
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/bin/tile_o${o}_q${q}.so tools/bin/bcast_o${o}_q${q}.o \
-      $(ls simplemath_amd/lib/obj/*.o | grep -v broadcast.o) -lhiprtc -ldl ) &
+# The tile kernel's two patches (SMHIP_TILE_WIDE: 64 x 512 B / 64 x 1024 B) under its two walks (SMHIP_TILE_ORDER: 1 diagonal,
+# 0 row-major) over the shapes of tools/tile_shapes.py: the table behind the plan's choice (tile kernel).
+#   bash tools/tile_variants.sh <tag> [fine]        on the GPU box; writes gpurun_out/<tag>/tile_variants.txt
+set -o pipefail
+tag=${1:-r03}; out=gpurun_out/$tag; mkdir -p $out
+for wide in 0 1; do for order in 1 0; do
+  echo "## patch row $((512 * (wide + 1))) B, order $order" >> $out/tile_variants.txt
+  SMHIP_TILE_WIDE=$wide SMHIP_TILE_ORDER=$order timeout -k 10 110 python tools/tile_shapes.py - $2 >> $out/tile_variants.txt 2>&1 || exit 1
 done; done
-wait
-ls -la tools/bin/tile_o*.so
+tail -80 $out/tile_variants.txt
