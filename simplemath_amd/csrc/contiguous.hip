@@ -461,25 +461,74 @@ template <typename T> struct PowSqrt {
     }
 };
 
+// One read and one write stream through scalar_vec_kernel: workgroups of 256 at every size (tools/sweep_scalar.hip,
+// profiles/r01_sweep_scalar.txt: 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane
+// lose 4-10 %); very large arrays in pieces (internal.h: piece_for).
+template <typename T, typename Op, bool SWAPPED>
+int launch_scalar_stream(const T *pa, T value, T *po, size_t n_vec, int tail, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const size_t n = n_vec * W + (size_t)tail;
+    const int pol = stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)});
+    unsigned grid;
+    if (const size_t piece = piece_for(n_vec, 2)) {
+        for (size_t v0 = 0;; v0 += piece) {
+            const bool last = v0 + piece >= n_vec;
+            const size_t nv = last ? n_vec - v0 : piece;
+            if (int rc = grid_for(nv + (last && tail ? 1 : 0), kBlockSmall, &grid)) return rc;
+            hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa + v0 * W, value, po + v0 * W, nv,
+                               last ? tail : 0, pol);
+            if (last) break;
+        }
+        return SMHIP_OK;
+    }
+    if (int rc = grid_for(n_vec + (tail ? 1 : 0), kBlockSmall, &grid)) return rc;
+    hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, pol);
+    return SMHIP_OK;
+}
+
 template <typename T, typename Op, bool SWAPPED>
 int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
     const T *pa = static_cast<const T *>(a);
     T *po = static_cast<T *>(out);
-    unsigned grid;
     const size_t n_vec = n / W;
     const int tail = (int)(n % W);
-    const size_t threads = n_vec + (tail ? 1 : 0);
     if constexpr (IsHeavy<Op>::value && std::is_floating_point<T>::value && !SWAPPED) {
         if (value == T(2) || value == T(1) || value == T(-1) || value == T(0.5)) {
-            if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-            const dim3 g(grid), b(kBlockSmall);
-            if (value == T(2)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowSquare<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
-            else if (value == T(1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowIdentity<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
-            else if (value == T(-1)) hipLaunchKernelGGL((scalar_vec_kernel<T, PowReciprocal<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
-            else hipLaunchKernelGGL((scalar_vec_kernel<T, PowSqrt<T>, kBlockSmall, false>), g, b, 0, s, pa, value, po, n_vec, tail, stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)}));
+            int rc;
+            if (value == T(2)) rc = launch_scalar_stream<T, PowSquare<T>, false>(pa, value, po, n_vec, tail, s);
+            else if (value == T(1)) rc = launch_scalar_stream<T, PowIdentity<T>, false>(pa, value, po, n_vec, tail, s);
+            else if (value == T(-1)) rc = launch_scalar_stream<T, PowReciprocal<T>, false>(pa, value, po, n_vec, tail, s);
+            else rc = launch_scalar_stream<T, PowSqrt<T>, false>(pa, value, po, n_vec, tail, s);
+            if (rc) return rc;
             SMHIP_LAUNCH_CHECK("array_scalar pow (exact form)");
             return SMHIP_OK;
+        }
+        if constexpr (std::is_same<T, double>::value) {
+            int m2;
+            static const int max_m2 = [] { const char *e = getenv("SMHIP_POW_HALFINT_MAX"); return e && *e ? atoi(e) : 16; }();  // tools/pow64_halfint.py
+            if (smpow64::halfint_exponent(value, &m2) && (m2 < 0 ? -m2 : m2) <= max_m2 && m2 != -15) {  // -7.5: the one chain slower than exp(s log a) (213.6 against 197.6 us)
+                // sm_pow64.h: pow_halfint_n.  Through the one-shot tile form like the general pow (three vectors per lane; with
+                // one vector per lane the chain's latency adds to the load's: 189.7 us, no faster than exp(s log a)), one kernel
+                // per exponent (with a run-time exponent the chain is a loop with branches: 174-218 us).  N = 2^26, random
+                // bases (tools/pow64_halfint.py, profiles/r03_pow64_halfint.txt): pow(a, 2.5) 193.8 -> 168.2 us (69.3 -> 79.8 %
+                // of HBM peak), integers 166.6-169.9 us, a * 2.5 on the same box 165.4 us.
+                if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
+                const double *none = nullptr;
+                switch (m2) {
+#define SMHIP_HALFINT_CASE(M) case M: launch_heavy<double, PowHalfInt64<M>, 1>(pa, none, value, po, n_vec, tail, s); break;
+                    SMHIP_HALFINT_CASE(-16) SMHIP_HALFINT_CASE(-14) SMHIP_HALFINT_CASE(-13) SMHIP_HALFINT_CASE(-12) SMHIP_HALFINT_CASE(-11)
+                    SMHIP_HALFINT_CASE(-10) SMHIP_HALFINT_CASE(-9) SMHIP_HALFINT_CASE(-8) SMHIP_HALFINT_CASE(-7) SMHIP_HALFINT_CASE(-6) SMHIP_HALFINT_CASE(-5)
+                    SMHIP_HALFINT_CASE(-4) SMHIP_HALFINT_CASE(-3) SMHIP_HALFINT_CASE(-2) SMHIP_HALFINT_CASE(-1) SMHIP_HALFINT_CASE(1) SMHIP_HALFINT_CASE(2)
+                    SMHIP_HALFINT_CASE(3) SMHIP_HALFINT_CASE(4) SMHIP_HALFINT_CASE(5) SMHIP_HALFINT_CASE(6) SMHIP_HALFINT_CASE(7) SMHIP_HALFINT_CASE(8)
+                    SMHIP_HALFINT_CASE(9) SMHIP_HALFINT_CASE(10) SMHIP_HALFINT_CASE(11) SMHIP_HALFINT_CASE(12) SMHIP_HALFINT_CASE(13) SMHIP_HALFINT_CASE(14)
+                    SMHIP_HALFINT_CASE(15) SMHIP_HALFINT_CASE(16)
+#undef SMHIP_HALFINT_CASE
+                    default: return fail(SMHIP_ERR_INVALID, "half-integer exponent out of range");
+                }
+                SMHIP_LAUNCH_CHECK("array_scalar pow (half-integer exponent)");
+                return SMHIP_OK;
+            }
         }
     }
     constexpr bool kHeavy = IsHeavy<Op>::value;
@@ -487,23 +536,7 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
         launch_heavy<T, Op, SWAPPED ? 2 : 1>(pa, static_cast<const T *>(nullptr), value, po, n_vec, tail, s);
     } else {
-        // one read + one write stream: workgroups of 256 at every size (tools/sweep_scalar.hip, profiles/r01_sweep_scalar.txt:
-        // 81.7 % of peak at N = 2^28 against 78.7 % with 1024, and two or more vectors per lane lose 4-10 %)
-        const int pol = stream_policy({{pa, n * sizeof(T)}}, {po, n * sizeof(T)});
-        if (const size_t piece = piece_for(n_vec, 2)) {  // large: several launches (internal.h: piece_for)
-            for (size_t v0 = 0;; v0 += piece) {
-                const bool last = v0 + piece >= n_vec;
-                const size_t nv = last ? n_vec - v0 : piece;
-                if (int rc = grid_for(nv + (last && tail ? 1 : 0), kBlockSmall, &grid)) return rc;
-                hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa + v0 * W, value, po + v0 * W, nv,
-                                   last ? tail : 0, pol);
-                if (last) break;
-            }
-            SMHIP_LAUNCH_CHECK("array_scalar");
-            return SMHIP_OK;
-        }
-        if (int rc = grid_for(threads, kBlockSmall, &grid)) return rc;
-        hipLaunchKernelGGL((scalar_vec_kernel<T, Op, kBlockSmall, SWAPPED>), dim3(grid), dim3(kBlockSmall), 0, s, pa, value, po, n_vec, tail, pol);
+        if (int rc = launch_scalar_stream<T, Op, SWAPPED>(pa, value, po, n_vec, tail, s)) return rc;
     }
     SMHIP_LAUNCH_CHECK("array_scalar");
     return SMHIP_OK;

@@ -336,6 +336,20 @@ template <> struct OpCtx<PowBanked> {
     }
 };
 
+// sm::pow(a, s) on doubles with s a multiple of one half, |s| <= 8: a double-double product chain instead of exp(s log a)
+// (sm_pow64.h: pow_halfint_n) -- no table, and with the exponent a template parameter no branch either.  M2 = 2 s.  Only
+// launched by contiguous.hip's array-scalar form (run_scalar), through the one-shot tile kernel.
+template <int M2> struct PowHalfInt64 {
+    static __device__ __forceinline__ double apply(double a, double) {
+        const double xs[1] = {a};
+        double r[1];
+        smpow64::pow_halfint_n<1, M2>(xs, M2, r);
+        return r[0];
+    }
+};
+template <typename Op> struct HalfIntOf { static constexpr int value = 0; };
+template <int M2> struct HalfIntOf<PowHalfInt64<M2>> { static constexpr int value = M2; };
+
 // apply_simd's role: the Op across W independent elements held in registers.
 // PowOp<float> evaluates them side by side (one constant per polynomial step,
 // no branches); every other Op is one instruction per element.
@@ -347,6 +361,8 @@ __device__ __forceinline__ void apply_n(const OpCtx<Op> &ctx, const T (&a)[W], c
         smpow64::pow_n<W>(a, b, r, ctx.logtab, ctx.exptab);
     } else if constexpr (std::is_same<Op, PowBanked>::value) {
         smpow64::pow_n<W, smpow64::TabBanked>(a, b, r, ctx.tab);
+    } else if constexpr (HalfIntOf<Op>::value != 0) {
+        smpow64::pow_halfint_n<W, HalfIntOf<Op>::value>(a, HalfIntOf<Op>::value, r);
     } else {
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);

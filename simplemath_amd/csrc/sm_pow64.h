@@ -522,4 +522,155 @@ SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W
     pow_n<W, TabAoS>(x, y, out, TabAoS{logtab, exptab});
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Scalar exponents that are a multiple of one half, |y| <= 8 (sm::pow(a, 2.5), a cube, an inverse square root ...):
+// x = m 2^e with e even when y is not an integer, so that x^y = m^y 2^(e y) with an INTEGER e y.  m^|y| is a product
+// chain in double-double arithmetic (squarings and multiplications of (hi, lo) pairs, each exact to ~2^-104; the square
+// root to ~2^-73: a seed, two Newton steps, one exact residual), a negative exponent one double-double reciprocal, and
+// the power of two goes on with v_ldexp_f64.  No table, no logarithm: ~30 vector instructions per element for y = 2.5
+// against ~65 plus five scattered LDS reads for the general form -- which makes the operator HBM-bound.  The value
+// rounded at the end is within 2^-72 of the true power, so the result is the correctly rounded power except once in
+// ~2^19 elements, where it is its neighbour: <= 1 ULP from libm's pow like the general form (tests/cpp/pow_halfint_host_check.cpp:
+// every exponent -8 ... 8 in steps of one half over the whole range of x, subnormals and the special-case lattice included).
+struct DD { double hi, lo; };
+SM_POW_FN DD dd_renorm(double p, double e) { const double hi = p + e; return DD{hi, e - (hi - p)}; }  // |e| <= |p| ulp-wise
+SM_POW_FN DD dd_sqr(DD a) {
+    const double p = a.hi * a.hi;
+    double e = SM_POW_FMA(a.hi, a.hi, -p);
+    e = SM_POW_FMA(a.hi + a.hi, a.lo, e);
+    return dd_renorm(p, e);
+}
+SM_POW_FN DD dd_mul(DD a, DD b) {
+    const double p = a.hi * b.hi;
+    double e = SM_POW_FMA(a.hi, b.hi, -p);
+    e = SM_POW_FMA(a.hi, b.lo, e);
+    e = SM_POW_FMA(a.lo, b.hi, e);
+    return dd_renorm(p, e);
+}
+// seeds good to 2^-20 or better: the device's v_rsq_f64 / v_rcp_f64; on the host a float-rounded value stands in for them
+SM_POW_FN double seed_rsq(double m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(m);
+#else
+    return (double)(float)(1.0 / sqrt(m));
+#endif
+}
+SM_POW_FN double seed_rcp(double m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(m);
+#else
+    return (double)(float)(1.0 / m);
+#endif
+}
+SM_POW_FN DD dd_sqrt(double m) {  // m in [0.5, 2)
+    const double rs = seed_rsq(m), h = 0.5 * rs;
+    double s = m * rs;
+    s = SM_POW_FMA(SM_POW_FMA(-s, s, m), h, s);
+    s = SM_POW_FMA(SM_POW_FMA(-s, s, m), h, s);
+    return DD{s, SM_POW_FMA(-s, s, m) * h};
+}
+SM_POW_FN DD dd_recip(DD a) {  // a.hi normal, far from the ends of the range
+    double q = seed_rcp(a.hi);
+    q = SM_POW_FMA(q, SM_POW_FMA(-a.hi, q, 1.0), q);
+    q = SM_POW_FMA(q, SM_POW_FMA(-a.hi, q, 1.0), q);
+    const double r = SM_POW_FMA(-a.lo, q, SM_POW_FMA(-a.hi, q, 1.0));
+    return dd_renorm(q, q * r);
+}
+// Is y one of these exponents?  *m2 = 2 y.  (y = 0 and the exponents whose power is one IEEE operation are served elsewhere.)
+SM_POW_FN bool halfint_exponent(double y, int *m2) {
+    const double t = y + y;
+    if (!(t >= -16.0 && t <= 16.0) || t != SM_POW_RINT(t) || t == 0.0) return false;
+    *m2 = (int)t;
+    return true;
+}
+// W bases held in registers, one exponent: the control flow depends on the exponent alone.
+// CM2 != 0: the exponent (times two) as a compile-time constant -- the chain becomes straight-line code and the compiler
+// interleaves the W (and the caller's U x W) independent chains; this is the form the kernels use (one instantiation per
+// exponent).  With a run-time exponent the same code is a loop with branches: pow(a, 2.5) at N = 2^26 174 us against
+// 218 us with wave-uniform branches per element and 183 us with the W chains inside one pass of the branches.
+template <int W, int CM2 = 0>
+SM_POW_FN void pow_halfint_n(const double (&x)[W], int m2, double (&out)[W]) {
+    if (CM2 != 0) m2 = CM2;
+    const int am = m2 < 0 ? -m2 : m2, n = am >> 1;
+    const bool half = (am & 1) != 0, neg_y = m2 < 0;
+    double ax[W], m[W];
+    int e[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        ax[w] = bits_f64(f64_bits(x[w]) & 0x7fffffffffffffffULL);
+#if defined(__HIP_DEVICE_COMPILE__)
+        m[w] = __builtin_amdgcn_frexp_mant(ax[w]);  // [0.5, 1), subnormals included
+        e[w] = __builtin_amdgcn_frexp_exp(ax[w]);
+#else
+        m[w] = frexp(ax[w], &e[w]);
+#endif
+        if (half) {  // an even e for half-integer exponents: m in [0.5, 2)
+            const int adj = e[w] & 1;
+            m[w] = adj ? m[w] + m[w] : m[w];
+            e[w] -= adj;
+        }
+    }
+    // m^n: square-and-multiply over the bits of n
+    DD b[W], p[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { b[w] = DD{m[w], 0.0}; p[w] = DD{1.0, 0.0}; }
+    bool have = false;
+    for (int k = n; k; k >>= 1) {
+        if (k & 1) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) p[w] = have ? dd_mul(p[w], b[w]) : b[w];
+            have = true;
+        }
+        if (k >> 1) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) b[w] = dd_sqr(b[w]);
+        }
+    }
+    if (half) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) { const DD s = dd_sqrt(m[w]); p[w] = have ? dd_mul(p[w], s) : s; }
+    }
+    if (neg_y) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) p[w] = dd_recip(p[w]);
+    }
+    const double inf = bits_f64(0x7ff0000000000000ULL);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int scale = (e[w] * m2) / 2;  // exact: e is even whenever m2 is odd
+#if defined(__HIP_DEVICE_COMPILE__)
+        double r = __builtin_ldexp(p[w].hi + p[w].lo, scale);
+#else
+        double r = ldexp(p[w].hi + p[w].lo, scale);
+#endif
+        // zeros, infinities, negative bases (C99 F.9.4.4); NaN went through the arithmetic
+        const bool x_zero = ax[w] == 0.0, x_inf = ax[w] == inf, x_neg = (f64_bits(x[w]) >> 63) != 0;
+        r = x_zero ? (neg_y ? inf : 0.0) : r;
+        r = x_inf ? (neg_y ? 0.0 : inf) : r;
+        if (!half) r = (x_neg && (n & 1)) ? -r : r;                                          // integer exponent: the sign of an odd power
+        else r = (x_neg && !x_zero && !x_inf) ? bits_f64(0x7ff8000000000000ULL) : r;           // a negative base to a fractional power
+        out[w] = r;
+    }
+}
+SM_POW_FN double pow_halfint(double x, int m2) {
+    const double xs[1] = {x};
+    double r[1];
+    pow_halfint_n<1>(xs, m2, r);
+    return r[0];
+}
+// the compile-time forms by run-time exponent (host check; a kernel's scalar tail)
+template <int LO, int HI>
+SM_POW_FN double pow_halfint_switch(double x, int m2) {
+    if constexpr (LO == HI) {
+        const double xs[1] = {x};
+        double r[1];
+        pow_halfint_n<1, LO == 0 ? 1 : LO>(xs, m2, r);
+        return r[0];
+    } else {
+        constexpr int MID = LO + (HI - LO) / 2;
+        return m2 <= MID ? pow_halfint_switch<LO, MID>(x, m2) : pow_halfint_switch<MID + 1, HI>(x, m2);
+    }
+}
+
 }  // namespace smpow64

@@ -217,6 +217,32 @@ def test_pow_exact_exponents(smhip, oracle):
             assert ulp(got[ok], lib[ok]).max() <= 1, (np.dtype(dt), y)
 
 
+def test_pow_f64_half_integer_exponents(smhip, oracle):
+    """sm::pow(a, s) on doubles with s a multiple of one half, |s| <= 8: the double-double product chain of sm_pow64.h
+    (pow_halfint) instead of exp(s log a).  Every such exponent against libm's pow (the reference's PowOp<double>::apply,
+    pow.h:8-10): <= 1 ULP, NaNs in the same places, zeros and infinities with the same sign -- over mixed-sign values,
+    subnormals, values whose power overflows or underflows, and the special values; odd tails included."""
+    a = np.concatenate([gen.gen(np.float64, 6001, 111, "mixed"), gen.gen(np.float64, 4000, 112, "positive"),
+                        np.exp2(np.linspace(-1074, 1023, 4003)), -np.exp2(np.linspace(-300, 300, 1001)),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 4.0, 5e-324, -5e-324, 1e-310, 1.7976931348623157e308,
+                                  -1.7976931348623157e308, 2.2250738585072014e-308], dtype=np.float64)])
+    da = smhip.to_device(a)
+    for m2 in range(-16, 17):
+        if m2 == 0:
+            continue
+        y = np.float64(m2 * 0.5)
+        got = smhip.array_scalar(sma.OP_POW, da, y).numpy()
+        with np.errstate(all="ignore"):
+            want = oracle.array_scalar(orc.POW, a, y)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), y
+        ok = ~np.isnan(want)
+        same_kind = ((got[ok] == 0) == (want[ok] == 0)) & (np.isinf(got[ok]) == np.isinf(want[ok]))
+        # a power that libm rounds to 0 / the smallest subnormal (or to inf / the largest double) may differ by that one ULP
+        assert orc.ulp_diff_f64(got[ok], want[ok]).max() <= 1, (y, a[ok][np.argmax(orc.ulp_diff_f64(got[ok], want[ok]))])
+        assert np.array_equal(np.signbit(got[ok]), np.signbit(want[ok])), y
+        assert same_kind.mean() > 0.999, y
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64", "i32", "i64"])
 def test_array_scalar_vs_oracle(smhip, oracle, dt):
     for op in ("add", "sub", "mul", "div"):

@@ -26,3 +26,16 @@ def test_pow64_algorithm_on_host():
     assert m and int(m.group(2)) > 3_500_000
     assert int(m.group(1)) <= 1, out
     assert "lattice_mismatches 0" in out, out
+
+
+def test_pow64_half_integer_exponents_on_host():
+    """smpow64::pow_halfint (scalar exponents -8 ... 8 in steps of one half: a double-double product chain, no table)
+    against glibc pow over 8.8 M bases from the whole range, negative bases and the zero / infinity / NaN lattice."""
+    from simplemath_amd import build
+    exe = build.build_host_programs()["pow_halfint_host_check"]
+    out = subprocess.run([exe, "300000"], capture_output=True, text=True, check=True, timeout=300).stdout
+    m = re.search(r"max_ulp (\d+) over (\d+) identical ([0-9.]+)", out)
+    assert m and int(m.group(2)) > 8_000_000
+    assert int(m.group(1)) <= 1, out
+    assert float(m.group(3)) > 0.999, out
+    assert "lattice_mismatches 0" in out, out
