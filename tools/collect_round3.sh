@@ -12,12 +12,13 @@ for wl in bcast_mul pow add_sum; do
   f=$(find $src/prof_${wl}_cold -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -rn | head -1 | cut -d" " -f2-); [ -n "$f" ] && cp "$f" ${pre}_${wl}_cold_kernel_stats.csv
 done
 cp $src/bench_add_single.json ${pre}_bench_add_single.json
+[ -s $src/bench_torchrun1.json ] && cp $src/bench_torchrun1.json ${pre}_bench_torchrun1.json
 cp $src/traffic.json ${pre}_pmc_traffic.json
 cp $src/traffic.json profiles/traffic_latest.json
 cp $src/pmc_sq.txt ${pre}_pmc_sq_cycles.txt
 cp $src/cpp_benchmarks.txt ${pre}_cpp_benchmarks.txt
 for t in op_matrix bcast_matrix reduce_rates misc_rates pow_shapes pow_exhaustive chain_rates pow64_rate cold_rates cold_rates_size_rule sweep_cold \
-         sweep_anyorder big_add sweep_vmm pmc_vmm sweep_distance sweep_fused2; do
+         sweep_anyorder big_add sweep_vmm pmc_vmm sweep_distance sweep_fused2 tile_shapes_auto tile_shapes_f64; do
   [ -s $src/$t.txt ] && cp $src/$t.txt ${pre}_$t.txt
 done
 # the cold-operand counter table: the summary lines only (the pass log above them is scratch)

@@ -17,6 +17,8 @@ if [ "$part" = a ]; then
   timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log
   timeout -k 10 300 python bench.py > $out/bench_add.json 2> $out/bench_add.err; echo "bench rc=$?"; cut -c1-400 $out/bench_add.json
   timeout -k 10 300 python bench.py --gpus 1 --mode single --no-cpu-baseline > $out/bench_add_single.json 2> $out/bench_add_single.err; echo "bench single rc=$?"
+  # the driver's N > 1 launch line with one rank: torch.distributed over RCCL + libsmhip's communicator
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --configs none > $out/bench_torchrun1.json 2> $out/bench_torchrun1.err; echo "bench torchrun rc=$?"
   for wl in bcast_mul pow add_sum transpose_add; do
     timeout -k 10 200 python bench.py --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err; echo "bench $wl rc=$?"
   done
@@ -45,6 +47,8 @@ else
   timeout -k 10 100 python tools/pow_shapes.py > $out/pow_shapes.txt 2>&1
   timeout -k 10 200 python tools/chain_rates.py > $out/chain_rates.txt 2>&1
   timeout -k 10 200 python tools/pow64_rate.py > $out/pow64_rate.txt 2>&1
+  timeout -k 10 110 python tools/tile_shapes.py - > $out/tile_shapes_auto.txt 2>&1
+  timeout -k 10 110 python tools/tile_shapes.py - f64 > $out/tile_shapes_f64.txt 2>&1
   echo "matrices done"
   timeout -k 10 200 python tools/cold_rates.py > $out/cold_rates.txt 2>&1; cat $out/cold_rates.txt
   SMHIP_RESIDENCY=off timeout -k 10 200 python tools/cold_rates.py > $out/cold_rates_size_rule.txt 2>&1

@@ -1,5 +1,5 @@
 """out(P, Q) = A.T + B with A of shape (Q, P): the LDS tile kernel over rectangular shapes, replayed and (where four operand sets fit in 40 GiB) cold.
-python tools/tile_shapes.py [library|-] [fine]   -- tools/tile_variants.sh builds libraries that differ in the patch walk and q extent."""
+python tools/tile_shapes.py [library|-] [fine|f64]   -- tools/tile_variants.sh builds libraries that differ in the patch walk and q extent."""
 import sys, ctypes as C
 sys.path.insert(0, "/root/repo")
 import numpy as np
@@ -19,20 +19,27 @@ def timeit(fn, steps=10):
         res.append(lib.elapsed_ms(e0, e1) / steps * 1000)
     return sorted(res)[1]
 f32 = C.c_int(0)
+F64 = len(sys.argv) > 2 and sys.argv[2] == "f64"   # doubles: 64 x 64 (512 B) and 64 x 128 (1024 B) patches
+DT, ESZ = (C.c_int(1), 8) if F64 else (f32, 4)
 SHAPES = ((4096, 4096), (2048, 32768), (32768, 2048), (4096, 16384), (16384, 4096), (8192, 8192), (6144, 16384), (16384, 6144), (10240, 10240),
           (8192, 16384), (16384, 8192), (12288, 12288), (4096, 65536), (65536, 4096), (16384, 16384), (8192, 65536), (65536, 8192))
+if F64:
+    SHAPES = ((4096, 4096), (4096, 8192), (8192, 4096), (6144, 6144), (8192, 8192), (4096, 32768), (32768, 4096), (12288, 12288))
 if len(sys.argv) > 2 and sys.argv[2] == "fine":   # around the size where the wide patch takes over
     SHAPES = ((6144, 8192), (8192, 6144), (8192, 8192), (8192, 8704), (8704, 8192), (9216, 9216), (8192, 10240), (10240, 8192), (9728, 9728), (4096, 20480), (20480, 4096),
               (10240, 10240), (8192, 12288), (12288, 8192), (11264, 11264), (2048, 65536), (65536, 2048))
 for P, Q in SHAPES:
     n = P * Q
-    nsets = 4 if 12 * n * 4 <= 40 << 30 else 1
-    sets = [(lib.uniform_f32(n, 1 + k, -1, 1), lib.uniform_f32(n, 9 + k, -1, 1), lib.empty((n,), np.float32)) for k in range(nsets)]
+    nsets = 4 if 12 * n * ESZ <= 40 << 30 else 1
+    if F64:
+        sets = [(lib.full((n,), 1.5 + k, np.float64), lib.full((n,), 2.5 + k, np.float64), lib.empty((n,), np.float64)) for k in range(nsets)]
+    else:
+        sets = [(lib.uniform_f32(n, 1 + k, -1, 1), lib.uniform_f32(n, 9 + k, -1, 1), lib.empty((n,), np.float32)) for k in range(nsets)]
     state = [0]
     def one(rotate):
         A, B, out = sets[state[0] % nsets if rotate else 0]; state[0] += 1
-        lib.c.smhip_elementwise(C.c_int(0), f32, C.c_void_p(A.ptr), i64([1, P]), C.c_void_p(B.ptr), i64([Q, 1]), i64([P, Q]), C.c_int(2), C.c_void_p(out.ptr))
+        lib.c.smhip_elementwise(C.c_int(0), DT, C.c_void_p(A.ptr), i64([1, P]), C.c_void_p(B.ptr), i64([Q, 1]), i64([P, Q]), C.c_int(2), C.c_void_p(out.ptr))
     t = timeit(lambda: one(False))
     tc = timeit(lambda: one(True), 12) if nsets > 1 else float("nan")
-    print("out %5d x %5d  %6.0f MiB/operand  replay %8.1f us %5.1f %%   cold %8.1f us %5.1f %%" % (P, Q, n * 4 / 2**20, t, 12.0 * n / t * 1e-3 / 80, tc, 12.0 * n / tc * 1e-3 / 80), flush=True)
+    print("out %5d x %5d  %6.0f MiB/operand  replay %8.1f us %5.1f %%   cold %8.1f us %5.1f %%" % (P, Q, n * ESZ / 2**20, t, 3.0 * ESZ * n / t * 1e-3 / 80, tc, 3.0 * ESZ * n / tc * 1e-3 / 80), flush=True)
     del sets; lib.pool_trim()
