@@ -37,10 +37,13 @@ for c in cases:
         for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
             rows = list(csv.DictReader(open(f)))
             if not rows: continue
-            kern = max(rows, key=lambda r: int(r["Dispatch_Id"]))["Kernel_Name"]  # the case's kernel is the last one launched
+            # the case's kernel is the last one launched; its cold and its replayed launches may be different instantiations
+            # (config 3's shape takes one vector per lane cold, two replayed), so launches are matched by the function's name
+            base = lambda name: name.split("<")[0]
+            kern = base(max(rows, key=lambda r: int(r["Dispatch_Id"]))["Kernel_Name"])
             per = collections.defaultdict(list); dur = {}
             for r in rows:
-                if r["Kernel_Name"] != kern: continue
+                if base(r["Kernel_Name"]) != kern: continue
                 per[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 dur[int(r["Dispatch_Id"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
             if not seen_dur:
