@@ -24,7 +24,10 @@ for n in ((1 << 14) * 4 * 3 + 5, (1 << 14) * 4 * 2, (1 << 14) * 4 + 1, (1 << 14)
     res[tag + "/user_s"] = lib.array_scalar(user, a, np.float32(3.0)).numpy()
     ha, hb = a.numpy(), b.numpy()
     d64a, d64b = lib.to_device(ha.astype(np.float64)), lib.to_device(hb.astype(np.float64))
-    res[tag + "/pow64_s"] = lib.array_scalar(sma.OP_POW, d64a, np.float64(2.5)).numpy()
+    res[tag + "/pow64_s"] = lib.array_scalar(sma.OP_POW, d64a, np.float64(2.5)).numpy()    # the double-double product chain
+    res[tag + "/pow64_g"] = lib.array_scalar(sma.OP_POW, d64a, np.float64(2.7)).numpy()    # the general form
+    res[tag + "/pow64_sq"] = lib.array_scalar(sma.OP_POW, d64a, np.float64(2.0)).numpy()   # a single IEEE operation
+    res[tag + "/pow_rsqrt"] = lib.array_scalar(sma.OP_POW, d64a, np.float64(-0.5)).numpy()
     res[tag + "/add64"] = lib.contiguous(sma.OP_ADD, d64a, d64b).numpy()
     ia = lib.to_device((ha * 1000).astype(np.int32))
     ib = lib.to_device((hb * 1000).astype(np.int32))
