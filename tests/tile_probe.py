@@ -42,6 +42,27 @@ for t in range(36):
             print("MISMATCH", t, dtn, opn, dims, kind, int((got != want).sum()))
             sys.exit(1)
         cases += 1
+# pow through the tile kernel: its tables share the LDS with the patch (2 / 5 KiB next to 33 / 66 KiB)
+for dt, bar in ((np.float32, 1), (np.float64, 1)):
+    for dims in ((512, 768), (300, 260)):
+        base = rng.uniform(0.05, 30.0, dims).astype(dt)
+        e = rng.uniform(-3.0, 3.0, dims[::-1]).astype(dt)
+        db_, de_ = smhip.to_device(base), smhip.to_device(e)
+        for va, vb, ba, bb in ((base.T, e, base, e), (base.T, e.T.copy().T, base, None)):
+            if bb is None:  # both operands turned: e stored transposed
+                et = np.ascontiguousarray(e.T)
+                det = smhip.to_device(et)
+                got = smhip.binary(sma.OPS["pow"], db_.view_like(base.T, base), det.view_like(et.T, et)).numpy()
+            else:
+                got = smhip.binary(sma.OPS["pow"], db_.view_like(base.T, base), de_).numpy()
+            with np.errstate(all="ignore"):
+                exact = np.power(base.T.astype(np.longdouble), e.astype(np.longdouble)).astype(dt)
+            it = np.int32 if dt == np.float32 else np.int64
+            d = np.abs(got.view(it).astype(np.int64) - exact.view(it).astype(np.int64))
+            if d.max() > bar:
+                print("MISMATCH pow", np.dtype(dt), dims, int(d.max()))
+                sys.exit(1)
+            cases += 1
 if len(sys.argv) > 1 and sys.argv[1] == "big":
     # 8704 x 8192 f32 = 272 MiB per array: past the Infinity Cache, so the unforced library takes the wide patch
     P, Q = 8704, 8192
