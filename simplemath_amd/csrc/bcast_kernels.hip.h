@@ -481,9 +481,11 @@ __device__ __forceinline__ void dense_lds_body(const T *__restrict__ x, const T 
 #define SMHIP_TILE_BOTH_CHUNK 8
 #endif
 constexpr int kTileP = 64;
-// Bytes of one patch row along q: 512 (`QB` default), or 1024 for the WIDE patch that launches over arrays beyond the
-// Infinity Cache take together with a row-major walk (TileParams::order 0) -- see plan_launch() and DESIGN.md section 3.
-constexpr int kTileQBytes = 512, kTileQBytesWide = 1024;
+// Bytes of one patch row along q: 512 (`QB` default); 1024 for the WIDE patch that launches over arrays beyond the
+// Infinity Cache take together with a row-major walk (TileParams::order 0); 128 for the SHORT patch of planes whose q extent
+// is a few dozen elements (out (4194304, 32) = a.T + b: a 512-byte patch row is three quarters empty there) -- see
+// plan_launch() and DESIGN.md section 3.
+constexpr int kTileQBytes = 512, kTileQBytesWide = 1024, kTileQBytesShort = 128;
 template <typename T, int QB = kTileQBytes> constexpr int tile_q() { return QB / (int)sizeof(T); }
 
 struct TileParams {

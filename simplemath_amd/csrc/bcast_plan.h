@@ -29,7 +29,7 @@ struct Launch {
     bool ca, cb;            // row: CONST_A / CONST_B
     bool swapped;           // lds: the streamed operand is the Op's right one
     bool vec;               // tile: 16-byte form
-    bool wide;              // tile: 1024-byte patch rows (kTileQBytesWide), row-major walk
+    int qb;                 // tile: bytes of one patch row (kTileQBytes, or kTileQBytesWide with the row-major walk, or kTileQBytesShort)
     int ma, mb;             // tile: LDS-mode operands (compile-time in the 16-byte form)
     int w;                  // gather: outputs per lane
                             // strided rows: ia / ib are the inner strides (0..4)

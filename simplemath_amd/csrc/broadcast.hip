@@ -251,12 +251,24 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             TileParams &t = L->p.tile;
             t = TileParams{};
             const bool vec = pl.shape[paxis] % W == 0 && inner % W == 0;
-            // The patch and its walk.  Up to the Infinity Cache's size per array: 64 x 512 B patches along a diagonal.
-            // Beyond: 64 x 1024 B patches, row-major, so that the workgroups in flight together write (and read the
-            // direct operand in) whole rows of the output -- tools/tile_shapes.py, profiles/r03_tile_shapes.txt.
-            static const int forced = [] { const char *e = getenv("SMHIP_TILE_WIDE"); return e && *e ? atoi(e) : -1; }();
-            const bool wide = vec && (forced >= 0 ? forced != 0 : pl.n * (size_t)esz > kInfinityCacheBytes);
-            const int tq = (wide ? kTileQBytesWide : kTileQBytes) / esz;  // tile_q<T, QB>()
+            // The patch and its walk (tools/tile_shapes.py, profiles/r03_tile_shapes.txt).  Up to the Infinity Cache's size per
+            // array: 64 x 512 B patches along a diagonal.  Beyond: 64 x 1024 B patches, row-major, so that the workgroups in
+            // flight together write (and read the direct operand in) whole rows of the output -- where both plane extents
+            // give that patch and its walk something to work with: skinny planes lose badly ((4194304, 32): 40 -> 15 %,
+            // (1048576, 128): 77 -> 38 %, (256, 524288): 71 -> 63 %; from 512 x 512 on the two are level).  A q extent of at
+            // most 256 bytes: 64 x 128 B patches ((4194304, 32): 40 -> 78 %, (2097152, 16): 33 -> 82 %).
+            // SMHIP_TILE_QB = 128 / 512 / 1024 forces one (tests, sweeps); SMHIP_TILE_WIDE = 0 / 1 is the older spelling of 512 / 1024.
+            static const int forced = [] {
+                if (const char *e = getenv("SMHIP_TILE_QB"); e && *e) { const int v = atoi(e); return v == kTileQBytesShort || v == kTileQBytesWide ? v : kTileQBytes; }
+                if (const char *e = getenv("SMHIP_TILE_WIDE"); e && *e) return atoi(e) != 0 ? kTileQBytesWide : kTileQBytes;
+                return 0;
+            }();
+            const bool roomy = pl.shape[paxis] >= 512 && inner * esz >= 2 * kTileQBytesWide;
+            const int qb = !vec ? kTileQBytes
+                         : forced ? forced
+                         : inner * esz <= 2 * kTileQBytesShort ? kTileQBytesShort
+                         : roomy && pl.n * (size_t)esz > kInfinityCacheBytes ? kTileQBytesWide : kTileQBytes;
+            const int tq = qb / esz;  // tile_q<T, QB>()
             t.np = (uint32_t)pl.shape[paxis];
             t.nq = (uint32_t)inner;
             t.a_p = pl.sa[paxis]; t.a_q = ia;
@@ -293,9 +305,9 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                 // the 16-byte form needs whole vectors along both plane axes; bases and pitches may be anything
                 L->kind = Launch::kTile;
                 L->vec = vec;
-                L->wide = wide;
+                L->qb = qb;
                 static const int forced_order = [] { const char *e = getenv("SMHIP_TILE_ORDER"); return e && *e ? atoi(e) : -1; }();
-                t.order = forced_order >= 0 ? (forced_order != 0) : wide ? 0 : 1;  // SMHIP_TILE_ORDER: for tools/tile_variants.sh
+                t.order = forced_order >= 0 ? (forced_order != 0) : qb == kTileQBytesWide ? 0 : 1;  // SMHIP_TILE_ORDER: for tools/tile_variants.sh
                 L->ma = L->vec ? t.mode_a : 0;
                 L->mb = L->vec ? t.mode_b : 0;
                 L->grid = (unsigned)blocks;
@@ -425,13 +437,17 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
             return SMHIP_OK;
         case Launch::kTile:
             if (!L.vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
-            else if (L.wide) {
-                if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1, kTileQBytesWide>), grid, block, 0, s, a, b, out, L.p.tile);
-                else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0, kTileQBytesWide>), grid, block, 0, s, a, b, out, L.p.tile);
-                else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1, kTileQBytesWide>), grid, block, 0, s, a, b, out, L.p.tile);
-            } else if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
-            else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
-            else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
+            else {
+                auto go = [&](auto qb_tag) {
+                    constexpr int QB = decltype(qb_tag)::value;
+                    if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1, QB>), grid, block, 0, s, a, b, out, L.p.tile);
+                    else if (L.ma == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 0, QB>), grid, block, 0, s, a, b, out, L.p.tile);
+                    else hipLaunchKernelGGL((tile_kernel<T, Op, true, 0, 1, QB>), grid, block, 0, s, a, b, out, L.p.tile);
+                };
+                if (L.qb == kTileQBytesWide) go(std::integral_constant<int, kTileQBytesWide>{});
+                else if (L.qb == kTileQBytesShort) go(std::integral_constant<int, kTileQBytesShort>{});
+                else go(std::integral_constant<int, kTileQBytes>{});
+            }
             SMHIP_LAUNCH_CHECK("tile_kernel");
             return SMHIP_OK;
         case Launch::kStrided: {
@@ -616,6 +632,201 @@ int run_short_rows(const void *x, const void *y, void *out, size_t rows, uint32_
     if (swapped) hipLaunchKernelGGL((short_rows_kernel<T, Op, true>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n, nt);
     else hipLaunchKernelGGL((short_rows_kernel<T, Op, false>), grid, block, 0, s, static_cast<const T *>(x), static_cast<const T *>(y), static_cast<T *>(out), FastDiv(r), n_vec, (uint32_t)n, nt);
     SMHIP_LAUNCH_CHECK("short_rows_kernel");
+    return SMHIP_OK;
+}
+
+// ------------------------------------------------------------------ record kernel (AoS <-> SoA)
+// A 2-D plane with one TINY extent k and one long extent n, one operand "turned" (its contiguous axis is the other one):
+//   SMALL_P:  out (k, n) = t.T op o  with t stored dense (n, k)  -- records of k elements become k rows   (AoS -> SoA)
+//   !SMALL_P: out (n, k) = t.T op o  with t stored (k, n)        -- k rows become records of k elements   (SoA -> AoS)
+// The tile kernel wants both plane extents >= 16 and wastes most of a 64-row patch on a small one ((32, 4194304): 61 %,
+// (16, 4194304): 47 %); below 16 the gather kernel walked these planes at 18-58 % (tools/tile_shapes.py tiny,
+// profiles/r03_tile_skinny.txt).  Here a workgroup takes R records.  The side whose memory is ONE contiguous run of R * k
+// elements (t for SMALL_P, out and a dense o otherwise) moves as flat 16-byte vectors whatever k is (3, 5, 12 ...); the
+// other side moves as 16-byte vectors along its k row segments of R elements; in between sits an LDS tile [k][R] (the
+// tile kernel's column skew), written and read element-wise.  R * k <= 8192 four-byte (4096 eight-byte) elements, R a
+// multiple of 64: every lane owns eight vector slots on either side, slots past the chunk re-read its last vector
+// (clamped index) so that no branch sits between the loads, and only their LDS writes / stores are guarded.  The last,
+// partial chunk goes element-wise.  `o` is dense in the plane or ONE value (copies: SMHIP_OP_LEFT).
+struct RecordParams {
+    uint32_t k, R, pitch; // elements per record, records per workgroup, words between the k rows of the LDS tile
+    uint64_t n;           // records
+    FastDiv kdiv, vrdiv;  // / k;  / (R / W): vectors per row segment
+    int64_t t_pitch;      // !SMALL_P: distance between the k rows of t (SMALL_P: t is dense, record r at r * k)
+    int64_t o_pitch;      // SMALL_P: distance between the k rows of o (!SMALL_P: o is dense, record r at r * k)
+    int o_scalar;         // o is one value
+    uint32_t nt;
+};
+template <typename T> constexpr int record_chunk() { return 32768 / (int)sizeof(T); }  // elements per workgroup at most
+
+template <typename T, typename Op, bool SMALL_P, bool T_IS_A>
+__global__ __launch_bounds__(256) void record_kernel(const T *__restrict__ t, const T *__restrict__ o, T *__restrict__ out, RecordParams p) {
+    constexpr int W = VecTraits<T>::width, CMAX = record_chunk<T>(), S = CMAX / (W * 256);
+    typedef typename VecTraits<T>::vec_t V;
+    __shared__ T tile[CMAX + CMAX / 32 + 32 * 17];
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t k = p.k, R = p.R, PITCH = p.pitch;
+    auto at = [&](uint32_t small, uint32_t rec) -> uint32_t { return small * PITCH + rec + (rec >> 5); };
+    const uint64_t j0 = (uint64_t)blockIdx.x * R;
+    const uint32_t Rc = (uint32_t)(p.n - j0 < R ? p.n - j0 : R);
+    const T oval = p.o_scalar ? *o : T{};
+    auto apply1 = [&](T xt, T xo) { return T_IS_A ? Op::apply(xt, xo) : Op::apply(xo, xt); };
+    // flat side: the chunk's R * k elements in memory order;  row side: k segments of R elements
+    const T *tflat = t + j0 * k, *oflat = o + j0 * k;
+    T *outflat = out + j0 * k;
+    if (Rc == R) {  // a whole chunk (uniform)
+        const uint32_t NV = R * k / W;  // vectors on either side (R is a multiple of 64)
+        V tv[S], ov[S];
+        uint32_t rs[S], cs[S];  // row-side coordinates of slot s: small index, first record of its vector
+        auto issue = [&](auto nt_tag) {
+            constexpr bool NT = decltype(nt_tag)::value;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const uint32_t v = threadIdx.x + 256u * s, vc = v < NV ? v : NV - 1;
+                uint32_t i, jg;
+                p.vrdiv.divmod(vc, i, jg);
+                rs[s] = i; cs[s] = jg * W;
+                if (SMALL_P) {
+                    tv[s] = load_stream_as(T, reinterpret_cast<const V *>(tflat) + vc, NT);
+                    if (!p.o_scalar) ov[s] = load_stream_as(T, reinterpret_cast<const V *>(o + (int64_t)i * p.o_pitch + j0 + jg * W), NT);
+                } else {
+                    tv[s] = load_stream_as(T, reinterpret_cast<const V *>(t + (int64_t)i * p.t_pitch + j0 + jg * W), NT);
+                    if (!p.o_scalar) ov[s] = load_stream_as(T, reinterpret_cast<const V *>(oflat) + vc, NT);
+                }
+            }
+        };
+        if (p.nt & kLoadNt) issue(BoolTag<true>{});
+        else issue(BoolTag<false>{});
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t v = threadIdx.x + 256u * s;
+            if (v < NV) {
+                if (SMALL_P) {  // t arrived in memory order: element e of the chunk is (record e / k, index e % k)
+                    uint32_t r, i;
+                    p.kdiv.divmod(v * W, r, i);
+#pragma unroll
+                    for (int kk = 0; kk < W; ++kk) {
+                        tile[at(i, r)] = tv[s][kk];
+                        if (++i == k) { i = 0; ++r; }
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < W; ++kk) tile[at(rs[s], cs[s] + kk)] = tv[s][kk];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t v = threadIdx.x + 256u * s;
+            if (v < NV) {
+                T xt[W], xo[W], xr[W];
+                if (SMALL_P) {
+#pragma unroll
+                    for (int kk = 0; kk < W; ++kk) xt[kk] = tile[at(rs[s], cs[s] + kk)];
+                } else {
+                    uint32_t r, i;
+                    p.kdiv.divmod(v * W, r, i);
+#pragma unroll
+                    for (int kk = 0; kk < W; ++kk) {
+                        xt[kk] = tile[at(i, r)];
+                        if (++i == k) { i = 0; ++r; }
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < W; ++kk) xo[kk] = p.o_scalar ? oval : ov[s][kk];
+                if (T_IS_A) apply_n<Op, T, W>(ctx, xt, xo, xr);
+                else apply_n<Op, T, W>(ctx, xo, xt, xr);
+                V val;
+#pragma unroll
+                for (int kk = 0; kk < W; ++kk) val[kk] = xr[kk];
+                if (SMALL_P) store_stream_if(T, reinterpret_cast<V *>(out + (uint64_t)rs[s] * p.n + j0 + cs[s]), val, p.nt);
+                else store_stream_if(T, reinterpret_cast<V *>(outflat) + v, val, p.nt);
+            }
+        }
+        return;
+    }
+    // the last, partial chunk: element by element
+    const uint32_t C = Rc * k;
+    for (uint32_t e = threadIdx.x; e < C; e += 256) {
+        if (SMALL_P) {
+            const uint32_t r = e / k, i = e - r * k;
+            tile[at(i, r)] = tflat[e];
+        } else {
+            const uint32_t i = e / Rc, r = e - i * Rc;
+            tile[at(i, r)] = t[(int64_t)i * p.t_pitch + j0 + r];
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < C; e += 256) {
+        if (SMALL_P) {
+            const uint32_t i = e / Rc, r = e - i * Rc;
+            const T xo = p.o_scalar ? oval : o[(int64_t)i * p.o_pitch + j0 + r];
+            out[(uint64_t)i * p.n + j0 + r] = apply1(tile[at(i, r)], xo);
+        } else {
+            const uint32_t r = e / k, i = e - r * k;
+            const T xo = p.o_scalar ? oval : oflat[e];
+            outflat[e] = apply1(tile[at(i, r)], xo);
+        }
+    }
+}
+
+// Does the normalised plane fit the record kernel?  Fills the parameters and says which operand is the turned one.
+inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p, bool *t_is_a) {
+    static const bool off = [] { const char *e = getenv("SMHIP_RECORD_KERNEL"); return e && atoi(e) == 0 && *e; }();  // tools: SMHIP_RECORD_KERNEL=0
+    if (off || pl.ndim != 2) return false;
+    const int64_t P = pl.shape[0], Q = pl.shape[1];
+    const int W = 16 / esz, cmax = 32768 / esz;
+    auto turned = [&](const int64_t *st) { return st[0] == 1 && st[1] >= P && P > 1; };              // contiguous along dim 0
+    auto direct = [&](const int64_t *st) { return st[1] == 1 && st[0] >= Q; };                         // contiguous along dim 1
+    auto scalar = [&](const int64_t *st) { return st[0] == 0 && st[1] == 0; };
+    const bool ta = turned(pl.sa) && (direct(pl.sb) || scalar(pl.sb)), tb = turned(pl.sb) && (direct(pl.sa) || scalar(pl.sa));
+    if (ta == tb) return false;
+    const int64_t *st = ta ? pl.sa : pl.sb, *so = ta ? pl.sb : pl.sa;
+    *t_is_a = ta;
+    RecordParams r{};
+    r.o_scalar = scalar(so) ? 1 : 0;
+    if (P <= 32 && Q >= 4096 && st[1] == P) {            // few long rows out of dense records: AoS -> SoA
+        *small_p = true;
+        r.k = (uint32_t)P; r.n = (uint64_t)Q;
+        r.o_pitch = so[0];
+    } else if (Q < 16 && P >= 4096 && (r.o_scalar || so[0] == Q)) {  // records out of few long rows: SoA -> AoS (16 and up: the tile kernel's short patch)
+        *small_p = false;
+        r.k = (uint32_t)Q; r.n = (uint64_t)P;
+        r.t_pitch = st[1];
+    } else {
+        return false;
+    }
+    r.R = (uint32_t)(cmax / (int64_t)r.k) / 64 * 64;
+    if (r.R < 64 || r.n / r.R + 1 >= 0x7fffffffull) return false;
+    // The flat side scatters a lane's four elements e = 4 l + kk to (record e / k, index e % k).  For k a power of two
+    // from 8 up a 32-lane group touches the rows kk, kk + 4, kk + 8 ... at 32 * 4 / k consecutive records each: those
+    // rows must start 256 / k banks apart (an odd pitch put rows 4 apart four banks apart: (8, n) 64 %, (16, n) 63 %).
+    r.pitch = r.R + r.R / 32 + 1;
+    if (r.k >= 8 && (r.k & (r.k - 1)) == 0) {
+        const uint32_t want = (64 / r.k) % 16;  // pitch mod 16: 4 * pitch = 256 / k (mod 64)
+        while (r.pitch % 16 != want) ++r.pitch;
+    }
+    r.kdiv = FastDiv(r.k);
+    r.vrdiv = FastDiv(r.R / (uint32_t)W);
+    *rp = r;
+    return true;
+}
+
+template <typename T, typename Op>
+int run_record(const RecordParams &rp, bool small_p, bool t_is_a, const void *a, const void *b, void *out, hipStream_t s) {
+    const T *t = static_cast<const T *>(t_is_a ? a : b), *o = static_cast<const T *>(t_is_a ? b : a);
+    const dim3 grid((unsigned)((rp.n + rp.R - 1) / rp.R)), block(256);
+    T *po = static_cast<T *>(out);
+    if (small_p) {
+        if (t_is_a) hipLaunchKernelGGL((record_kernel<T, Op, true, true>), grid, block, 0, s, t, o, po, rp);
+        else hipLaunchKernelGGL((record_kernel<T, Op, true, false>), grid, block, 0, s, t, o, po, rp);
+    } else {
+        if (t_is_a) hipLaunchKernelGGL((record_kernel<T, Op, false, true>), grid, block, 0, s, t, o, po, rp);
+        else hipLaunchKernelGGL((record_kernel<T, Op, false, false>), grid, block, 0, s, t, o, po, rp);
+    }
+    SMHIP_LAUNCH_CHECK("record_kernel");
     return SMHIP_OK;
 }
 
@@ -844,6 +1055,32 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         ((pl.sa[0] == 0 && pl.sa[1] == 1) || (pl.sa[0] == 1 && pl.sa[1] == 0 && pl.shape[1] >= SMHIP_FLAT_ROWS_MIN_COLS))) {
         // the same shape with the roles exchanged (row + A, column * A): + and * commute bit for bit
         return launch_flat_rows(op, dtype, b, a, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sa[0] == 0, s);
+    }
+    if (!user) {  // a plane with one tiny extent and one turned operand: the record kernel (AoS <-> SoA)
+        RecordParams rp;
+        bool small_p, t_is_a;
+        if (plan_record(pl, (int)dtype_size(dtype), &rp, &small_p, &t_is_a)) {
+            const size_t esz = dtype_size(dtype), bytes = pl.n * esz;
+            const Span sa_{a, (pl.sa[0] || pl.sa[1]) ? bytes : esz}, sb_{b, (pl.sb[0] || pl.sb[1]) ? bytes : esz};
+            rp.nt = (uint32_t)stream_policy({sa_, sb_}, Span{out, bytes});
+#define SMHIP_RECORD(T)                                                                                  \
+    switch (op) {                                                                                        \
+        case SMHIP_OP_ADD: return run_record<T, AddOp<T>>(rp, small_p, t_is_a, a, b, out, s);           \
+        case SMHIP_OP_SUB: return run_record<T, SubtractOp<T>>(rp, small_p, t_is_a, a, b, out, s);      \
+        case SMHIP_OP_MUL: return run_record<T, MultiplyOp<T>>(rp, small_p, t_is_a, a, b, out, s);      \
+        case SMHIP_OP_DIV: return run_record<T, DivideOp<T>>(rp, small_p, t_is_a, a, b, out, s);        \
+        case SMHIP_OP_POW: return run_record<T, PowOp<T>>(rp, small_p, t_is_a, a, b, out, s);           \
+        case SMHIP_OP_LEFT: return run_record<T, LeftOp<T>>(rp, small_p, t_is_a, a, b, out, s);         \
+    }                                                                                                    \
+    break;
+            switch (dtype) {
+                case SMHIP_F32: SMHIP_RECORD(float)
+                case SMHIP_F64: SMHIP_RECORD(double)
+                case SMHIP_I32: SMHIP_RECORD(int32_t)
+                case SMHIP_I64: SMHIP_RECORD(int64_t)
+            }
+#undef SMHIP_RECORD
+        }
     }
     Launch L;
     if (int rc = plan_launch(pl, (int)dtype_size(dtype), heavy, &L)) return rc;

@@ -535,7 +535,7 @@ int jit_launch(int op, int dtype, const bk::Launch &L, const void *a, const void
             if (L.swapped) { x = b; y = a; }  // the streamed operand comes first
             break;
         case Launch::kTile:
-            snprintf(body, sizeof body, "tile_body<T,UserOp,%s,%d,%d,%d>", L.vec ? "true" : "false", L.ma, L.mb, L.wide ? bk::kTileQBytesWide : bk::kTileQBytes);
+            snprintf(body, sizeof body, "tile_body<T,UserOp,%s,%d,%d,%d>", L.vec ? "true" : "false", L.ma, L.mb, L.vec ? L.qb : bk::kTileQBytes);
             params = "TileParams";
             break;
         case Launch::kGather:

@@ -1393,14 +1393,67 @@ def test_large_view_shapes_vs_numpy(smhip):
             assert np.array_equal(got, f(va, vb)), (t, dtn, opn, dims, ka, kb)
 
 
+def test_record_kernel_aos_soa(smhip):
+    """Planes with one tiny extent and one turned operand (arrays of small records <-> few long rows) take the record kernel
+    (broadcast.hip): records of 2 ... 32 elements, both directions, the turned operand on either side of a non-commutative
+    Op, record counts that end inside a workgroup's chunk, padded row pitches, every element type, and the same shapes as
+    plain copies (`dst = src.T`); numpy is the specification (one correctly rounded operation per element)."""
+    rng = np.random.default_rng(4242)
+    t = 0
+    for k in (2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 24, 32):
+        for n in (4096, 5000 + k, 70001):
+            t += 1
+            dtn = ("f32", "f64", "i32", "i64")[t % 4]
+            dt = DT[dtn]
+            opn, f = (("sub", np.subtract), ("add", np.add), ("div", np.divide), ("mul", np.multiply))[t % 4] if dtn[0] == "f" else (("sub", np.subtract), ("mul", np.multiply))[t % 2]
+            recs = gen.gen(dt, n * k, 500 + t, "positive" if opn == "div" else "uniform").reshape(n, k)      # n records of k
+            rows = gen.gen(dt, n * k, 600 + t, "positive" if opn == "div" else "uniform").reshape(k, n)      # k rows of n
+            drecs, drows = smhip.to_device(recs), smhip.to_device(rows)
+            # AoS -> SoA: out (k, n) = recs.T op rows, and with the operands exchanged
+            got = smhip.binary(sma.OPS[opn], drecs.view_like(recs.T, recs), drows).numpy()
+            assert np.array_equal(got, f(recs.T, rows)), ("aos->soa", k, n, dtn, opn)
+            got = smhip.binary(sma.OPS[opn], drows, drecs.view_like(recs.T, recs)).numpy()
+            assert np.array_equal(got, f(rows, recs.T)), ("aos->soa swapped", k, n, dtn, opn)
+            # SoA -> AoS: out (n, k) = rows.T op recs
+            got = smhip.binary(sma.OPS[opn], drows.view_like(rows.T, rows), drecs).numpy()
+            assert np.array_equal(got, f(rows.T, recs)), ("soa->aos", k, n, dtn, opn)
+            got = smhip.binary(sma.OPS[opn], drecs, drows.view_like(rows.T, rows)).numpy()
+            assert np.array_equal(got, f(recs, rows.T)), ("soa->aos swapped", k, n, dtn, opn)
+            # the k rows inside rows of a longer pitch (a slice of a wider array)
+            wide = gen.gen(dt, k * (n + 37), 700 + t, "uniform").reshape(k, n + 37)
+            dwide = smhip.to_device(wide)
+            sl = wide[:, 5:5 + n]
+            got = smhip.binary(sma.OPS["add"], dwide.view_like(sl.T, wide), drecs).numpy()
+            assert np.array_equal(got, sl.T + recs), ("soa->aos pitch", k, n, dtn)
+            got = smhip.binary(sma.OPS["add"], drecs.view_like(recs.T, recs), dwide.view_like(sl, wide)).numpy()
+            assert np.array_equal(got, recs.T + sl), ("aos->soa pitch", k, n, dtn)
+            # copies: dst = src.T both ways
+            dst = smhip.empty((k, n), dt)
+            smhip.assign(dst, drecs.view_like(recs.T, recs))
+            assert np.array_equal(dst.numpy(), recs.T), ("copy aos->soa", k, n, dtn)
+            dst2 = smhip.empty((n, k), dt)
+            smhip.assign(dst2, drows.view_like(rows.T, rows))
+            assert np.array_equal(dst2.numpy(), rows.T), ("copy soa->aos", k, n, dtn)
+    # pow through it (tables in LDS next to the tile), float and double
+    for dt in (np.float32, np.float64):
+        base = rng.uniform(0.05, 30.0, (6000, 6)).astype(dt)
+        e = rng.uniform(-3.0, 3.0, (6, 6000)).astype(dt)
+        got = smhip.binary(sma.OP_POW, smhip.to_device(base).view_like(base.T, base), smhip.to_device(e)).numpy()
+        with np.errstate(all="ignore"):
+            exact = np.power(base.T.astype(np.longdouble), e.astype(np.longdouble)).astype(dt)
+        it = np.int32 if dt == np.float32 else np.int64
+        assert np.abs(got.view(it).astype(np.int64) - exact.view(it).astype(np.int64)).max() <= 1, dt
+
+
 def test_tile_kernel_patch_shapes():
-    """The tile kernel has two patch shapes (64 x 512 B on a diagonal walk up to 256 MiB per array, 64 x 1024 B row-major
-    beyond: DESIGN.md section 3).  tests/tile_probe.py runs transposed / permuted views of every element type, + * and a user
-    Op, bit-exact against numpy, with each shape forced at test sizes; unforced, its 272 MiB case takes the wide patch."""
+    """The tile kernel has three patch shapes (64 x 512 B on a diagonal walk up to 256 MiB per array, 64 x 1024 B row-major
+    beyond, 64 x 128 B for planes whose q extent is a few dozen elements: DESIGN.md section 3).  tests/tile_probe.py runs
+    transposed / permuted views of every element type, + * pow and a user Op against numpy with each shape forced at test
+    sizes; unforced, its skinny cases take the short patch and its 272 MiB case the wide one."""
     import subprocess, sys, os
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_probe.py")
-    for env, args in (({"SMHIP_TILE_WIDE": "1"}, []), ({"SMHIP_TILE_WIDE": "0"}, []), ({}, ["big"])):
-        clean = {k: v for k, v in os.environ.items() if k != "SMHIP_TILE_WIDE"}
+    for env, args in (({"SMHIP_TILE_QB": "1024"}, []), ({"SMHIP_TILE_QB": "512"}, []), ({"SMHIP_TILE_QB": "128"}, []), ({}, ["big"])):
+        clean = {k: v for k, v in os.environ.items() if k not in ("SMHIP_TILE_WIDE", "SMHIP_TILE_QB")}
         r = subprocess.run([sys.executable, probe] + args, capture_output=True, text=True, timeout=600, env=dict(clean, **env))
         assert r.returncode == 0 and "tile_probe ok" in r.stdout, (env, r.stdout[-2000:] + r.stderr[-2000:])
 

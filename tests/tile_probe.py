@@ -1,6 +1,7 @@
-"""The LDS tile kernel's two patch shapes against numpy.  SMHIP_TILE_WIDE=1 forces the 64 x 1024 B patch with its row-major
-walk at test sizes, =0 the 64 x 512 B patch on its diagonal; unset, the library chooses by size and the last case (one
-operand > 256 MiB) takes the wide patch by itself.  Transposed / permuted / offset views, one and two turned operands,
+"""The LDS tile kernel's three patch shapes against numpy.  SMHIP_TILE_QB=1024 forces the 64 x 1024 B patch with its
+row-major walk at test sizes, =512 the 64 x 512 B patch on its diagonal, =128 the short patch of skinny planes; unset, the
+library chooses: planes with a q extent of <= 256 bytes take the short patch, and the last case (one operand > 256 MiB) the
+wide one.  Transposed / permuted / offset views, one and two turned operands,
 f32 / f64 / i32, + and *, a user-defined Op (hipRTC compiles the same body), bit-exact (one correctly rounded operation
 per element).                    python tests/tile_probe.py [big]      -- prints "tile_probe ok <cases>".
 """
@@ -42,6 +43,23 @@ for t in range(36):
             print("MISMATCH", t, dtn, opn, dims, kind, int((got != want).sum()))
             sys.exit(1)
         cases += 1
+# skinny planes: q extents of 16 ... 64 elements (the short patch when the library chooses), long p extents
+for t, (P, Q) in enumerate(((5000, 32), (3108, 16), (4096, 64), (2052, 8), (1024, 24), (640, 48))):
+    dtn = ("f32", "f64", "i32")[t % 3]
+    dt = DT[dtn]
+    a = gen.gen(dt, P * Q, 900 + t, "uniform").reshape(Q, P)   # stored (Q, P), used transposed
+    b = gen.gen(dt, P * Q, 950 + t, "uniform").reshape(P, Q)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    for opn, f in (("add", np.add), ("mul", np.multiply)):
+        got = smhip.binary(sma.OPS[opn], da.view_like(a.T, a), db).numpy()
+        if not np.array_equal(got, f(a.T, b)):
+            print("MISMATCH skinny", dtn, opn, P, Q)
+            sys.exit(1)
+        got = smhip.binary(sma.OPS[opn], db.view_like(b.T, b), da).numpy()   # the other way round: long q, short p
+        if not np.array_equal(got, f(b.T, a)):
+            print("MISMATCH skinny turned", dtn, opn, P, Q)
+            sys.exit(1)
+        cases += 2
 # pow through the tile kernel: its tables share the LDS with the patch (2 / 5 KiB next to 33 / 66 KiB)
 for dt, bar in ((np.float32, 1), (np.float64, 1)):
     for dims in ((512, 768), (300, 260)):
@@ -74,4 +92,4 @@ if len(sys.argv) > 1 and sys.argv[1] == "big":
         print("MISMATCH big")
         sys.exit(1)
     cases += 1
-print("tile_probe ok", cases, "SMHIP_TILE_WIDE =", os.environ.get("SMHIP_TILE_WIDE", "(unset)"))
+print("tile_probe ok", cases, "SMHIP_TILE_QB =", os.environ.get("SMHIP_TILE_QB", "(unset)"))

@@ -1,12 +1,12 @@
 """out(P, Q) = A.T + B with A of shape (Q, P): the LDS tile kernel over rectangular shapes, replayed and (where four operand sets fit in 40 GiB) cold.
-python tools/tile_shapes.py [library|-] [fine|f64]   -- tools/tile_variants.sh builds libraries that differ in the patch walk and q extent."""
+python tools/tile_shapes.py [library|-] [fine|f64|skinny|tiny]   -- tools/tile_variants.sh builds libraries that differ in the patch walk and q extent."""
 import sys, ctypes as C
 sys.path.insert(0, "/root/repo")
 import numpy as np
 import simplemath_amd as sma
 import os
 lib = sma.load(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "-" else sma.load()
-print("library:", sys.argv[1] if len(sys.argv) > 1 else "built", " SMHIP_TILE_WIDE =", os.environ.get("SMHIP_TILE_WIDE", "(auto)"), flush=True)
+print("library:", sys.argv[1] if len(sys.argv) > 1 else "built", " SMHIP_TILE_QB =", os.environ.get("SMHIP_TILE_QB", os.environ.get("SMHIP_TILE_WIDE", "(auto)")), flush=True)
 def i64(seq): return (C.c_int64 * len(seq))(*[int(s) for s in seq])
 def timeit(fn, steps=10):
     for _ in range(3): fn()
@@ -25,6 +25,13 @@ SHAPES = ((4096, 4096), (2048, 32768), (32768, 2048), (4096, 16384), (16384, 409
           (8192, 16384), (16384, 8192), (12288, 12288), (4096, 65536), (65536, 4096), (16384, 16384), (8192, 65536), (65536, 8192))
 if F64:
     SHAPES = ((4096, 4096), (4096, 8192), (8192, 4096), (6144, 6144), (8192, 8192), (4096, 32768), (32768, 4096), (12288, 12288))
+if len(sys.argv) > 2 and sys.argv[2] == "skinny":   # one plane extent far below a patch row
+    SHAPES = ((4194304, 32), (32, 4194304), (2097152, 64), (1048576, 128), (128, 1048576), (524288, 256), (256, 524288), (262144, 512), (512, 262144), (2097152, 16), (16, 2097152))
+if len(sys.argv) > 2 and sys.argv[2] == "tiny":   # plane extents below the tile kernel's 16: AoS <-> SoA of small records (gather / strided kernels)
+    SHAPES = ((3, 16777216), (16777216, 3), (4, 16777216), (16777216, 4), (8, 8388608), (8388608, 8), (12, 4194304), (4194304, 12), (16, 4194304), (4194304, 16), (24, 4194304), (4194304, 24))
+if len(sys.argv) > 2 and sys.argv[2] == "pow2":   # the record kernel: long extents that are and are not a power of two
+    SHAPES = ((8, 8388608), (8, 8388608 + 4096), (16, 4194304), (16, 4194304 + 4096), (32, 2097152), (32, 2097152 + 4096), (4, 16777216), (4, 16777216 + 4096),
+              (8388608, 8), (8388608 + 4096, 8), (6, 8388608), (24, 2097152))
 if len(sys.argv) > 2 and sys.argv[2] == "fine":   # around the size where the wide patch takes over
     SHAPES = ((6144, 8192), (8192, 6144), (8192, 8192), (8192, 8704), (8704, 8192), (9216, 9216), (8192, 10240), (10240, 8192), (9728, 9728), (4096, 20480), (20480, 4096),
               (10240, 10240), (8192, 12288), (12288, 8192), (11264, 11264), (2048, 65536), (65536, 2048))
