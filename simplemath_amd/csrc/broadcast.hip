@@ -1056,30 +1056,51 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         // the same shape with the roles exchanged (row + A, column * A): + and * commute bit for bit
         return launch_flat_rows(op, dtype, b, a, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sa[0] == 0, s);
     }
-    if (!user) {  // a plane with one tiny extent and one turned operand: the record kernel (AoS <-> SoA)
+    if (!user && (pl.ndim == 2 || pl.ndim == 3)) {
+        // a plane with one tiny extent and one turned operand: the record kernel (AoS <-> SoA); a batch of such planes
+        // (an outermost axis in front of them) is one launch per plane when the planes are worth a launch each
+        const size_t esz = dtype_size(dtype);
+        Plan pp = pl;
+        int64_t batch = 1, ba = 0, bb = 0;
+        if (pl.ndim == 3) {
+            batch = pl.shape[0]; ba = pl.sa[0]; bb = pl.sb[0];
+            pp.ndim = 2;
+            for (int d = 0; d < 2; ++d) { pp.shape[d] = pl.shape[d + 1]; pp.sa[d] = pl.sa[d + 1]; pp.sb[d] = pl.sb[d + 1]; }
+            pp.n = (size_t)(pp.shape[0] * pp.shape[1]);
+        }
         RecordParams rp;
         bool small_p, t_is_a;
-        if (plan_record(pl, (int)dtype_size(dtype), &rp, &small_p, &t_is_a)) {
-            const size_t esz = dtype_size(dtype), bytes = pl.n * esz;
-            const Span sa_{a, (pl.sa[0] || pl.sa[1]) ? bytes : esz}, sb_{b, (pl.sb[0] || pl.sb[1]) ? bytes : esz};
-            rp.nt = (uint32_t)stream_policy({sa_, sb_}, Span{out, bytes});
-#define SMHIP_RECORD(T)                                                                                  \
-    switch (op) {                                                                                        \
-        case SMHIP_OP_ADD: return run_record<T, AddOp<T>>(rp, small_p, t_is_a, a, b, out, s);           \
-        case SMHIP_OP_SUB: return run_record<T, SubtractOp<T>>(rp, small_p, t_is_a, a, b, out, s);      \
-        case SMHIP_OP_MUL: return run_record<T, MultiplyOp<T>>(rp, small_p, t_is_a, a, b, out, s);      \
-        case SMHIP_OP_DIV: return run_record<T, DivideOp<T>>(rp, small_p, t_is_a, a, b, out, s);        \
-        case SMHIP_OP_POW: return run_record<T, PowOp<T>>(rp, small_p, t_is_a, a, b, out, s);           \
-        case SMHIP_OP_LEFT: return run_record<T, LeftOp<T>>(rp, small_p, t_is_a, a, b, out, s);         \
-    }                                                                                                    \
+        if ((pl.ndim == 2 || (batch <= 4096 && pp.n >= ((size_t)1 << 18))) && plan_record(pp, (int)esz, &rp, &small_p, &t_is_a)) {
+            auto span = [&](const void *ptr, const int64_t *st) {
+                int64_t last = 0;
+                for (int d = 0; d < pl.ndim; ++d) last += (pl.shape[d] - 1) * st[d];
+                return Span{ptr, (size_t)(last + 1) * esz};
+            };
+            rp.nt = (uint32_t)stream_policy({span(a, pl.sa), span(b, pl.sb)}, Span{out, pl.n * esz});
+            for (int64_t k = 0; k < batch; ++k) {
+                const void *ak = static_cast<const char *>(a) + k * ba * (int64_t)esz, *bk = static_cast<const char *>(b) + k * bb * (int64_t)esz;
+                void *ok = static_cast<char *>(out) + (size_t)k * pp.n * esz;
+                int rc = SMHIP_ERR_INVALID;
+#define SMHIP_RECORD(T)                                                                                       \
+    switch (op) {                                                                                             \
+        case SMHIP_OP_ADD: rc = run_record<T, AddOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;          \
+        case SMHIP_OP_SUB: rc = run_record<T, SubtractOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;     \
+        case SMHIP_OP_MUL: rc = run_record<T, MultiplyOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;     \
+        case SMHIP_OP_DIV: rc = run_record<T, DivideOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;       \
+        case SMHIP_OP_POW: rc = run_record<T, PowOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;          \
+        case SMHIP_OP_LEFT: rc = run_record<T, LeftOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;        \
+    }                                                                                                         \
     break;
-            switch (dtype) {
-                case SMHIP_F32: SMHIP_RECORD(float)
-                case SMHIP_F64: SMHIP_RECORD(double)
-                case SMHIP_I32: SMHIP_RECORD(int32_t)
-                case SMHIP_I64: SMHIP_RECORD(int64_t)
-            }
+                switch (dtype) {
+                    case SMHIP_F32: SMHIP_RECORD(float)
+                    case SMHIP_F64: SMHIP_RECORD(double)
+                    case SMHIP_I32: SMHIP_RECORD(int32_t)
+                    case SMHIP_I64: SMHIP_RECORD(int64_t)
+                }
 #undef SMHIP_RECORD
+                if (rc) return rc == SMHIP_ERR_INVALID ? fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype) : rc;
+            }
+            return SMHIP_OK;
         }
     }
     Launch L;

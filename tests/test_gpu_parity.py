@@ -1434,6 +1434,20 @@ def test_record_kernel_aos_soa(smhip):
             dst2 = smhip.empty((n, k), dt)
             smhip.assign(dst2, drows.view_like(rows.T, rows))
             assert np.array_equal(dst2.numpy(), rows.T), ("copy soa->aos", k, n, dtn)
+    # a batch of such planes: (B, n, k) viewed as (B, k, n), one launch per plane once a plane has 2^18 elements
+    for B, n, k, dtn in ((3, 90000, 3, "f32"), (2, 70000, 4, "f64"), (4, 66000, 12, "i32"), (5, 5000, 3, "f32")):
+        dt = DT[dtn]
+        recs = gen.gen(dt, B * n * k, 801, "uniform").reshape(B, n, k)
+        rows = gen.gen(dt, B * n * k, 802, "uniform").reshape(B, k, n)
+        drecs, drows = smhip.to_device(recs), smhip.to_device(rows)
+        rt, wt = np.transpose(recs, (0, 2, 1)), np.transpose(rows, (0, 2, 1))
+        got = smhip.binary(sma.OPS["sub"], drecs.view_like(rt, recs), drows).numpy()
+        assert np.array_equal(got, rt - rows), ("batched aos->soa", B, n, k, dtn)
+        got = smhip.binary(sma.OPS["sub"], drecs, drows.view_like(wt, rows)).numpy()
+        assert np.array_equal(got, recs - wt), ("batched soa->aos", B, n, k, dtn)
+        dst = smhip.empty((B, k, n), dt)
+        smhip.assign(dst, drecs.view_like(rt, recs))
+        assert np.array_equal(dst.numpy(), rt), ("batched copy", B, n, k, dtn)
     # pow through it (tables in LDS next to the tile), float and double
     for dt in (np.float32, np.float64):
         base = rng.uniform(0.05, 30.0, (6000, 6)).astype(dt)
