@@ -656,6 +656,8 @@ struct RecordParams {
     int64_t o_pitch;      // SMALL_P: distance between the k rows of o (!SMALL_P: o is dense, record r at r * k)
     int o_scalar;         // o is one value
     uint32_t nt;
+    FastDiv chunks;       // workgroups per plane: blockIdx = plane * chunks + chunk
+    int64_t t_batch, o_batch;  // distance between the planes of a batch in t and o (the output's planes are dense)
 };
 template <typename T> constexpr int record_chunk() { return 32768 / (int)sizeof(T); }  // elements per workgroup at most
 
@@ -668,7 +670,12 @@ __global__ __launch_bounds__(256) void record_kernel(const T *__restrict__ t, co
     ctx.init();
     const uint32_t k = p.k, R = p.R, PITCH = p.pitch;
     auto at = [&](uint32_t small, uint32_t rec) -> uint32_t { return small * PITCH + rec + (rec >> 5); };
-    const uint64_t j0 = (uint64_t)blockIdx.x * R;
+    uint32_t plane, chunk;
+    p.chunks.divmod(blockIdx.x, plane, chunk);
+    t += (int64_t)plane * p.t_batch;
+    o += (int64_t)plane * p.o_batch;
+    out += (uint64_t)plane * p.n * k;
+    const uint64_t j0 = (uint64_t)chunk * R;
     const uint32_t Rc = (uint32_t)(p.n - j0 < R ? p.n - j0 : R);
     const T oval = p.o_scalar ? *o : T{};
     auto apply1 = [&](T xt, T xo) { return T_IS_A ? Op::apply(xt, xo) : Op::apply(xo, xt); };
@@ -799,7 +806,11 @@ inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p
         return false;
     }
     r.R = (uint32_t)(cmax / (int64_t)r.k) / 64 * 64;
-    if (r.R < 64 || r.n / r.R + 1 >= 0x7fffffffull) return false;
+    if (r.R < 64) return false;
+    // a smaller R that divides the plane's record count spares every plane its element-wise last chunk (a batch of
+    // 224 x 224 x 3 images: 18.7 chunks of 2688 records -> 28 whole chunks of 1792)
+    for (uint32_t m = r.R / 64; m >= (r.R / 64 + 1) / 2; --m)
+        if (r.n % (64ull * m) == 0) { r.R = 64 * m; break; }
     // The flat side scatters a lane's four elements e = 4 l + kk to (record e / k, index e % k).  For k a power of two
     // from 8 up a 32-lane group touches the rows kk, kk + 4, kk + 8 ... at 32 * 4 / k consecutive records each: those
     // rows must start 256 / k banks apart (an odd pitch put rows 4 apart four banks apart: (8, n) 64 %, (16, n) 63 %).
@@ -815,9 +826,9 @@ inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p
 }
 
 template <typename T, typename Op>
-int run_record(const RecordParams &rp, bool small_p, bool t_is_a, const void *a, const void *b, void *out, hipStream_t s) {
+int run_record(const RecordParams &rp, size_t planes, bool small_p, bool t_is_a, const void *a, const void *b, void *out, hipStream_t s) {
     const T *t = static_cast<const T *>(t_is_a ? a : b), *o = static_cast<const T *>(t_is_a ? b : a);
-    const dim3 grid((unsigned)((rp.n + rp.R - 1) / rp.R)), block(256);
+    const dim3 grid((unsigned)(planes * rp.chunks.d)), block(256);
     T *po = static_cast<T *>(out);
     if (small_p) {
         if (t_is_a) hipLaunchKernelGGL((record_kernel<T, Op, true, true>), grid, block, 0, s, t, o, po, rp);
@@ -1057,8 +1068,8 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         return launch_flat_rows(op, dtype, b, a, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sa[0] == 0, s);
     }
     if (!user && (pl.ndim == 2 || pl.ndim == 3)) {
-        // a plane with one tiny extent and one turned operand: the record kernel (AoS <-> SoA); a batch of such planes
-        // (an outermost axis in front of them) is one launch per plane when the planes are worth a launch each
+        // a plane with one tiny extent and one turned operand, or a batch of such planes (an outermost axis in front of
+        // them): the record kernel (AoS <-> SoA)
         const size_t esz = dtype_size(dtype);
         Plan pp = pl;
         int64_t batch = 1, ba = 0, bb = 0;
@@ -1070,26 +1081,27 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         }
         RecordParams rp;
         bool small_p, t_is_a;
-        if ((pl.ndim == 2 || (batch <= 4096 && pp.n >= ((size_t)1 << 18))) && plan_record(pp, (int)esz, &rp, &small_p, &t_is_a)) {
-            auto span = [&](const void *ptr, const int64_t *st) {
-                int64_t last = 0;
-                for (int d = 0; d < pl.ndim; ++d) last += (pl.shape[d] - 1) * st[d];
-                return Span{ptr, (size_t)(last + 1) * esz};
-            };
-            rp.nt = (uint32_t)stream_policy({span(a, pl.sa), span(b, pl.sb)}, Span{out, pl.n * esz});
-            for (int64_t k = 0; k < batch; ++k) {
-                const void *ak = static_cast<const char *>(a) + k * ba * (int64_t)esz, *bk = static_cast<const char *>(b) + k * bb * (int64_t)esz;
-                void *ok = static_cast<char *>(out) + (size_t)k * pp.n * esz;
-                int rc = SMHIP_ERR_INVALID;
-#define SMHIP_RECORD(T)                                                                                       \
-    switch (op) {                                                                                             \
-        case SMHIP_OP_ADD: rc = run_record<T, AddOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;          \
-        case SMHIP_OP_SUB: rc = run_record<T, SubtractOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;     \
-        case SMHIP_OP_MUL: rc = run_record<T, MultiplyOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;     \
-        case SMHIP_OP_DIV: rc = run_record<T, DivideOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;       \
-        case SMHIP_OP_POW: rc = run_record<T, PowOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;          \
-        case SMHIP_OP_LEFT: rc = run_record<T, LeftOp<T>>(rp, small_p, t_is_a, ak, bk, ok, s); break;        \
-    }                                                                                                         \
+        if (plan_record(pp, (int)esz, &rp, &small_p, &t_is_a)) {
+            const uint64_t chunks = (rp.n + rp.R - 1) / rp.R;
+            if (chunks * (uint64_t)batch < 0x7fffffffull) {
+                rp.chunks = FastDiv((uint32_t)chunks);
+                rp.t_batch = t_is_a ? ba : bb;
+                rp.o_batch = t_is_a ? bb : ba;
+                auto span = [&](const void *ptr, const int64_t *st) {
+                    int64_t last = 0;
+                    for (int d = 0; d < pl.ndim; ++d) last += (pl.shape[d] - 1) * st[d];
+                    return Span{ptr, (size_t)(last + 1) * esz};
+                };
+                rp.nt = (uint32_t)stream_policy({span(a, pl.sa), span(b, pl.sb)}, Span{out, pl.n * esz});
+#define SMHIP_RECORD(T)                                                                                              \
+    switch (op) {                                                                                                    \
+        case SMHIP_OP_ADD: return run_record<T, AddOp<T>>(rp, (size_t)batch, small_p, t_is_a, a, b, out, s);        \
+        case SMHIP_OP_SUB: return run_record<T, SubtractOp<T>>(rp, (size_t)batch, small_p, t_is_a, a, b, out, s);   \
+        case SMHIP_OP_MUL: return run_record<T, MultiplyOp<T>>(rp, (size_t)batch, small_p, t_is_a, a, b, out, s);   \
+        case SMHIP_OP_DIV: return run_record<T, DivideOp<T>>(rp, (size_t)batch, small_p, t_is_a, a, b, out, s);     \
+        case SMHIP_OP_POW: return run_record<T, PowOp<T>>(rp, (size_t)batch, small_p, t_is_a, a, b, out, s);        \
+        case SMHIP_OP_LEFT: return run_record<T, LeftOp<T>>(rp, (size_t)batch, small_p, t_is_a, a, b, out, s);      \
+    }                                                                                                                \
     break;
                 switch (dtype) {
                     case SMHIP_F32: SMHIP_RECORD(float)
@@ -1098,9 +1110,7 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
                     case SMHIP_I64: SMHIP_RECORD(int64_t)
                 }
 #undef SMHIP_RECORD
-                if (rc) return rc == SMHIP_ERR_INVALID ? fail(SMHIP_ERR_INVALID, "elementwise: bad op %d / dtype %d", op, dtype) : rc;
             }
-            return SMHIP_OK;
         }
     }
     Launch L;

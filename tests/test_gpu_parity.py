@@ -1434,8 +1434,9 @@ def test_record_kernel_aos_soa(smhip):
             dst2 = smhip.empty((n, k), dt)
             smhip.assign(dst2, drows.view_like(rows.T, rows))
             assert np.array_equal(dst2.numpy(), rows.T), ("copy soa->aos", k, n, dtn)
-    # a batch of such planes: (B, n, k) viewed as (B, k, n), one launch per plane once a plane has 2^18 elements
-    for B, n, k, dtn in ((3, 90000, 3, "f32"), (2, 70000, 4, "f64"), (4, 66000, 12, "i32"), (5, 5000, 3, "f32")):
+    # a batch of such planes: (B, n, k) viewed as (B, k, n) -- NHWC <-> NCHW of 224 x 224 x 3 images among them (one launch:
+    # the workgroup index carries the plane; 50176 records go out as 28 whole chunks of 1792)
+    for B, n, k, dtn in ((3, 90000, 3, "f32"), (2, 70000, 4, "f64"), (4, 66000, 12, "i32"), (5, 5000, 3, "f32"), (8, 50176, 3, "f32"), (3, 50180, 3, "i64")):
         dt = DT[dtn]
         recs = gen.gen(dt, B * n * k, 801, "uniform").reshape(B, n, k)
         rows = gen.gen(dt, B * n * k, 802, "uniform").reshape(B, k, n)
