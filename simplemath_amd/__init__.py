@@ -79,6 +79,8 @@ class DeviceArray:
 
     def view_like(self, np_view, np_base):
         """The same view numpy made on the host base, on the device base."""
+        if np_view.size and not np.shares_memory(np_view, np_base):  # a view of ANOTHER array would turn into a wild device pointer
+            raise ValueError("view_like: np_view is not a view of np_base")
         off = (np_view.__array_interface__["data"][0] - np_base.__array_interface__["data"][0]) // self.dtype.itemsize
         return DeviceArray(self.lib, self.base_ptr, self.dtype, np_view.shape,
                            [s // self.dtype.itemsize for s in np_view.strides], off, self._owner)

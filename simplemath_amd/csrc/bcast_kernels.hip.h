@@ -302,10 +302,85 @@ __device__ __forceinline__ void strided2_row_body(const T *__restrict__ a, const
     }
 }
 
+// Stride 4 on four-byte elements (one channel of an RGBA image, a[:, ::4]) the same way: in the general form below lane l
+// loads the four vectors 4l .. 4l+3 -- four instructions that each touch every line of the wave's 4 KiB span and keep a
+// quarter of it (30 % of algorithmic bytes = 61 % of the lines that must move).  Here a wave owns 256 consecutive outputs
+// (the stride-2 chunk), lane l loads input vectors l, l + 64, l + 128, l + 192 -- four contiguous instructions --, keeps
+// element 0 of each and stores four single elements, again contiguous across the lanes; the other side, if dense, is read
+// the same way.
+constexpr int kStrided4Outputs = 4;  // per lane: 64 x 4 = 256 outputs per wave = 32 W kStrided2Groups for four-byte types
+template <typename T, typename Op, int SA, int SB>
+__device__ __forceinline__ void strided4_row_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, StridedParams p) {
+    static_assert(sizeof(T) == 4 && 32 * VecTraits<T>::width * kStrided2Groups == 64 * kStrided4Outputs, "the plan's chunk is the stride-2 one");
+    constexpr int G = kStrided4Outputs;
+    typedef typename VecTraits<T>::vec_t V;
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (chunk >= p.slots) return;
+    uint32_t row, c;
+    p.vpr.divmod(chunk, row, c);
+    int64_t offA = 0, offB = 0;
+    {
+        uint32_t rem = row;
+        for (int k = 0; k < p.n_outer - 1; ++k) {
+            uint32_t q, idx;
+            p.shape[k].divmod(rem, q, idx);
+            rem = q;
+            offA += (int64_t)idx * p.sa[k];
+            offB += (int64_t)idx * p.sb[k];
+        }
+        if (p.n_outer > 0) {
+            offA += (int64_t)rem * p.sa[p.n_outer - 1];
+            offB += (int64_t)rem * p.sb[p.n_outer - 1];
+        }
+    }
+    T *orow = out + (size_t)row * p.inner;
+    const uint32_t o0 = c * (64u * G) + lane;  // the lane's first output; the others follow 64 apart
+    // strictly inside the row: a strided vector reads three elements past its kept one, which then still belong to the row
+    if (c * (64u * G) + 64u * G < p.inner) {
+        T xa[G], xb[G];
+        auto fetch = [&](const T *base, auto stride_tag, auto nt_tag, uint32_t o, T &dst) {
+            constexpr int S = decltype(stride_tag)::value;
+            if constexpr (S == 0) dst = *base;
+            else if constexpr (S == 1) dst = __builtin_nontemporal_load(base + o);  // the dense side: non-temporal whatever the read policy
+            else {
+                const V v = load_stream_as(T, reinterpret_cast<const V *>(base + (int64_t)o * 4), decltype(nt_tag)::value);
+                dst = v[0];
+            }
+        };
+        if (p.nt & kLoadNt) {  // ONE branch around all the loads of the lane (see load_stream_as)
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(a + offA, IntTag<SA>{}, BoolTag<true>{}, o0 + 64u * g, xa[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(b + offB, IntTag<SB>{}, BoolTag<true>{}, o0 + 64u * g, xb[g]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(a + offA, IntTag<SA>{}, BoolTag<false>{}, o0 + 64u * g, xa[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) fetch(b + offB, IntTag<SB>{}, BoolTag<false>{}, o0 + 64u * g, xb[g]);
+        }
+        T res[G];
+        apply_n<Op, T, G>(ctx, xa, xb, res);
+#pragma unroll
+        for (int g = 0; g < G; ++g) __builtin_nontemporal_store(res[g], orow + o0 + 64u * g);
+    } else {
+        for (int g = 0; g < G; ++g) {
+            const uint32_t o = o0 + 64u * g;
+            if (o < p.inner) orow[o] = Op::apply(a[offA + (int64_t)o * SA], b[offB + (int64_t)o * SB]);
+        }
+    }
+}
+
 template <typename T, typename Op, int SA, int SB>
 __device__ __forceinline__ void strided_row_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, StridedParams p) {
     if constexpr ((SA == 2 || SB == 2) && SA <= 2 && SB <= 2) {
         strided2_row_body<T, Op, SA, SB>(a, b, out, p);
+        return;
+    }
+    if constexpr (sizeof(T) == 4 && (SA == 4 || SB == 4) && SA != 2 && SA != 3 && SB != 2 && SB != 3) {
+        strided4_row_body<T, Op, SA, SB>(a, b, out, p);
         return;
     }
     constexpr int W = VecTraits<T>::width;

@@ -336,7 +336,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             p.vpr = FastDiv((uint32_t)vpr);
             p.slots = (uint32_t)(rows * vpr);
             size_t blocks = (rows * vpr + 255) / 256;
-            if (big == 2) {  // strided2_row_body: a WAVE owns 64 W consecutive outputs of a row, four waves per workgroup
+            if (big == 2 || (big == 4 && esz == 4)) {  // strided2_row_body / strided4_row_body: a WAVE owns 64 W consecutive outputs (four-byte types: 256) of a row, four waves per workgroup
                 const size_t per_chunk = (size_t)32 * W * kStrided2Groups;
                 const size_t cpr = ((size_t)inner + per_chunk - 1) / per_chunk;
                 p.vpr = FastDiv((uint32_t)cpr);

@@ -1338,6 +1338,7 @@ def test_inner_strided_operands_take_wide_loads(smhip, oracle):
                  (a[:, ::2], b[:, :515]), (a[:, :343], b[:, 1::3]),                     # strided against dense
                  (a[:, ::4], b[:, 5:6]), (a[:, 3:4], b[:, ::2]),                        # strided against one value per row
                  (a[3:, 6:1030:2], b[3:, 7:1030:2]), (a[22:, ::2], b[22:, 1::2]),        # ends at the allocation's last element
+                 (a[:, ::4], b[:, :258]), (a[:, :258], b[:, 1::4]), (a[:, 2::4], b[:, 3::4]),  # stride 4: rows that end inside / at a 256-output chunk (first of a pair: a view of a, second: of b)
                  (fa[::2], fb[1::2]), (fa[23 * 1030 - 4 * 900::4], fb[:900]),           # 1-D
                  (a.reshape(23, 10, 103)[:, :, ::2][:, :, :40], b.reshape(23, 10, 103)[:, :, 1::2][:, :, :40])]  # short rows: gather
         for k, (va, vb) in enumerate(pairs):
