@@ -1450,6 +1450,13 @@ def test_record_kernel_aos_soa(smhip):
         dst = smhip.empty((B, k, n), dt)
         smhip.assign(dst, drecs.view_like(rt, recs))
         assert np.array_equal(dst.numpy(), rt), ("batched copy", B, n, k, dtn)
+    # integer pow (wrapping square-and-multiply, crafted_pow.h:54-103): non-negative exponents, numpy wraps the same way
+    for dt in (np.int32, np.int64):
+        base = rng.integers(-9, 10, (5000, 5)).astype(dt)
+        e = rng.integers(0, 12, (5, 5000)).astype(dt)
+        got = smhip.binary(sma.OP_POW, smhip.to_device(base).view_like(base.T, base), smhip.to_device(e)).numpy()
+        with np.errstate(all="ignore"):
+            assert np.array_equal(got, np.power(base.T, e)), dt
     # pow through it (tables in LDS next to the tile), float and double
     for dt in (np.float32, np.float64):
         base = rng.uniform(0.05, 30.0, (6000, 6)).astype(dt)
