@@ -1026,9 +1026,35 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
                 dense &= sx[d] == run;
                 run *= pl.shape[d];
             }
+            if (!dense) continue;  // x is a view
+            {   // y is constant along the trailing axes (a per-channel bias in NCHW: (B, C, H, W) + (1, C, 1, 1)): with those
+                // axes merged the problem is rows against ONE VALUE PER ROW, config 3's column form -- once y's values are
+                // written out as a dense vector of `rows` elements (a launch of a few microseconds).  The row kernel took
+                // (64, 256, 56, 56) + (1, 256, 1, 1) at 72.6 %; tools/bcast_zoo.py.
+                int j = pl.ndim - 1;
+                while (j >= 0 && sy[j] == 0) --j;
+                size_t cols = 1, rows = 1;
+                for (int d = j + 1; d < pl.ndim; ++d) cols *= (size_t)pl.shape[d];
+                for (int d = 0; d <= j; ++d) rows *= (size_t)pl.shape[d];
+                bool y_dense = true;  // already a dense vector of rows values: the flat route below takes it as it is
+                int64_t run_y = 1;
+                for (int d = j; d >= 0; --d) { y_dense &= sy[d] == run_y; run_y *= pl.shape[d]; }
+                if (j >= 0 && j < pl.ndim - 1 && !y_dense && cols >= (size_t)SMHIP_FLAT_ROWS_MIN_COLS && cols % (size_t)W == 0 && rows >= 4 &&
+                    rows * esz <= ((size_t)2 << 20) && cols < 0x7fffffffull && rows < 0x7fffffffull) {
+                    ScratchLease lease;
+                    double *tmp8;
+                    if (int rc = lease.take((rows * esz + 7) / 8, &tmp8)) return rc;
+                    int64_t eshape[SMHIP_MAX_NDIM], esy[SMHIP_MAX_NDIM], zeros[SMHIP_MAX_NDIM];
+                    for (int d = 0; d <= j; ++d) { eshape[d] = pl.shape[d]; esy[d] = sy[d]; zeros[d] = 0; }
+                    const void *x = role == 0 ? a : b, *y = role == 0 ? b : a;
+                    const Plan sub = normalise(eshape, esy, zeros, j + 1);
+                    if (int rc = launch_plan(SMHIP_OP_LEFT, dtype, y, y, tmp8, sub, s)) return rc;
+                    return launch_flat_rows(op, dtype, x, tmp8, out, rows, cols, false, s);
+                }
+            }
             int k = 0;
             while (k < pl.ndim && sy[k] == 0) ++k;
-            if (!dense || k == 0 || k == pl.ndim) continue;  // x is a view, or y ignores no leading axis, or y is a single value
+            if (k == 0 || k == pl.ndim) continue;  // y ignores no leading axis, or y is a single value
             size_t period = 1;
             for (int d = k; d < pl.ndim; ++d) period *= (size_t)pl.shape[d];
             size_t rep = 1;

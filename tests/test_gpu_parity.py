@@ -1185,7 +1185,23 @@ def test_periodic_small_operand_is_written_out_once(smhip):
     assert np.array_equal(smhip.binary(sma.OP_ADD, dev(xi), dev(ri)).numpy(), xi + ri)
     x5 = rng.uniform(0.5, 2.0, (17, 7, 300000)).astype(np.float32)               # 136 MiB; the small operand ignores only the outermost axis
     y5 = rng.uniform(0.5, 2.0, (7, 1)).astype(np.float32)                        # period 7 * 300000 = 8 MiB: too long, stays where it was
-    assert np.array_equal(smhip.binary(sma.OP_ADD, dev(x5), dev(y5)).numpy(), x5 + y5)
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dev(x5), dev(y5)).numpy(), x5 + y5)  # (since round 3: one value per row, below)
+    # a small operand that is constant along the TRAILING axes -- a per-channel bias in NCHW, (B, C, H, W) op (1, C, 1, 1): its
+    # values are written out as one per row of (B C, H W) and the flat tile kernel's column form takes it
+    xn = rng.uniform(0.5, 2.0, (42, 256, 56, 56)).astype(np.float32)              # 128.6 MiB
+    cb = rng.uniform(0.5, 2.0, (1, 256, 1, 1)).astype(np.float32)
+    dxn, dcb = dev(xn), dev(cb)
+    assert np.array_equal(smhip.binary(sma.OP_ADD, dxn, dcb).numpy(), xn + cb)
+    assert np.array_equal(smhip.binary(sma.OP_DIV, dxn, dcb).numpy(), xn / cb)
+    assert np.array_equal(smhip.binary(sma.OP_MUL, dcb, dxn).numpy(), cb * xn)    # on the left, commutative
+    assert np.array_equal(smhip.binary(sma.OP_SUB, dcb, dxn).numpy(), cb - xn)    # on the left, not commutative: the row kernel as before
+    got = smhip.binary(sma.OP_POW, dxn, dcb).numpy()
+    want = np.power(xn.astype(np.float64), cb.astype(np.float64)).astype(np.float32)
+    assert orc.ulp_diff_f32(got.reshape(-1), want.reshape(-1)).max() <= POW_ULP
+    del xn, dxn
+    xs = rng.uniform(0.5, 2.0, (3, 7, 5, 256, 1200)).astype(np.float64)            # 123 MiB... of f64: (3, 7, 5, 256, 1200) * 8 B = 246 MiB
+    ys = rng.uniform(0.5, 2.0, (7, 1, 256, 1)).astype(np.float64)                  # ignores axes 0 and 2, constant along the last
+    assert np.array_equal(smhip.binary(sma.OP_SUB, dev(xs), dev(ys)).numpy(), xs - ys)
 
 
 def test_fuzz_policy_smoke(smhip):
