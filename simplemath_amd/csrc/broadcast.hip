@@ -985,8 +985,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         }
         return SMHIP_OK;
     }
+    // (a dense (n, S) array seen as (S, n) -- records into rows -- is ONE pass through the record kernel below instead of S
+    // passes over the array here: dst (3, n) = src (n, 3).T 31.9 -> 87.3 %, tools/copy_zoo.py)
+    const bool records_into_rows = pl.ndim == 2 && pl.sa[0] == 1 && pl.sa[1] == pl.shape[0] && pl.shape[1] >= 4096;
     if (op == SMHIP_OP_LEFT && pl.ndim <= 2 && pl.sa[pl.ndim - 1] >= 2 && pl.sa[pl.ndim - 1] <= 4 && pl.shape[pl.ndim - 1] >= 64 &&
-        (pl.ndim == 1 || pl.sa[0] != 0)) {  // every S-th element of each row, made dense
+        (pl.ndim == 1 || pl.sa[0] != 0) && !records_into_rows) {  // every S-th element of each row, made dense
         const size_t rows = pl.ndim == 2 ? (size_t)pl.shape[0] : 1;
         const uint32_t inner = (uint32_t)pl.shape[pl.ndim - 1];
         const int64_t pitch = pl.ndim == 2 ? pl.sa[0] : 0;
