@@ -131,7 +131,24 @@ __global__ __launch_bounds__(BLOCK) void flat_tile_kernel(const T *__restrict__ 
     OpCtx<Op> ctx;
     const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
     V *ov = reinterpret_cast<V *>(out);
-    const size_t base = (size_t)blockIdx.x * (kTileBlock * U) + threadIdx.x;
+    // Which tile is this workgroup's?  Its own index -- except for a FEW LONG rows against one row (KIND 3 with `tail` =
+    // rows | log2(group) << 16; the kind has no scalar tail): walking the array flat, row r re-reads the broadcast row long
+    // after row r - 1 has pushed it out of the L2 ((8, 2^23) + (1, 2^23): the 32 MiB row came back from the Infinity Cache
+    // eight times, 65 % of algorithmic).  There 2^lg consecutive workgroups take neighbouring column tiles of one row, the
+    // next 2^lg the same columns of the next row: with lg = 10 (4 MiB of a row per visit) the slice of the broadcast row
+    // stays in the L2s across the rows -- 65 -> 81 % at (8, 2^23), 68 -> 79 % at (4, 2^24), 71 -> 89 % at (3, 3 * 2^22);
+    // groups of 8 ... 256 workgroups scatter the dense operand's stream over the rows instead and gain little or lose
+    // (tools/rows_walk.py, profiles/r03_rows_walk.txt).
+    size_t tile = blockIdx.x;
+    if (KIND == 3 && tail > 0) {
+        const uint32_t tpr = cv.d / (uint32_t)(kTileBlock * U), rows = (uint32_t)tail & 0xffffu, lg = (uint32_t)tail >> 16;  // whole tiles per row, a multiple of the group
+        if (blockIdx.x < tpr * rows) {
+            const uint32_t x = blockIdx.x & ((1u << lg) - 1u), g = blockIdx.x >> lg, r = g % rows, cg = g / rows;
+            tile = (size_t)r * tpr + (cg << lg) + x;
+        }
+        tail = 0;
+    }
+    const size_t base = tile * (kTileBlock * U) + threadIdx.x;
     auto eval = [&](const V &xa, const V &xb) {
         if constexpr (KIND == 0 || KIND >= 3) return apply_vec<Op, T>(ctx, xa, xb);
         else return apply_vec_scalar<Op, T, KIND == 2>(ctx, xa, s);
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void flat_tile_kernel(const T *__restrict__ 
     // would otherwise pay the staging once per 256 x U vectors.
     typename OpCtx<Op>::template Stage<kTileBlock> staged;
     ctx.template fetch<kTileBlock>(staged);
-    const bool full = (size_t)(blockIdx.x + 1) * (kTileBlock * U) <= n_vec;  // uniform over the workgroup
+    const bool full = (tile + 1) * (kTileBlock * U) <= n_vec;  // uniform over the workgroup
     V va[U], vb[U];
     T ys[U];  // KIND 4: the rows' exponents, splat only after the tables are committed
     if (full) {
@@ -371,8 +388,12 @@ void launch_rows(const T *pa, const T *pb, T *po, size_t n_vec, bool b_is_row, i
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;
     const dim3 grid((unsigned)tiles), block(kTileBlock);
     if (b_is_row) {
-        if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
-        else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
+        // few long rows (the broadcast row outlives no row in the L2): the kernel walks them column block by column block
+        const size_t rows = n_vec / cv.d, row_bytes = (size_t)cv.d * 16;
+        static const int lg = [] { const char *e = getenv("SMHIP_ROWS_WALK_LOG2"); return e && *e ? atoi(e) : 10; }();  // workgroups per visit of a row: 2^lg (-1: flat walk)
+        const int walk = (lg >= 0 && rows >= 2 && rows <= 4096 && row_bytes >= ((size_t)4 << 20) && cv.d % ((uint32_t)(kTileBlock * U) << lg) == 0) ? (int)rows | (lg << 16) : 0;
+        if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, walk, nt, cv);
+        else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, walk, nt, cv);
     } else {
         if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 4, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);
         else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 4, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, 0, nt, cv);

@@ -1410,6 +1410,23 @@ def test_large_view_shapes_vs_numpy(smhip):
             assert np.array_equal(got, f(va, vb)), (t, dtn, opn, dims, ka, kb)
 
 
+def test_few_long_rows_against_one_row(smhip):
+    """Config 3's shape with FEW LONG rows -- (6, 2^21) op (1, 2^21): the flat tile kernel walks such arrays column block by
+    column block (eight workgroups on one row's neighbouring tiles, the next eight on the next row's) so that the broadcast
+    row stays in the L2; every tile must still be visited exactly once: both operand orders, cold and replayed operands
+    (one / two vectors per lane), f32 / f64 / i32, against numpy."""
+    rng = np.random.default_rng(77)
+    for dtn, cols in (("f32", 1 << 21), ("f64", 1 << 20), ("i32", 3 << 20)):
+        dt = DT[dtn]
+        rows = 6 if dtn != "i32" else 2
+        x = gen.gen(dt, rows * cols, 31, "uniform").reshape(rows, cols)
+        r = gen.gen(dt, cols, 32, "uniform").reshape(1, cols)
+        dx, dr = smhip.to_device(x), smhip.to_device(r)
+        for rep in range(2):  # the second call finds its operands warm
+            assert np.array_equal(smhip.binary(sma.OP_SUB, dx, dr).numpy(), x - r), (dtn, rep)
+            assert np.array_equal(smhip.binary(sma.OP_MUL, dr, dx).numpy(), r * x), (dtn, rep)
+
+
 def test_record_kernel_aos_soa(smhip):
     """Planes with one tiny extent and one turned operand (arrays of small records <-> few long rows) take the record kernel
     (broadcast.hip): records of 2 ... 32 elements, both directions, the turned operand on either side of a non-commutative
