@@ -1135,6 +1135,8 @@ def test_fuzz_views_smoke(smhip):
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_flat.py"), "120", "17"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_records.py"), "60", "17"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok:" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_keep_store_is_followed_by_its_wait_states(smhip):
