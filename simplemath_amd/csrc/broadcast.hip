@@ -786,7 +786,7 @@ inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p
     const int64_t P = pl.shape[0], Q = pl.shape[1];
     const int W = 16 / esz, cmax = 32768 / esz;
     auto turned = [&](const int64_t *st) { return st[0] == 1 && st[1] >= P && P > 1; };              // contiguous along dim 0
-    auto direct = [&](const int64_t *st) { return st[1] == 1 && st[0] >= Q; };                         // contiguous along dim 1
+    auto direct = [&](const int64_t *st) { return st[1] == 1 && (st[0] >= Q || st[0] == 0); };        // contiguous along dim 1 (or one row for every row)
     auto scalar = [&](const int64_t *st) { return st[0] == 0 && st[1] == 0; };
     const bool ta = turned(pl.sa) && (direct(pl.sb) || scalar(pl.sb)), tb = turned(pl.sb) && (direct(pl.sa) || scalar(pl.sa));
     if (ta == tb) return false;

@@ -1455,6 +1455,10 @@ def test_record_kernel_aos_soa(smhip):
             assert np.array_equal(got, f(rows.T, recs)), ("soa->aos", k, n, dtn, opn)
             got = smhip.binary(sma.OPS[opn], drecs, drows.view_like(rows.T, rows)).numpy()
             assert np.array_equal(got, f(recs, rows.T)), ("soa->aos swapped", k, n, dtn, opn)
+            # against ONE long row for all k rows
+            one = rows[:1]
+            got = smhip.binary(sma.OPS[opn], drecs.view_like(recs.T, recs), drows.view_like(one, rows)).numpy()
+            assert np.array_equal(got, f(recs.T, one)), ("aos->soa against one row", k, n, dtn, opn)
             # the k rows inside rows of a longer pitch (a slice of a wider array)
             wide = gen.gen(dt, k * (n + 37), 700 + t, "uniform").reshape(k, n + 37)
             dwide = smhip.to_device(wide)
