@@ -640,7 +640,10 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     if constexpr (VEC) {
         constexpr bool kBoth = MA == 1 && MB == 1;
         const int64_t direct_q = MA == 1 ? p.b_q : p.a_q;
-        if (full && (kBoth || direct_q == 1)) {
+        // (a direct operand that does not move along q -- one value per row, or one value: `dst = src.T` is such a problem --
+        // is splat from one element per slot; through the guarded path below A.T * column ran at 48-50 % at 12288^2 and beyond)
+        const bool dsplat = !kBoth && direct_q == 0;
+        if (full && (kBoth || direct_q == 1 || direct_q == 0)) {
             const T *d0 = MA == 1 ? b0 : a0;  // the direct operand (unused when both are turned)
             const int64_t d_p = MA == 1 ? p.b_p : p.a_p;
             // Slots whose loads go out together.  One turned operand: all of them (and all of the direct operand's).  Two
@@ -671,7 +674,13 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
 #pragma unroll
                         for (int s = 0; s < S2; ++s) {
                             const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
-                            vd[s] = load_stream_as(T, reinterpret_cast<const V *>(d0 + (int64_t)il * d_p + jg * W), NT);
+                            if (dsplat) {
+                                const T one = d0[(int64_t)il * d_p];
+#pragma unroll
+                                for (int k = 0; k < W; ++k) vd[s][k] = one;
+                            } else {
+                                vd[s] = load_stream_as(T, reinterpret_cast<const V *>(d0 + (int64_t)il * d_p + jg * W), NT);
+                            }
                         }
                     }
                 };

@@ -43,6 +43,24 @@ for t in range(36):
             print("MISMATCH", t, dtn, opn, dims, kind, int((got != want).sum()))
             sys.exit(1)
         cases += 1
+# a turned operand against one that does not move along q (one value per row, one value: `dst = src.T` is such a problem)
+for t, (P, Q) in enumerate(((768, 1024), (516, 260), (1000, 772))):
+    dtn = ("f32", "f64", "i32")[t % 3]
+    dt = DT[dtn]
+    a = gen.gen(dt, P * Q, 960 + t, "uniform").reshape(Q, P)
+    col = gen.gen(dt, P, 970 + t, "uniform").reshape(P, 1)
+    da, dcol = smhip.to_device(a), smhip.to_device(col)
+    got = smhip.binary(sma.OPS["sub"], da.view_like(a.T, a), dcol).numpy()
+    if not np.array_equal(got, a.T - col):
+        print("MISMATCH turned - column", dtn, P, Q); sys.exit(1)
+    got = smhip.binary(sma.OPS["sub"], dcol, da.view_like(a.T, a)).numpy()
+    if not np.array_equal(got, col - a.T):
+        print("MISMATCH column - turned", dtn, P, Q); sys.exit(1)
+    dst = smhip.empty((P, Q), dt)
+    smhip.assign(dst, da.view_like(a.T, a))
+    if not np.array_equal(dst.numpy(), a.T):
+        print("MISMATCH dst = src.T", dtn, P, Q); sys.exit(1)
+    cases += 3
 # skinny planes: q extents of 16 ... 64 elements (the short patch when the library chooses), long p extents
 for t, (P, Q) in enumerate(((5000, 32), (3108, 16), (4096, 64), (2052, 8), (1024, 24), (640, 48))):
     dtn = ("f32", "f64", "i32")[t % 3]

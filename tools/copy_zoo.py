@@ -32,6 +32,8 @@ N = 8192
 run("dst = src (dense)", (N, N), (N, 1), (N, 1), N * N, N * N)
 run("dst = src.T", (N, N), (1, N), (N, 1), N * N, N * N)
 run("dst.T = src", (N, N), (N, 1), (1, N), N * N, N * N)
+run("dst = src.T at 12288^2 (the wide patch)", (12288, 12288), (1, 12288), (12288, 1), 12288 * 12288, 12288 * 12288)
+run("dst = src.T at 16384^2", (16384, 16384), (1, 16384), (16384, 1), 1 << 28, 1 << 28)
 run("dst[:, :6144] = src", (N, 6144), (6144, 1), (N, 1), N * 6144, N * N)
 run("dst[1:-1, 1:-1] = src", (N - 2, N - 2), (N - 2, 1), (N, 1), (N - 2) * (N - 2), N * N, doff=N + 1)
 run("dst[::2, :] = src", (N // 2, N), (N, 1), (2 * N, 1), N * N // 2, N * N)
