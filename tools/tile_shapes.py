@@ -32,6 +32,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "tiny":   # plane extents below the tile
 if len(sys.argv) > 2 and sys.argv[2] == "pow2":   # the record kernel: long extents that are and are not a power of two
     SHAPES = ((8, 8388608), (8, 8388608 + 4096), (16, 4194304), (16, 4194304 + 4096), (32, 2097152), (32, 2097152 + 4096), (4, 16777216), (4, 16777216 + 4096),
               (8388608, 8), (8388608 + 4096, 8), (6, 8388608), (24, 2097152))
+if len(sys.argv) > 2 and sys.argv[2] == "odd":   # extents that are not a multiple of the vector width: the tile kernel's element form
+    SHAPES = ((8192, 8192), (8191, 8191), (8190, 8190), (8188, 8188), (8191, 8192), (8192, 8191), (12287, 12287), (12284, 12284), (16383, 16383))
 if len(sys.argv) > 2 and sys.argv[2] == "fine":   # around the size where the wide patch takes over
     SHAPES = ((6144, 8192), (8192, 6144), (8192, 8192), (8192, 8704), (8704, 8192), (9216, 9216), (8192, 10240), (10240, 8192), (9728, 9728), (4096, 20480), (20480, 4096),
               (10240, 10240), (8192, 12288), (12288, 8192), (11264, 11264), (2048, 65536), (65536, 2048))
