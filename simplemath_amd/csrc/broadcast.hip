@@ -439,7 +439,7 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
             SMHIP_LAUNCH_CHECK("dense_lds_kernel");
             return SMHIP_OK;
         case Launch::kTile:
-            if (!L.vec) hipLaunchKernelGGL((tile_kernel<T, Op, false, 0, 0, kTileQBytes>), grid, block, 0, s, a, b, out, L.p.tile);
+            if (!L.vec) return fail(SMHIP_ERR_INVALID, "tile kernel: the plan always asks for the 16-byte form");  // (the one-element-per-slot form is no longer built: the 16-byte form takes every extent)
             else {
                 auto go = [&](auto qb_tag) {
                     constexpr int QB = decltype(qb_tag)::value;
