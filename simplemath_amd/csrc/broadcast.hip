@@ -256,7 +256,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             // flight together write (and read the direct operand in) whole rows of the output -- where both plane extents
             // give that patch and its walk something to work with: skinny planes lose badly ((4194304, 32): 40 -> 15 %,
             // (1048576, 128): 77 -> 38 %, (256, 524288): 71 -> 63 %; from 512 x 512 on the two are level).  A q extent of at
-            // most 256 bytes: 64 x 128 B patches ((4194304, 32): 40 -> 78 %, (2097152, 16): 33 -> 82 %).
+            // most 256 bytes (or of 384 bytes): 64 x 128 B patches ((4194304, 32): 40 -> 78 %, (2097152, 16): 33 -> 82 %).
             // SMHIP_TILE_QB = 128 / 512 / 1024 forces one (tests, sweeps); SMHIP_TILE_WIDE = 0 / 1 is the older spelling of 512 / 1024.
             static const int forced = [] {
                 if (const char *e = getenv("SMHIP_TILE_QB"); e && *e) { const int v = atoi(e); return v == kTileQBytesShort || v == kTileQBytesWide ? v : kTileQBytes; }
@@ -266,7 +266,7 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
             const bool roomy = pl.shape[paxis] >= 512 && inner * esz >= 2 * kTileQBytesWide;
             const int qb = !vec ? kTileQBytes
                          : forced ? forced
-                         : inner * esz <= 2 * kTileQBytesShort ? kTileQBytesShort
+                         : (inner * esz <= 2 * kTileQBytesShort || (inner * esz < kTileQBytes && (inner * esz) % kTileQBytesShort == 0)) ? kTileQBytesShort  // ... or a whole number of short patch rows under 512 bytes ((B, 96, 96): 58 -> 82-84 %; 100 columns: 58 -> 32 %, so not those)
                          : roomy && pl.n * (size_t)esz > kInfinityCacheBytes ? kTileQBytesWide : kTileQBytes;
             const int tq = qb / esz;  // tile_q<T, QB>()
             t.np = (uint32_t)pl.shape[paxis];
@@ -782,6 +782,144 @@ __global__ __launch_bounds__(256) void record_kernel(const T *__restrict__ t, co
     }
 }
 
+// ------------------------------------------------------------------ small planes, batched
+// out (B, P, Q) = t op o with t a dense batch of (Q, P) planes read transposed and P * Q small (4 x 4 ... 64 x 64): the tile
+// kernel spends a 64-row patch per plane (16 x 16 planes: 25 % of peak, 4 x 4 ... 24 x 24 and 48 x 48, 96 x 96: 50-59 %,
+// tools/small_planes.py).  A chunk of G whole planes is ONE contiguous run in t, in o and in out, so everything global is
+// flat 16-byte vectors (eight slots per lane, clamped like the record kernel's) and the transposition happens in LDS: t's
+// rows are stored with an odd pitch, and an output vector's four elements are read back one row apart.
+struct PlanesParams {
+    uint32_t P, Q, pitch;   // out plane (P, Q); t plane (Q, P); LDS words between t's rows (P | 1)
+    uint32_t G;             // planes per workgroup
+    uint64_t planes;        // B
+    FastDiv pq, pdiv, qdiv; // / (P Q);  / P;  / Q
+    int o_scalar;
+    uint32_t nt;
+};
+template <typename T, typename Op, bool T_IS_A>
+__global__ __launch_bounds__(256) void planes_kernel(const T *__restrict__ t, const T *__restrict__ o, T *__restrict__ out, PlanesParams p) {
+    constexpr int W = VecTraits<T>::width, CMAX = record_chunk<T>(), S = CMAX / (W * 256);
+    typedef typename VecTraits<T>::vec_t V;
+    __shared__ T tile[CMAX + CMAX / 2 + 8];
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t PQ = p.P * p.Q;
+    const uint64_t b0 = (uint64_t)blockIdx.x * p.G;
+    const uint32_t Gc = (uint32_t)(p.planes - b0 < p.G ? p.planes - b0 : p.G);
+    const T *tc = t + b0 * PQ, *oc = o + b0 * PQ;
+    T *outc = out + b0 * PQ;
+    const T oval = p.o_scalar ? *o : T{};
+    auto lds_of_t = [&](uint32_t e) -> uint32_t {  // element e of the chunk in t's order: plane e / PQ, row j, column i
+        uint32_t b, r, j, i;
+        p.pq.divmod(e, b, r);
+        p.pdiv.divmod(r, j, i);
+        return (b * p.Q + j) * p.pitch + i;
+    };
+    if (Gc == p.G) {  // a whole chunk (uniform): G * P * Q elements, a multiple of the vector width
+        const uint32_t NV = p.G * PQ / W;
+        V tv[S], ov[S];
+        auto issue = [&](auto nt_tag) {
+            constexpr bool NT = decltype(nt_tag)::value;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const uint32_t v = threadIdx.x + 256u * s, vc = v < NV ? v : NV - 1;
+                tv[s] = load_stream_as(T, reinterpret_cast<const V *>(tc) + vc, NT);
+                if (!p.o_scalar) ov[s] = load_stream_as(T, reinterpret_cast<const V *>(oc) + vc, NT);
+            }
+        };
+        if (p.nt & kLoadNt) issue(BoolTag<true>{});
+        else issue(BoolTag<false>{});
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t v = threadIdx.x + 256u * s;
+            if (v < NV) {
+                uint32_t b, r, j, i;
+                p.pq.divmod(v * W, b, r);
+                p.pdiv.divmod(r, j, i);
+#pragma unroll
+                for (int kk = 0; kk < W; ++kk) {
+                    tile[(b * p.Q + j) * p.pitch + i] = tv[s][kk];
+                    if (++i == p.P) { i = 0; if (++j == p.Q) { j = 0; ++b; } }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t v = threadIdx.x + 256u * s;
+            if (v < NV) {
+                uint32_t b, r, i, j;  // out element: plane b, row i (of P), column j (of Q)  <-  t's row j, column i
+                p.pq.divmod(v * W, b, r);
+                p.qdiv.divmod(r, i, j);
+                T xt[W], xo[W], xr[W];
+#pragma unroll
+                for (int kk = 0; kk < W; ++kk) {
+                    xt[kk] = tile[(b * p.Q + j) * p.pitch + i];
+                    xo[kk] = p.o_scalar ? oval : ov[s][kk];
+                    if (++j == p.Q) { j = 0; if (++i == p.P) { i = 0; ++b; } }
+                }
+                if (T_IS_A) apply_n<Op, T, W>(ctx, xt, xo, xr);
+                else apply_n<Op, T, W>(ctx, xo, xt, xr);
+                V val;
+#pragma unroll
+                for (int kk = 0; kk < W; ++kk) val[kk] = xr[kk];
+                store_stream_if(T, reinterpret_cast<V *>(outc) + v, val, p.nt);
+            }
+        }
+        return;
+    }
+    // the last, partial chunk: element by element
+    const uint32_t C = Gc * PQ;
+    for (uint32_t e = threadIdx.x; e < C; e += 256) tile[lds_of_t(e)] = tc[e];
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < C; e += 256) {
+        uint32_t b, r, i, j;
+        p.pq.divmod(e, b, r);
+        p.qdiv.divmod(r, i, j);
+        const T xt = tile[(b * p.Q + j) * p.pitch + i], xo = p.o_scalar ? oval : oc[e];
+        outc[e] = T_IS_A ? Op::apply(xt, xo) : Op::apply(xo, xt);
+    }
+}
+
+// Is the normalised problem a dense batch of small planes with one operand read transposed?
+inline bool plan_planes(const Plan &pl, int esz, PlanesParams *pp, bool *t_is_a) {
+    static const bool off = [] { const char *e = getenv("SMHIP_PLANES_KERNEL"); return e && *e && atoi(e) == 0; }();  // tools: SMHIP_PLANES_KERNEL=0
+    if (off || pl.ndim != 3) return false;
+    const int64_t B = pl.shape[0], P = pl.shape[1], Q = pl.shape[2], PQ = P * Q;
+    const int W = 16 / esz, cmax = 32768 / esz;
+    if (P < 2 || Q < 2 || PQ > cmax || B < 64) return false;
+    if (P % 64 == 0 && (Q * esz) % 128 == 0) return false;  // whole 64-row patches with line-aligned rows: the tile kernel's best case (64 x 64: 89 % against 78 % here)
+    auto turned = [&](const int64_t *st) { return st[0] == PQ && st[1] == 1 && st[2] == P; };
+    auto dense = [&](const int64_t *st) { return st[0] == PQ && st[1] == Q && st[2] == 1; };
+    auto scalar = [&](const int64_t *st) { return st[0] == 0 && st[1] == 0 && st[2] == 0; };
+    const bool ta = turned(pl.sa) && (dense(pl.sb) || scalar(pl.sb)), tb = turned(pl.sb) && (dense(pl.sa) || scalar(pl.sa));
+    if (ta == tb) return false;
+    *t_is_a = ta;
+    PlanesParams r{};
+    r.o_scalar = scalar(ta ? pl.sb : pl.sa) ? 1 : 0;
+    r.P = (uint32_t)P; r.Q = (uint32_t)Q; r.pitch = (uint32_t)P | 1u;
+    r.planes = (uint64_t)B;
+    uint32_t G = (uint32_t)(cmax / PQ);
+    while (G > 0 && ((uint64_t)G * PQ) % W) --G;                       // whole vectors per chunk
+    while (G > 0 && (uint64_t)G * Q * r.pitch > (uint64_t)cmax + cmax / 2) --G;  // the padded tile fits
+    while (G > 0 && ((uint64_t)G * PQ) % W) --G;
+    if (G < 1 || (r.planes + G - 1) / G >= 0x7fffffffull) return false;
+    r.G = G;
+    r.pq = FastDiv((uint32_t)PQ); r.pdiv = FastDiv(r.P); r.qdiv = FastDiv(r.Q);
+    *pp = r;
+    return true;
+}
+
+template <typename T, typename Op>
+int run_planes(const PlanesParams &pp, bool t_is_a, const void *a, const void *b, void *out, hipStream_t s) {
+    const T *t = static_cast<const T *>(t_is_a ? a : b), *o = static_cast<const T *>(t_is_a ? b : a);
+    const dim3 grid((unsigned)((pp.planes + pp.G - 1) / pp.G)), block(256);
+    if (t_is_a) hipLaunchKernelGGL((planes_kernel<T, Op, true>), grid, block, 0, s, t, o, static_cast<T *>(out), pp);
+    else hipLaunchKernelGGL((planes_kernel<T, Op, false>), grid, block, 0, s, t, o, static_cast<T *>(out), pp);
+    SMHIP_LAUNCH_CHECK("planes_kernel");
+    return SMHIP_OK;
+}
+
 // Does the normalised plane fit the record kernel?  Fills the parameters and says which operand is the turned one.
 inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p, bool *t_is_a) {
     static const bool off = [] { const char *e = getenv("SMHIP_RECORD_KERNEL"); return e && atoi(e) == 0 && *e; }();  // tools: SMHIP_RECORD_KERNEL=0
@@ -1098,6 +1236,32 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         ((pl.sa[0] == 0 && pl.sa[1] == 1) || (pl.sa[0] == 1 && pl.sa[1] == 0 && pl.shape[1] >= SMHIP_FLAT_ROWS_MIN_COLS))) {
         // the same shape with the roles exchanged (row + A, column * A): + and * commute bit for bit
         return launch_flat_rows(op, dtype, b, a, out, (size_t)pl.shape[0], (size_t)pl.shape[1], pl.sa[0] == 0, s);
+    }
+    if (!user && pl.ndim == 3) {  // a dense batch of small planes, one operand read transposed
+        PlanesParams pp;
+        bool t_is_a;
+        if (plan_planes(pl, (int)dtype_size(dtype), &pp, &t_is_a)) {
+            const size_t esz = dtype_size(dtype), bytes = pl.n * esz;
+            const bool sa_scalar = !(pl.sa[0] || pl.sa[1] || pl.sa[2]), sb_scalar = !(pl.sb[0] || pl.sb[1] || pl.sb[2]);
+            pp.nt = (uint32_t)stream_policy({Span{a, sa_scalar ? esz : bytes}, Span{b, sb_scalar ? esz : bytes}}, Span{out, bytes});
+#define SMHIP_PLANES(T)                                                                    \
+    switch (op) {                                                                          \
+        case SMHIP_OP_ADD: return run_planes<T, AddOp<T>>(pp, t_is_a, a, b, out, s);      \
+        case SMHIP_OP_SUB: return run_planes<T, SubtractOp<T>>(pp, t_is_a, a, b, out, s); \
+        case SMHIP_OP_MUL: return run_planes<T, MultiplyOp<T>>(pp, t_is_a, a, b, out, s); \
+        case SMHIP_OP_DIV: return run_planes<T, DivideOp<T>>(pp, t_is_a, a, b, out, s);   \
+        case SMHIP_OP_POW: return run_planes<T, PowOp<T>>(pp, t_is_a, a, b, out, s);      \
+        case SMHIP_OP_LEFT: return run_planes<T, LeftOp<T>>(pp, t_is_a, a, b, out, s);    \
+    }                                                                                      \
+    break;
+            switch (dtype) {
+                case SMHIP_F32: SMHIP_PLANES(float)
+                case SMHIP_F64: SMHIP_PLANES(double)
+                case SMHIP_I32: SMHIP_PLANES(int32_t)
+                case SMHIP_I64: SMHIP_PLANES(int64_t)
+            }
+#undef SMHIP_PLANES
+        }
     }
     if (!user && (pl.ndim == 2 || pl.ndim == 3)) {
         // a plane with one tiny extent and one turned operand, or a batch of such planes (an outermost axis in front of

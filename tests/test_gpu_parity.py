@@ -1412,6 +1412,40 @@ def test_large_view_shapes_vs_numpy(smhip):
             assert np.array_equal(got, f(va, vb)), (t, dtn, opn, dims, ka, kb)
 
 
+def test_small_planes_batched(smhip):
+    """A dense batch of small planes with one operand read transposed -- (B, n, m) seen as (B, m, n) -- takes the planes
+    kernel (broadcast.hip): plane shapes from 2 x 2 to 64 x 64 incl. odd ones, batch counts that end inside a workgroup's
+    chunk, the transposed operand on either side of a non-commutative Op, every element type, plain copies; numpy is the
+    specification."""
+    rng = np.random.default_rng(99)
+    t = 0
+    for n, m in ((2, 2), (3, 3), (4, 4), (3, 5), (7, 2), (8, 8), (12, 12), (16, 16), (16, 3), (3, 16), (24, 24), (31, 33), (32, 32), (48, 48), (64, 64), (5, 100), (100, 5)):
+        for B in (64, 1000, 4099):
+            t += 1
+            dtn = ("f32", "f64", "i32", "i64")[t % 4]
+            dt = DT[dtn]
+            x = gen.gen(dt, B * n * m, 100 + t, "uniform").reshape(B, n, m)
+            y = gen.gen(dt, B * n * m, 200 + t, "uniform").reshape(B, m, n)
+            dx, dy = smhip.to_device(x), smhip.to_device(y)
+            xt = np.transpose(x, (0, 2, 1))
+            got = smhip.binary(sma.OPS["sub"], dx.view_like(xt, x), dy).numpy()
+            assert np.array_equal(got, xt - y), ("planes", n, m, B, dtn)
+            got = smhip.binary(sma.OPS["sub"], dy, dx.view_like(xt, x)).numpy()
+            assert np.array_equal(got, y - xt), ("planes swapped", n, m, B, dtn)
+            dst = smhip.empty((B, m, n), dt)
+            smhip.assign(dst, dx.view_like(xt, x))
+            assert np.array_equal(dst.numpy(), xt), ("planes copy", n, m, B, dtn)
+    for dt in (np.float32, np.float64):  # pow: the tables share the LDS with the tile
+        base = rng.uniform(0.05, 30.0, (3000, 6, 10)).astype(dt)
+        e = rng.uniform(-3.0, 3.0, (3000, 10, 6)).astype(dt)
+        bt = np.transpose(base, (0, 2, 1))
+        got = smhip.binary(sma.OP_POW, smhip.to_device(base).view_like(bt, base), smhip.to_device(e)).numpy()
+        with np.errstate(all="ignore"):
+            exact = np.power(bt.astype(np.longdouble), e.astype(np.longdouble)).astype(dt)
+        it = np.int32 if dt == np.float32 else np.int64
+        assert np.abs(got.view(it).astype(np.int64) - exact.view(it).astype(np.int64)).max() <= 1, dt
+
+
 def test_few_long_rows_against_one_row(smhip):
     """Config 3's shape with FEW LONG rows -- (6, 2^21) op (1, 2^21): the flat tile kernel walks such arrays column block by
     column block (eight workgroups on one row's neighbouring tiles, the next eight on the next row's) so that the broadcast
