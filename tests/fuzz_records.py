@@ -42,6 +42,16 @@ for c in range(cases):
         dst = smhip.empty((B, k, n), dt); smhip.assign(dst, drecs.view_like(rt, recs)); got = dst.numpy(); want = rt
     else:
         dst = smhip.empty((B, n, k), dt); smhip.assign(dst, dwide.view_like(wt, wide)); got = dst.numpy(); want = wt
+    if c % 3 == 0:  # ... and a dense batch of small planes read transposed (the planes kernel, or the tile kernel past its limits)
+        pn, pm, pB = int(rng.integers(2, 100)), int(rng.integers(2, 100)), int(rng.choice([64, 65, 257, 1000, 3001]))
+        x = gen.gen(dt, pB * pn * pm, 3000 + c, "uniform").reshape(pB, pn, pm)
+        y = gen.gen(dt, pB * pn * pm, 4000 + c, "uniform").reshape(pB, pm, pn)
+        dx, dy = smhip.to_device(x), smhip.to_device(y)
+        xt = np.transpose(x, (0, 2, 1))
+        g2 = smhip.binary(sma.OPS[opn], dy, dx.view_like(xt, x)).numpy()
+        if not np.array_equal(g2, f(y, xt)):
+            print("MISMATCH planes", (c, dtn, pn, pm, pB, opn))
+            sys.exit(1)
     if not np.array_equal(got, want):
         bad = np.argwhere(got != want)
         print("MISMATCH", what, "differing:", len(bad), "first at", bad[0])
