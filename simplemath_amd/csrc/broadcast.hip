@@ -668,7 +668,7 @@ template <typename T, typename Op, bool SMALL_P, bool T_IS_A>
 __global__ __launch_bounds__(256) void record_kernel(const T *__restrict__ t, const T *__restrict__ o, T *__restrict__ out, RecordParams p) {
     constexpr int W = VecTraits<T>::width, CMAX = record_chunk<T>(), S = CMAX / (W * 256);
     typedef typename VecTraits<T>::vec_t V;
-    __shared__ T tile[CMAX + CMAX / 32 + 32 * 17];
+    __shared__ T tile[CMAX + CMAX / 32 + 128 * 16];  // k rows of at most R + R / 32 + 16 words, k <= 128
     OpCtx<Op> ctx;
     ctx.init();
     const uint32_t k = p.k, R = p.R, PITCH = p.pitch;
@@ -935,11 +935,13 @@ inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p
     *t_is_a = ta;
     RecordParams r{};
     r.o_scalar = scalar(so) ? 1 : 0;
-    if (P <= 32 && Q >= 4096 && st[1] == P) {            // few long rows out of dense records: AoS -> SoA
+    static const int64_t max_p = [] { const char *e = getenv("SMHIP_RECORD_MAX_P"); return e && *e ? (int64_t)atoi(e) : (int64_t)128; }();
+    static const int64_t max_q = [] { const char *e = getenv("SMHIP_RECORD_MAX_Q"); return e && *e ? (int64_t)atoi(e) : (int64_t)128; }();
+    if (P <= max_p && Q >= 4096 && st[1] == P) {            // few long rows out of dense records: AoS -> SoA
         *small_p = true;
         r.k = (uint32_t)P; r.n = (uint64_t)Q;
         r.o_pitch = so[0];
-    } else if (Q < 16 && P >= 4096 && (r.o_scalar || so[0] == Q)) {  // records out of few long rows: SoA -> AoS (16 and up: the tile kernel's short patch)
+    } else if ((Q < 16 || (Q <= max_q && (Q * esz) % 128 != 0)) && P >= 4096 && (r.o_scalar || so[0] == Q)) {  // records out of few long rows: SoA -> AoS (whole short patch rows: the tile kernel)
         *small_p = false;
         r.k = (uint32_t)Q; r.n = (uint64_t)P;
         r.t_pitch = st[1];
@@ -947,7 +949,7 @@ inline bool plan_record(const Plan &pl, int esz, RecordParams *rp, bool *small_p
         return false;
     }
     r.R = (uint32_t)(cmax / (int64_t)r.k) / 64 * 64;
-    if (r.R < 64) return false;
+    if (r.R < 64 || r.k > 128) return false;
     // a smaller R that divides the plane's record count spares every plane its element-wise last chunk (a batch of
     // 224 x 224 x 3 images: 18.7 chunks of 2688 records -> 28 whole chunks of 1792)
     for (uint32_t m = r.R / 64; m >= (r.R / 64 + 1) / 2; --m)

@@ -17,7 +17,7 @@ OPS = {"add": np.add, "sub": np.subtract, "mul": np.multiply}
 for c in range(cases):
     dtn = ("f32", "f64", "i32", "i64")[int(rng.integers(0, 4))]
     dt = DT[dtn]
-    k = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 20, 24, 31, 32, 33, 40, 48, 64]))
+    k = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 20, 24, 31, 32, 33, 40, 48, 64, 72, 96, 100, 127, 128]))
     n = int(rng.choice([4096, 4097, 5000, 8192, 12345, 40000, 65536, 100003]))
     B = int(rng.choice([1, 1, 1, 2, 5]))
     pad = int(rng.choice([0, 0, 0, 1, 7, 64]))

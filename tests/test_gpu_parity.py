@@ -1465,12 +1465,12 @@ def test_few_long_rows_against_one_row(smhip):
 
 def test_record_kernel_aos_soa(smhip):
     """Planes with one tiny extent and one turned operand (arrays of small records <-> few long rows) take the record kernel
-    (broadcast.hip): records of 2 ... 32 elements, both directions, the turned operand on either side of a non-commutative
+    (broadcast.hip): records of 2 ... 128 elements, both directions, the turned operand on either side of a non-commutative
     Op, record counts that end inside a workgroup's chunk, padded row pitches, every element type, and the same shapes as
     plain copies (`dst = src.T`); numpy is the specification (one correctly rounded operation per element)."""
     rng = np.random.default_rng(4242)
     t = 0
-    for k in (2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 24, 32):
+    for k in (2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 24, 32, 36, 48, 100, 128):
         for n in (4096, 5000 + k, 70001):
             t += 1
             dtn = ("f32", "f64", "i32", "i64")[t % 4]

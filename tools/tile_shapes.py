@@ -34,6 +34,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "pow2":   # the record kernel: long exte
               (8388608, 8), (8388608 + 4096, 8), (6, 8388608), (24, 2097152))
 if len(sys.argv) > 2 and sys.argv[2] == "odd":   # extents that are not a multiple of the vector width: the tile kernel's element form
     SHAPES = ((8192, 8192), (8191, 8191), (8190, 8190), (8188, 8188), (8191, 8192), (8192, 8191), (12287, 12287), (12284, 12284), (16383, 16383))
+if len(sys.argv) > 2 and sys.argv[2] == "mid":   # a small extent between the record kernel's 32 and a whole patch
+    SHAPES = ((36, 1 << 21), (40, 1 << 21), (48, 1 << 21), (56, 1 << 21), (64, 1 << 21), (72, 1 << 20), (96, 1 << 20), (1 << 21, 36), (1 << 21, 40), (1 << 21, 48), (1 << 21, 72), (1 << 20, 100))
 if len(sys.argv) > 2 and sys.argv[2] == "fine":   # around the size where the wide patch takes over
     SHAPES = ((6144, 8192), (8192, 6144), (8192, 8192), (8192, 8704), (8704, 8192), (9216, 9216), (8192, 10240), (10240, 8192), (9728, 9728), (4096, 20480), (20480, 4096),
               (10240, 10240), (8192, 12288), (12288, 8192), (11264, 11264), (2048, 65536), (65536, 2048))
