@@ -625,6 +625,77 @@ __global__ __launch_bounds__(256) void short_rows_kernel(const T *__restrict__ x
     }
 }
 
+// Short rows of a VIEW: out (rows, c) dense = a op b with both operands stepping by one along the row and by their own pitch
+// from row to row (a column slice A[:, :c] of a wider array, or a dense array: pitch = c).  The row kernel gives a row to a
+// few lanes and leaves most of a wave idle on rows of 17 ... 127 elements (44-67 % of peak, tools/short_inner.py); here the
+// OUTPUT is walked flat, one 16-byte vector per lane: one fast division finds the vector's row and column, a dense operand
+// is one vector load, a pitched one W single loads that follow the row boundaries.
+template <typename T, typename Op, bool A_DENSE, bool B_DENSE>
+__global__ __launch_bounds__(256) void pitched_rows_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, FastDiv c,
+                                                           int64_t pa, int64_t pb, uint32_t n_vec, uint32_t n, int nt) {
+    constexpr int W = VecTraits<T>::width;
+    typedef typename VecTraits<T>::vec_t V;
+    OpCtx<Op> ctx;
+    ctx.init();
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v > n_vec) return;
+    const uint32_t e0 = v * W;
+    uint32_t row, col;
+    c.divmod(e0, row, col);
+    const bool whole = c.d % W == 0;  // uniform
+    if (v < n_vec) {
+        T xa[W], xb[W], res[W];
+        auto fetch = [&](const T *base, int64_t pitch, auto dense_tag, T (&dst)[W]) {
+            if constexpr (decltype(dense_tag)::value) {
+                const V val = load_stream_if(T, reinterpret_cast<const V *>(base + e0), nt);
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst[k] = val[k];
+            } else if (whole && pitch % W == 0 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0) {  // rows of whole vectors on 16-byte boundaries (misaligned vector loads lose to W single loads here: 79 against 87 %)
+                const V val = load_stream_if(T, reinterpret_cast<const V *>(base + (int64_t)row * pitch + col), nt);
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst[k] = val[k];
+            } else {
+                uint32_t r = row, cc = col;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    dst[k] = base[(int64_t)r * pitch + cc];
+                    if (++cc == c.d) { cc = 0; ++r; }
+                }
+            }
+        };
+        fetch(a, pa, BoolTag<A_DENSE>{}, xa);
+        fetch(b, pb, BoolTag<B_DENSE>{}, xb);
+        apply_n<Op, T, W>(ctx, xa, xb, res);
+        V rv;
+#pragma unroll
+        for (int k = 0; k < W; ++k) rv[k] = res[k];
+        store_stream_if(T, reinterpret_cast<V *>(out + e0), rv, nt);
+    } else {
+        uint32_t r = row, cc = col;
+        for (uint32_t e = e0; e < n; ++e) {
+            out[e] = Op::apply(a[(int64_t)r * pa + cc], b[(int64_t)r * pb + cc]);
+            if (++cc == c.d) { cc = 0; ++r; }
+        }
+    }
+}
+
+template <typename T, typename Op>
+int run_pitched_rows(const void *a, const void *b, void *out, size_t rows, uint32_t c, int64_t pa, int64_t pb, hipStream_t s) {
+    constexpr int W = VecTraits<T>::width;
+    const size_t n = rows * c;
+    const uint32_t n_vec = (uint32_t)(n / W);
+    const dim3 grid((unsigned)(((size_t)n_vec + 1 + 255) / 256)), block(256);
+    const T *ta = static_cast<const T *>(a), *tb = static_cast<const T *>(b);
+    const int nt = stream_policy({Span{a, (size_t)((rows - 1) * pa + c) * sizeof(T)}, Span{b, (size_t)((rows - 1) * pb + c) * sizeof(T)}}, Span{out, n * sizeof(T)});
+    const bool ad = pa == (int64_t)c, bd = pb == (int64_t)c;
+    T *po = static_cast<T *>(out);
+    if (ad) hipLaunchKernelGGL((pitched_rows_kernel<T, Op, true, false>), grid, block, 0, s, ta, tb, po, FastDiv(c), pa, pb, n_vec, (uint32_t)n, nt);
+    else if (bd) hipLaunchKernelGGL((pitched_rows_kernel<T, Op, false, true>), grid, block, 0, s, ta, tb, po, FastDiv(c), pa, pb, n_vec, (uint32_t)n, nt);
+    else hipLaunchKernelGGL((pitched_rows_kernel<T, Op, false, false>), grid, block, 0, s, ta, tb, po, FastDiv(c), pa, pb, n_vec, (uint32_t)n, nt);
+    SMHIP_LAUNCH_CHECK("pitched_rows_kernel");
+    return SMHIP_OK;
+}
+
 template <typename T, typename Op>
 int run_short_rows(const void *x, const void *y, void *out, size_t rows, uint32_t r, bool swapped, hipStream_t s) {
     constexpr int W = VecTraits<T>::width;
@@ -1206,7 +1277,8 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
             size_t rep = 1;
             while ((period * rep) % (size_t)W) ++rep;  // at most W copies make the period a whole number of vectors
             const size_t cols = period * rep, rows = pl.n / cols;
-            if (pl.n % cols || rows < 4 || cols * esz > ((size_t)2 << 20)) continue;
+            const size_t tail_periods = (pl.n % cols) / period;  // whole periods behind the last whole row (< rep of them): a launch of their own
+            if (rows < 4 || cols * esz > ((size_t)2 << 20)) continue;
             if (k == pl.ndim - 1 && rep == 1) continue;  // already rows against one row: the flat route below takes it as it is
             ScratchLease lease;
             double *tmp8;
@@ -1219,7 +1291,22 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
             const void *x = role == 0 ? a : b, *y = role == 0 ? b : a;
             const Plan sub = normalise(eshape, esy, zeros, en);
             if (int rc = launch_plan(SMHIP_OP_LEFT, dtype, y, y, tmp8, sub, s)) return rc;
-            return launch_flat_rows(op, dtype, x, tmp8, out, rows, cols, true, s);
+            if (int rc = launch_flat_rows(op, dtype, x, tmp8, out, rows, cols, true, s)) return rc;
+            if (tail_periods) {
+                // (rows of 31 against one row: four periods make whole vectors, and 2^26 / 31 rows are not a multiple of four --
+                // until round 3 that sent the whole problem to the row kernel: 40 % instead of 86 %)
+                const size_t done = rows * cols;
+                eshape[0] = (int64_t)tail_periods;
+                int64_t esx[SMHIP_MAX_NDIM + 1];
+                int64_t run_x = 1;
+                for (int d = en - 1; d >= 1; --d) { esx[d] = run_x; run_x *= eshape[d]; }
+                esx[0] = run_x;
+                const char *xt = static_cast<const char *>(x) + done * esz;
+                char *ot = static_cast<char *>(out) + done * esz;
+                const Plan tailp = role == 0 ? normalise(eshape, esx, esy, en) : normalise(eshape, esy, esx, en);
+                return role == 0 ? launch_plan(op, dtype, xt, y, ot, tailp, s) : launch_plan(op, dtype, y, xt, ot, tailp, s);
+            }
+            return SMHIP_OK;
         }
     }
     const bool heavy = op == SMHIP_OP_POW && (dtype == SMHIP_F32 || dtype == SMHIP_F64);  // as launch_aot's kRows: float / double pow only
@@ -1328,7 +1415,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
     }
     if (user) return jit_launch(op, dtype, L, a, b, out, s);
     // rows of 2..15 elements against one value per row: x dense (r, 1), y a dense vector (1, 0)
-    if (L.kind == Launch::kGather && pl.ndim == 2 && pl.shape[1] >= 2 && pl.shape[1] < 16 && op != SMHIP_OP_LEFT) {
+    // ... and rows of any length that is not a whole number of vectors (17, 31, 63 elements): the row kernel handled those at
+    // 46-66 % (tools/short_inner.py); the flat tile kernel's column form takes the whole-vector lengths
+    const bool odd_rows = L.kind == Launch::kRow && pl.ndim == 2 && pl.shape[1] >= 16 && pl.shape[1] <= 1024 &&
+                          pl.shape[1] % (16 / (int64_t)dtype_size(dtype)) != 0 && pl.n < 0x7fffffffull;
+    if ((odd_rows || (L.kind == Launch::kGather && pl.shape[1] >= 2 && pl.shape[1] < 16)) && pl.ndim == 2 && op != SMHIP_OP_LEFT) {
         const bool y_is_b = pl.sa[0] == pl.shape[1] && pl.sa[1] == 1 && pl.sb[0] == 1 && pl.sb[1] == 0;
         const bool y_is_a = pl.sb[0] == pl.shape[1] && pl.sb[1] == 1 && pl.sa[0] == 1 && pl.sa[1] == 0;
         if (y_is_b || y_is_a) {
@@ -1352,6 +1443,29 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
             }
 #undef SMHIP_SHORT_ROWS
         }
+    }
+    // short rows of a view against a dense partner or another view (both stepping by one along the row)
+    static const int64_t pitched_max = [] { const char *e = getenv("SMHIP_PITCHED_ROWS_MAX"); return e && *e ? (int64_t)atoi(e) : (int64_t)4096; }();
+    if ((L.kind == Launch::kRow || L.kind == Launch::kGather) && pl.ndim == 2 && op != SMHIP_OP_LEFT && pl.sa[1] == 1 && pl.sb[1] == 1 && pl.shape[1] >= 2 && pl.shape[1] < pitched_max &&
+        pl.sa[0] >= pl.shape[1] && pl.sb[0] >= pl.shape[1] && (pl.sa[0] != pl.shape[1] || pl.sb[0] != pl.shape[1]) && pl.n < 0x7fffffffull) {
+        const size_t rows = (size_t)pl.shape[0];
+        const uint32_t c = (uint32_t)pl.shape[1];
+#define SMHIP_PITCHED(T)                                                                                         \
+    switch (op) {                                                                                                \
+        case SMHIP_OP_ADD: return run_pitched_rows<T, AddOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s);     \
+        case SMHIP_OP_SUB: return run_pitched_rows<T, SubtractOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s); \
+        case SMHIP_OP_MUL: return run_pitched_rows<T, MultiplyOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s); \
+        case SMHIP_OP_DIV: return run_pitched_rows<T, DivideOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s);  \
+        case SMHIP_OP_POW: return run_pitched_rows<T, PowOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s);     \
+    }                                                                                                            \
+    break;
+        switch (dtype) {
+            case SMHIP_F32: SMHIP_PITCHED(float)
+            case SMHIP_F64: SMHIP_PITCHED(double)
+            case SMHIP_I32: SMHIP_PITCHED(int32_t)
+            case SMHIP_I64: SMHIP_PITCHED(int64_t)
+        }
+#undef SMHIP_PITCHED
     }
 #define SMHIP_DISPATCH_OP(T)                                                                   \
     switch (op) {                                                                              \

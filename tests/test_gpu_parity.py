@@ -741,7 +741,7 @@ def test_short_rows_against_per_row_values(smhip, oracle):
     element type and Op, rows that straddle vectors and workgroups, element counts with every tail."""
     for dtn, op in (("f32", "div"), ("f64", "mul"), ("i32", "sub"), ("i64", "add"), ("f32", "pow")):
         dt = DT[dtn]
-        for n, r in ((20000, 3), (9001, 5), (10007, 15), (12345, 2), (8193, 7)):
+        for n, r in ((20000, 3), (9001, 5), (10007, 15), (12345, 2), (8193, 7), (5001, 17), (3000, 31), (2003, 63), (1001, 250), (70, 1023)):  # (from 16 up: rows that are not whole vectors)
             kind = "positive" if op == "pow" else "uniform"
             x = gen.gen(dt, n * r, 141, kind).reshape(n, r)
             y = gen.gen(dt, n, 142, "nonzero" if dtn[0] == "i" else kind).reshape(n, 1)
@@ -1204,6 +1204,19 @@ def test_periodic_small_operand_is_written_out_once(smhip):
     xs = rng.uniform(0.5, 2.0, (3, 7, 5, 256, 1200)).astype(np.float64)            # 123 MiB... of f64: (3, 7, 5, 256, 1200) * 8 B = 246 MiB
     ys = rng.uniform(0.5, 2.0, (7, 1, 256, 1)).astype(np.float64)                  # ignores axes 0 and 2, constant along the last
     assert np.array_equal(smhip.binary(sma.OP_SUB, dev(xs), dev(ys)).numpy(), xs - ys)
+
+
+def test_periodic_route_with_leftover_rows(smhip):
+    """Rows of 31 against one row at >= 128 MiB: four periods make whole vectors, and a row count that is not a multiple of
+    four leaves up to three rows to a launch of their own (until round 3 such counts sent the whole problem to the row
+    kernel); both operand orders, against numpy."""
+    rng = np.random.default_rng(5)
+    for rows, c in ((1083000 + 3, 31), (2000001, 17)):
+        x = rng.uniform(0.5, 2.0, (rows, c)).astype(np.float32)
+        r = rng.uniform(0.5, 2.0, (1, c)).astype(np.float32)
+        dx, dr = smhip.to_device(x), smhip.to_device(r)
+        assert np.array_equal(smhip.binary(sma.OP_SUB, dx, dr).numpy(), x - r), (rows, c)
+        assert np.array_equal(smhip.binary(sma.OP_MUL, dr, dx).numpy(), r * x), (rows, c)
 
 
 def test_fuzz_policy_smoke(smhip):
