@@ -630,7 +630,8 @@ __global__ __launch_bounds__(256) void short_rows_kernel(const T *__restrict__ x
 // few lanes and leaves most of a wave idle on rows of 17 ... 127 elements (44-67 % of peak, tools/short_inner.py); here the
 // OUTPUT is walked flat, one 16-byte vector per lane: one fast division finds the vector's row and column, a dense operand
 // is one vector load, a pitched one W single loads that follow the row boundaries.
-template <typename T, typename Op, bool A_DENSE, bool B_DENSE>
+// AK / BK: 0 the operand steps by its pitch from row to row, 1 it is dense (pitch = c), 2 it is ONE value (view op scalar).
+template <typename T, typename Op, int AK, int BK>
 __global__ __launch_bounds__(256) void pitched_rows_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, FastDiv c,
                                                            int64_t pa, int64_t pb, uint32_t n_vec, uint32_t n, int nt) {
     constexpr int W = VecTraits<T>::width;
@@ -645,8 +646,12 @@ __global__ __launch_bounds__(256) void pitched_rows_kernel(const T *__restrict__
     const bool whole = c.d % W == 0;  // uniform
     if (v < n_vec) {
         T xa[W], xb[W], res[W];
-        auto fetch = [&](const T *base, int64_t pitch, auto dense_tag, T (&dst)[W]) {
-            if constexpr (decltype(dense_tag)::value) {
+        auto fetch = [&](const T *base, int64_t pitch, auto kind_tag, T (&dst)[W]) {
+            if constexpr (decltype(kind_tag)::value == 2) {
+                const T one = *base;
+#pragma unroll
+                for (int k = 0; k < W; ++k) dst[k] = one;
+            } else if constexpr (decltype(kind_tag)::value == 1) {
                 const V val = load_stream_if(T, reinterpret_cast<const V *>(base + e0), nt);
 #pragma unroll
                 for (int k = 0; k < W; ++k) dst[k] = val[k];
@@ -663,8 +668,8 @@ __global__ __launch_bounds__(256) void pitched_rows_kernel(const T *__restrict__
                 }
             }
         };
-        fetch(a, pa, BoolTag<A_DENSE>{}, xa);
-        fetch(b, pb, BoolTag<B_DENSE>{}, xb);
+        fetch(a, pa, IntTag<AK>{}, xa);
+        fetch(b, pb, IntTag<BK>{}, xb);
         apply_n<Op, T, W>(ctx, xa, xb, res);
         V rv;
 #pragma unroll
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(256) void pitched_rows_kernel(const T *__restrict__
     } else {
         uint32_t r = row, cc = col;
         for (uint32_t e = e0; e < n; ++e) {
-            out[e] = Op::apply(a[(int64_t)r * pa + cc], b[(int64_t)r * pb + cc]);
+            out[e] = Op::apply(AK == 2 ? *a : a[(int64_t)r * pa + cc], BK == 2 ? *b : b[(int64_t)r * pb + cc]);
             if (++cc == c.d) { cc = 0; ++r; }
         }
     }
@@ -686,12 +691,19 @@ int run_pitched_rows(const void *a, const void *b, void *out, size_t rows, uint3
     const uint32_t n_vec = (uint32_t)(n / W);
     const dim3 grid((unsigned)(((size_t)n_vec + 1 + 255) / 256)), block(256);
     const T *ta = static_cast<const T *>(a), *tb = static_cast<const T *>(b);
-    const int nt = stream_policy({Span{a, (size_t)((rows - 1) * pa + c) * sizeof(T)}, Span{b, (size_t)((rows - 1) * pb + c) * sizeof(T)}}, Span{out, n * sizeof(T)});
-    const bool ad = pa == (int64_t)c, bd = pb == (int64_t)c;
+    const int nt = stream_policy({Span{a, pa ? (size_t)((rows - 1) * pa + c) * sizeof(T) : sizeof(T)}, Span{b, pb ? (size_t)((rows - 1) * pb + c) * sizeof(T) : sizeof(T)}}, Span{out, n * sizeof(T)});
+    // kinds: 2 = one value (pitch 0 from the caller), 1 = dense, 0 = pitched
+    const int ak = pa == 0 ? 2 : pa == (int64_t)c ? 1 : 0, bk = pb == 0 ? 2 : pb == (int64_t)c ? 1 : 0;
     T *po = static_cast<T *>(out);
-    if (ad) hipLaunchKernelGGL((pitched_rows_kernel<T, Op, true, false>), grid, block, 0, s, ta, tb, po, FastDiv(c), pa, pb, n_vec, (uint32_t)n, nt);
-    else if (bd) hipLaunchKernelGGL((pitched_rows_kernel<T, Op, false, true>), grid, block, 0, s, ta, tb, po, FastDiv(c), pa, pb, n_vec, (uint32_t)n, nt);
-    else hipLaunchKernelGGL((pitched_rows_kernel<T, Op, false, false>), grid, block, 0, s, ta, tb, po, FastDiv(c), pa, pb, n_vec, (uint32_t)n, nt);
+    const FastDiv cd(c);
+#define SMHIP_GO(AK, BK) hipLaunchKernelGGL((pitched_rows_kernel<T, Op, AK, BK>), grid, block, 0, s, ta, tb, po, cd, pa, pb, n_vec, (uint32_t)n, nt)
+    if (ak == 0 && bk == 0) SMHIP_GO(0, 0);
+    else if (ak == 0 && bk == 1) SMHIP_GO(0, 1);
+    else if (ak == 1 && bk == 0) SMHIP_GO(1, 0);
+    else if (ak == 0 && bk == 2) SMHIP_GO(0, 2);
+    else if (ak == 2 && bk == 0) SMHIP_GO(2, 0);
+    else return fail(SMHIP_ERR_INVALID, "pitched rows: no view among the operands");
+#undef SMHIP_GO
     SMHIP_LAUNCH_CHECK("pitched_rows_kernel");
     return SMHIP_OK;
 }
@@ -1446,8 +1458,11 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
     }
     // short rows of a view against a dense partner or another view (both stepping by one along the row)
     static const int64_t pitched_max = [] { const char *e = getenv("SMHIP_PITCHED_ROWS_MAX"); return e && *e ? (int64_t)atoi(e) : (int64_t)4096; }();
-    if ((L.kind == Launch::kRow || L.kind == Launch::kGather) && pl.ndim == 2 && op != SMHIP_OP_LEFT && pl.sa[1] == 1 && pl.sb[1] == 1 && pl.shape[1] >= 2 && pl.shape[1] < pitched_max &&
-        pl.sa[0] >= pl.shape[1] && pl.sb[0] >= pl.shape[1] && (pl.sa[0] != pl.shape[1] || pl.sb[0] != pl.shape[1]) && pl.n < 0x7fffffffull) {
+    auto rowwise = [&](const int64_t *st) { return st[1] == 1 && st[0] >= pl.shape[1]; };        // steps by one along the row
+    auto onevalue = [&](const int64_t *st) { return st[0] == 0 && st[1] == 0; };
+    auto pitched = [&](const int64_t *st) { return rowwise(st) && st[0] != pl.shape[1]; };        // ... and is a view
+    if ((L.kind == Launch::kRow || L.kind == Launch::kGather) && pl.ndim == 2 && pl.shape[1] >= 2 && pl.shape[1] < pitched_max &&
+        pl.n < 0x7fffffffull && (pitched(pl.sa) || pitched(pl.sb)) && (rowwise(pl.sa) || onevalue(pl.sa)) && (rowwise(pl.sb) || onevalue(pl.sb))) {
         const size_t rows = (size_t)pl.shape[0];
         const uint32_t c = (uint32_t)pl.shape[1];
 #define SMHIP_PITCHED(T)                                                                                         \
@@ -1457,6 +1472,7 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
         case SMHIP_OP_MUL: return run_pitched_rows<T, MultiplyOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s); \
         case SMHIP_OP_DIV: return run_pitched_rows<T, DivideOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s);  \
         case SMHIP_OP_POW: return run_pitched_rows<T, PowOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s);     \
+        case SMHIP_OP_LEFT: return run_pitched_rows<T, LeftOp<T>>(a, b, out, rows, c, pl.sa[0], pl.sb[0], s);   \
     }                                                                                                            \
     break;
         switch (dtype) {

@@ -20,8 +20,12 @@ for c in (2, 3, 5, 13, 17, 20, 31, 33, 50, 63, 64, 65, 100, 127, 250, 500, 1000,
     n = r * c
     x = lib.uniform_f32(n, 1, -1, 1); y = lib.uniform_f32(max(n, 4096), 2, -1, 1); out = lib.empty((n,), np.float32)
     line = "rows of %3d:" % c
-    for name, ys, alg in (("+row", (0, 1), 8.0), ("+col", (1, 0), 8.0), ("+dense view (pitch c+3)", None, 12.0)):
-        if ys is None:
+    for name, ys, alg in (("+row", (0, 1), 8.0), ("+col", (1, 0), 8.0), ("+dense view (pitch c+3)", None, 12.0), ("view*2", "scalar", 8.0)):
+        if ys == "scalar":
+            rr = (1 << 26) // (c + 3)
+            fn = lambda: lib.c.smhip_elementwise(C.c_int(2), C.c_int(0), C.c_void_p(x.ptr), i64([c + 3, 1]), C.c_void_p(y.ptr), i64([0, 0]), i64([rr - 1, c]), C.c_int(2), C.c_void_p(out.ptr))
+            m = (rr - 1) * c
+        elif ys is None:
             # x as a view of rows with a pitch of c + 3 (a column slice of a wider array) plus dense y
             rr = (1 << 26) // (c + 3)
             fn = lambda: lib.c.smhip_elementwise(C.c_int(0), C.c_int(0), C.c_void_p(x.ptr), i64([c + 3, 1]), C.c_void_p(y.ptr), i64([c, 1]), i64([rr - 1, c]), C.c_int(2), C.c_void_p(out.ptr))
