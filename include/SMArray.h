@@ -55,11 +55,53 @@ concept ArithmeticOrComplex =
     (requires { typename T::value_type; } && std::is_arithmetic_v<typename T::value_type> &&
      std::same_as<T, std::complex<typename T::value_type>>);
 
+template <ArithmeticOrComplex T>
+class SMArray;
+
 namespace detail {
+
+// ---- deferred operator chains ------------------------------------------------------------------------------------------
+// The reference evaluates `(A * row + B) * 0.5f` as three operator calls with a temporary each (SMArray.h:217-305); here
+// a temporary that feeds the next operator OF THE SAME FULL-EXPRESSION is never written to HBM: + - * / do not launch
+// at once, they record a one-stage *chain* in the result's Storage, and an operator whose operand is that unevaluated
+// temporary (an rvalue) extends the chain instead of reading it.  The chain is launched -- as ONE kernel where its
+// operands allow, smhip_chain -- at the latest when the full-expression ends: every operator argument binds to a small
+// wrapper (Operand / ScalarArg below) whose destructor, run when the statement's temporaries die, evaluates whatever is
+// still pending on the thread.  So a NAMED value is always computed by the end of the statement that names it; nothing
+// stays lazy across statements.  Before that point a chain is evaluated as soon as anything looks at its result (`data`,
+// operator(), toString(), device_data(), another library call), and before any array is WRITTEN (host or device), so
+// an operand cannot change under a recorded chain.  At most one chain is pending per thread.
+struct PendingBase {
+    virtual void run() = 0;  // evaluate into the Storage that owns this object (and destroy it)
+    virtual ~PendingBase() = default;
+};
+inline thread_local PendingBase *tls_pending = nullptr;
+inline void flush_pending() {
+    if (PendingBase *p = tls_pending) {
+        tls_pending = nullptr;
+        p->run();
+    }
+}
+// What the fusion did on this thread (tests and benchmarks read it through sm::fusion_stats()).
+struct FusionStats {
+    unsigned long long chains = 0;        // smhip_chain calls: expressions of two or more operators evaluated as one call
+    unsigned long long fused_stages = 0;  // operators inside them
+    unsigned long long single_ops = 0;    // deferred operators that ended up alone and ran as the plain operator
+};
+inline thread_local FusionStats tls_fusion_stats;
+// The end of a full-expression, seen from the destructor of one of its temporaries.
+inline void end_of_expression(int exceptions_at_birth) {
+    if (!tls_pending) return;
+    if (std::uncaught_exceptions() > exceptions_at_birth) {  // unwinding: the result is being destroyed as well, nothing to compute
+        tls_pending = nullptr;
+        return;
+    }
+    flush_pending();
+}
 
 // One allocation, shared by an owning array and every view of it.
 template <typename T>
-struct Storage {
+struct Storage : std::enable_shared_from_this<Storage<T>> {
     T *host = nullptr;
     void *dev = nullptr;
     std::size_t count = 0;
@@ -69,18 +111,34 @@ struct Storage {
     int device = 0;           // the GPU the device buffer lives on (the creating thread's current device)
     unsigned inline_uses = 0; // times the host-only elements rode in a kernel's argument block instead of being uploaded
     unsigned fetches = 0;     // single elements read back one at a time (fetch()); after a few the whole array is mirrored
+    std::unique_ptr<PendingBase> pending;  // the operator chain that will produce these elements, while it has not run
+
+    // The values are about to be looked at: run the recorded chain first.
+    void ensure() {
+        if (pending) {
+            if (tls_pending == pending.get()) tls_pending = nullptr;
+            pending->run();  // resets `pending`
+        }
+    }
+    // An array is about to be written: a chain recorded on this thread may still want its old values.
+    void before_write() {
+        ensure();
+        if (tls_pending) flush_pending();
+    }
 
     explicit Storage(std::size_t n) : count(n) { smhip_get_device(&device); }
     Storage(T *adopted, std::size_t n) : host(adopted), count(n), host_valid(true) { smhip_get_device(&device); }  // takes ownership of new T[]
     Storage(const Storage &) = delete;
     Storage &operator=(const Storage &) = delete;
     ~Storage() {
+        if (pending && tls_pending == pending.get()) tls_pending = nullptr;  // a result nobody looked at: never computed
         if (dev) smhip_free(dev);
         delete[] host;
     }
 
     // host side current, device side left valid (read-only intent)
     const T *host_ro() {
+        ensure();
         if (!host) host = new T[count ? count : 1];
         if (!host_valid) {
             if (dev_valid) {
@@ -98,6 +156,7 @@ struct Storage {
     // copy stays valid) and further reads are host reads.
     static constexpr unsigned kFetchesBeforeMirror = 8;
     T fetch(std::size_t index) {
+        ensure();
         if (host_valid || !dev_valid || ++fetches > kFetchesBeforeMirror) return host_ro()[index];
         T v;
         hip::DeviceGuard on(device);
@@ -106,12 +165,14 @@ struct Storage {
     }
     // host side current and possibly about to be written: device side goes stale
     T *host_rw() {
+        before_write();
         host_ro();
         dev_valid = false;
         return host;
     }
     // device side current, host mirror stays valid
     T *dev_ro() {
+        ensure();
         if (!dev || !dev_valid) {
             hip::DeviceGuard on(device);
             if (!dev) hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
@@ -124,12 +185,14 @@ struct Storage {
     }
     // device side current and about to be partly overwritten: host mirror goes stale
     T *dev_rw() {
+        before_write();
         T *p = dev_ro();
         host_valid = false;
         return p;
     }
     // device side about to be overwritten entirely
     T *dev_wo() {
+        before_write();
         if (!dev) {
             hip::DeviceGuard on(device);
             hip::check(smhip_alloc(&dev, (count ? count : 1) * sizeof(T)));
@@ -170,6 +233,40 @@ private:
     std::shared_ptr<Storage<T>> st_;
     std::size_t offset_ = 0;
 };
+
+// What the array argument of + - * / binds to (implicitly, from an SMArray lvalue or rvalue).  It remembers whether the
+// argument was a temporary -- only a temporary's unevaluated chain may be continued -- and its destructor marks the end
+// of the full-expression (see "deferred operator chains" above).
+template <typename T>
+class Operand {
+public:
+    Operand(const SMArray<T> &a) : arr_(&a), rvalue_(false), exceptions_(std::uncaught_exceptions()) {}  // NOLINT: implicit on purpose
+    Operand(SMArray<T> &&a) : arr_(&a), rvalue_(true), exceptions_(std::uncaught_exceptions()) {}       // NOLINT
+    Operand(const Operand &) = delete;
+    Operand &operator=(const Operand &) = delete;
+    ~Operand() noexcept(false) { end_of_expression(exceptions_); }
+    const SMArray<T> &array() const { return *arr_; }
+    bool temporary() const { return rvalue_; }
+private:
+    const SMArray<T> *arr_;
+    bool rvalue_;
+    int exceptions_;
+};
+// The scalar argument of + - * / (implicitly from a T): same end-of-expression duty.
+template <typename T>
+class ScalarArg {
+public:
+    ScalarArg(T v) : value(v), exceptions_(std::uncaught_exceptions()) {}  // NOLINT: implicit on purpose
+    ScalarArg(const ScalarArg &) = delete;
+    ScalarArg &operator=(const ScalarArg &) = delete;
+    ~ScalarArg() noexcept(false) { end_of_expression(exceptions_); }
+    T value;
+private:
+    int exceptions_;
+};
+
+template <typename T>
+struct Chain;
 
 inline std::vector<std::size_t> dense_strides(const std::vector<std::size_t> &shape) {
     std::vector<std::size_t> st(shape.size());
@@ -350,14 +447,26 @@ public:
         }
     }
 
-    SMArray operator+(const SMArray &arr) const { return apply<AddOp<T>>(arr); }
-    SMArray operator-(const SMArray &arr) const { return apply<SubtractOp<T>>(arr); }
-    SMArray operator*(const SMArray &arr) const { return apply<MultiplyOp<T>>(arr); }
-    SMArray operator/(const SMArray &arr) const { return apply<DivideOp<T>>(arr); }
-    SMArray operator+(const T val) const { return apply_scalar<AddOp<T>>(val); }
-    SMArray operator-(const T val) const { return apply_scalar<SubtractOp<T>>(val); }
-    SMArray operator*(const T val) const { return apply_scalar<MultiplyOp<T>>(val); }
-    SMArray operator/(const T val) const { return apply_scalar<DivideOp<T>>(val); }
+    // + - * / with an array (NumPy broadcasting) or a scalar: reference SMArray.h:217-305.  The argument types convert
+    // implicitly from SMArray / T (detail::Operand, detail::ScalarArg); the && forms are chosen when the left operand
+    // is a temporary, whose not-yet-evaluated chain the operator then continues (see "deferred operator chains" above):
+    // `(A * row + B) * 0.5f` is one kernel and 12 bytes per element, not three and 28.
+    SMArray operator+(const detail::Operand<T> &rhs) const & { return deferred<AddOp<T>>(*this, false, &rhs, T{}); }
+    SMArray operator-(const detail::Operand<T> &rhs) const & { return deferred<SubtractOp<T>>(*this, false, &rhs, T{}); }
+    SMArray operator*(const detail::Operand<T> &rhs) const & { return deferred<MultiplyOp<T>>(*this, false, &rhs, T{}); }
+    SMArray operator/(const detail::Operand<T> &rhs) const & { return deferred<DivideOp<T>>(*this, false, &rhs, T{}); }
+    SMArray operator+(const detail::Operand<T> &rhs) && { return deferred<AddOp<T>>(*this, true, &rhs, T{}); }
+    SMArray operator-(const detail::Operand<T> &rhs) && { return deferred<SubtractOp<T>>(*this, true, &rhs, T{}); }
+    SMArray operator*(const detail::Operand<T> &rhs) && { return deferred<MultiplyOp<T>>(*this, true, &rhs, T{}); }
+    SMArray operator/(const detail::Operand<T> &rhs) && { return deferred<DivideOp<T>>(*this, true, &rhs, T{}); }
+    SMArray operator+(const detail::ScalarArg<T> &val) const & { return deferred<AddOp<T>>(*this, false, nullptr, val.value); }
+    SMArray operator-(const detail::ScalarArg<T> &val) const & { return deferred<SubtractOp<T>>(*this, false, nullptr, val.value); }
+    SMArray operator*(const detail::ScalarArg<T> &val) const & { return deferred<MultiplyOp<T>>(*this, false, nullptr, val.value); }
+    SMArray operator/(const detail::ScalarArg<T> &val) const & { return deferred<DivideOp<T>>(*this, false, nullptr, val.value); }
+    SMArray operator+(const detail::ScalarArg<T> &val) && { return deferred<AddOp<T>>(*this, true, nullptr, val.value); }
+    SMArray operator-(const detail::ScalarArg<T> &val) && { return deferred<SubtractOp<T>>(*this, true, nullptr, val.value); }
+    SMArray operator*(const detail::ScalarArg<T> &val) && { return deferred<MultiplyOp<T>>(*this, true, nullptr, val.value); }
+    SMArray operator/(const detail::ScalarArg<T> &val) && { return deferred<DivideOp<T>>(*this, true, nullptr, val.value); }
 
     // Broadcasted `*this Op rhs` for any Op policy: what a user-added operator calls
     // (the README's "add the operator in SMArray.h" step, without editing the class).
@@ -371,22 +480,7 @@ public:
         if constexpr (hip::on_device_v<T, Op>) {
             hip::DeviceGuard on(common_device(*this, rhs));  // the kernel runs where the operands live; the result is born there
             SMArray out = device_empty(std::move(br.resultShape));
-            if (!out._shape.empty() && out.totalSize <= SMHIP_INLINE_MAX_OUTPUTS && (host_only_small() || rhs.host_only_small()) &&
-                hip::device_op<Op>::id() <= SMHIP_OP_POW) {
-                // a tiny operand that exists only on the host rides in the kernel's argument block: one packet instead
-                // of an upload packet plus a kernel packet (smhip_elementwise_inline)
-                const std::size_t ia = host_only_small(), ib = rhs.host_only_small();
-                const auto sa = hip::to_i64(br.newStrides1), sb = hip::to_i64(br.newStrides2), sh = hip::to_i64(out._shape);
-                hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id,
-                                                    ia ? static_cast<const void *>(data.read()) : device_data(), ia, sa.data(),
-                                                    ib ? static_cast<const void *>(rhs.data.read()) : rhs.device_data(), ib, sb.data(),
-                                                    sh.data(), static_cast<int>(sh.size()), out.device_data_mut()));
-                if (ia) ++data.storage()->inline_uses;
-                if (ib) ++rhs.data.storage()->inline_uses;
-                return out;
-            }
-            hip::element_wise_op_device<T, Op>(device_data(), br.newStrides1, rhs.device_data(), br.newStrides2,
-                                               out.device_data_mut(), out._shape);
+            apply_into<Op>(rhs, br, out);
             return out;
         } else {
             T *result = new T[br.totalSize ? br.totalSize : 1];
@@ -407,24 +501,7 @@ public:
         if constexpr (hip::on_device_v<T, Op>) {
             hip::DeviceGuard on(device());
             SMArray out = device_empty(std::vector<std::size_t>(_shape));
-            if (!_shape.empty() && totalSize <= SMHIP_INLINE_MAX_OUTPUTS && host_only_small() && hip::device_op<Op>::id() <= SMHIP_OP_POW) {
-                // host-built tiny array op scalar: both ride in the launch packet
-                const auto sa = hip::to_i64(_strides), sh = hip::to_i64(_shape);
-                const std::vector<std::int64_t> zeros(sh.size(), 0);
-                hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id, data.read(), host_only_small(), sa.data(),
-                                                    &value, sizeof(T), zeros.data(), sh.data(), static_cast<int>(sh.size()),
-                                                    out.device_data_mut()));
-                ++data.storage()->inline_uses;
-                return out;
-            }
-            if (is_dense()) {
-                hip::array_scalar_op_device<T, Op>(device_data(), value, totalSize, out.device_data_mut());
-            } else {  // a view: honour its strides (the reference reads views as flat here, SURVEY 8a quirk 3)
-                hip::DeviceBuffer s(sizeof(T));
-                hip::check(smhip_upload(s.get(), &value, sizeof(T)));
-                hip::element_wise_op_device<T, Op>(device_data(), _strides, s.template as<T>(),
-                                                   std::vector<std::size_t>(_shape.size(), 0), out.device_data_mut(), _shape);
-            }
+            apply_scalar_into<Op>(value, out);
             return out;
         } else {
             std::vector<T> flat(totalSize ? totalSize : 1);
@@ -440,6 +517,56 @@ public:
         }
     }
 
+private:
+    // The device-side body of apply<Op>: `*this Op rhs` into `out` (dense, of br's result shape, on the operands' GPU).
+    template <typename Op>
+    void apply_into(const SMArray &rhs, const BroadCastResult &br, SMArray &out) const {
+        {
+            if (!out._shape.empty() && out.totalSize <= SMHIP_INLINE_MAX_OUTPUTS && (host_only_small() || rhs.host_only_small()) &&
+                hip::device_op<Op>::id() <= SMHIP_OP_POW) {
+                // a tiny operand that exists only on the host rides in the kernel's argument block: one packet instead
+                // of an upload packet plus a kernel packet (smhip_elementwise_inline)
+                const std::size_t ia = host_only_small(), ib = rhs.host_only_small();
+                const auto sa = hip::to_i64(br.newStrides1), sb = hip::to_i64(br.newStrides2), sh = hip::to_i64(out._shape);
+                hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id,
+                                                    ia ? static_cast<const void *>(data.read()) : device_data(), ia, sa.data(),
+                                                    ib ? static_cast<const void *>(rhs.data.read()) : rhs.device_data(), ib, sb.data(),
+                                                    sh.data(), static_cast<int>(sh.size()), out.device_data_mut()));
+                if (ia) ++data.storage()->inline_uses;
+                if (ib) ++rhs.data.storage()->inline_uses;
+                return;
+            }
+            hip::element_wise_op_device<T, Op>(device_data(), br.newStrides1, rhs.device_data(), br.newStrides2,
+                                               out.device_data_mut(), out._shape);
+        }
+    }
+
+    // The device-side body of apply_scalar<Op>, into `out` (dense, of this array's shape).
+    template <typename Op>
+    void apply_scalar_into(T value, SMArray &out) const {
+        {
+            if (!_shape.empty() && totalSize <= SMHIP_INLINE_MAX_OUTPUTS && host_only_small() && hip::device_op<Op>::id() <= SMHIP_OP_POW) {
+                // host-built tiny array op scalar: both ride in the launch packet
+                const auto sa = hip::to_i64(_strides), sh = hip::to_i64(_shape);
+                const std::vector<std::int64_t> zeros(sh.size(), 0);
+                hip::check(smhip_elementwise_inline(hip::device_op<Op>::id(), hip::dtype_of<T>::id, data.read(), host_only_small(), sa.data(),
+                                                    &value, sizeof(T), zeros.data(), sh.data(), static_cast<int>(sh.size()),
+                                                    out.device_data_mut()));
+                ++data.storage()->inline_uses;
+                return;
+            }
+            if (is_dense()) {
+                hip::array_scalar_op_device<T, Op>(device_data(), value, totalSize, out.device_data_mut());
+            } else {  // a view: honour its strides (the reference reads views as flat here, SURVEY 8a quirk 3)
+                hip::DeviceBuffer s(sizeof(T));
+                hip::check(smhip_upload(s.get(), &value, sizeof(T)));
+                hip::element_wise_op_device<T, Op>(device_data(), _strides, s.template as<T>(),
+                                                   std::vector<std::size_t>(_shape.size(), 0), out.device_data_mut(), _shape);
+            }
+        }
+    }
+
+public:
     [[nodiscard]] std::string toString() const {
         std::ostringstream oss;
         const T *base = data.read();
@@ -481,8 +608,15 @@ public:
     // The GPU two operands of one operator share.  Kernels run on the operands' device (the operators take a DeviceGuard on
     // it, whatever GPU the calling thread is on); operands resident on DIFFERENT GPUs cannot meet in one kernel -- peer
     // access is not assumed -- and that is an error, not a silent wrong-device launch.
+    // An operand that has no device buffer yet (host-built, or a result still pending) belongs to no GPU in particular: it
+    // adopts its partner's and is uploaded / born there.
     static int common_device(const SMArray &x, const SMArray &y) {
-        const int dx = x.device(), dy = y.device();
+        auto &sx = *x.data.storage(), &sy = *y.data.storage();
+        if (sx.device != sy.device) {
+            if (!sx.dev && !sx.pending) sx.device = sy.device;
+            else if (!sy.dev && !sy.pending) sy.device = sx.device;
+        }
+        const int dx = sx.device, dy = sy.device;
         if (dx != dy)
             throw std::runtime_error("simpleMath/MI355X: the operands live on different GPUs (" + std::to_string(dx) + " and " + std::to_string(dy) +
                                      "); bring them to one device first (sm::Sharded<T>::gather / scatter, or build both on the same GPU)");
@@ -537,6 +671,71 @@ private:
     bool isView = false;
 
     SMArray() = default;  // internal: views and device-born results
+
+    friend struct detail::Chain<T>;
+
+    // Another handle on the same elements (same storage, offset, shape, strides): what a recorded chain keeps of an operand.
+    SMArray alias() const {
+        SMArray v;
+        v.data = data;
+        v._shape = _shape;
+        v._strides = _strides;
+        v.ndim = ndim;
+        v.totalSize = totalSize;
+        v.isView = true;
+        return v;
+    }
+
+    // Is this array the unevaluated result of the chain pending on this thread, with nobody else holding its storage?  Only
+    // then may an operator that consumes it (as a temporary) continue the chain instead of reading the result.
+    detail::Chain<T> *continuable() const {
+        const auto &st = data.storage();
+        if (!st || !st->pending || detail::tls_pending != st->pending.get() || isView || data.offset() != 0 || st.use_count() != 1) return nullptr;
+        auto *c = static_cast<detail::Chain<T> *>(st->pending.get());
+        return c->full() ? nullptr : c;
+    }
+
+    // x Op y (y == nullptr: x Op scalar), recorded rather than launched when it can be part of a one-pass chain: built-in
+    // + - * / on an element type with kernels.  See "deferred operator chains" at the top of this file.
+    template <typename Op>
+    static SMArray deferred(const SMArray &x, bool x_temporary, const detail::Operand<T> *rhs, T scalar) {
+        constexpr bool chainable = hip::on_device_v<T, Op> && hip::is_builtin_op<Op>::value && !std::is_same_v<Op, PowOp<T>>;
+        if constexpr (!chainable) {
+            return rhs ? x.template apply<Op>(rhs->array()) : x.template apply_scalar<Op>(scalar);
+        } else {
+            const SMArray *y = rhs ? &rhs->array() : nullptr;
+            std::vector<std::size_t> shape = (!y || x._shape == y->_shape) ? x._shape : sm::broadcast(x._shape, x._strides, y->_shape, y->_strides).resultShape;
+            if (shape.size() > MAX_NDIM) throw std::runtime_error("rank exceeds MAX_NDIM");
+            const std::size_t n = calculateTotalSize(shape);
+            // nothing to gain from waiting: empty and 0-d results, and tiny host-built operands (they ride in the launch
+            // packet of the plain operator, apply_into)
+            detail::Chain<T> *cx = x_temporary ? x.continuable() : nullptr;
+            detail::Chain<T> *cy = (!cx && y && rhs->temporary()) ? y->continuable() : nullptr;
+            if (shape.empty() || n == 0 || (!cx && !cy && n <= SMHIP_INLINE_MAX_OUTPUTS && (x.host_only_small() || (y && y->host_only_small()))))
+                return y ? x.template apply<Op>(*y) : x.template apply_scalar<Op>(scalar);
+            const int device = y ? common_device(x, *y) : x.device();
+            const int op = hip::device_op<Op>::id();
+            hip::DeviceGuard on(device);
+            SMArray out = device_empty(std::move(shape));  // no device buffer yet: Storage allocates on first use
+            detail::Storage<T> &ost = *out.data.storage();
+            if (cx) {  // (pending temporary) Op y: the chain goes on
+                ost.pending = std::move(x.data.storage()->pending);
+                cx->retarget(&ost, out._shape);
+                if (y) cx->push(op, false, *y); else cx->push(op, false, scalar);
+            } else if (cy) {  // x Op (pending temporary): the same, with the stage's operands exchanged
+                ost.pending = std::move(y->data.storage()->pending);
+                cy->retarget(&ost, out._shape);
+                cy->push(op, true, x);
+            } else {
+                detail::flush_pending();  // one chain per thread
+                auto c = std::make_unique<detail::Chain<T>>(&ost, out._shape, device, x);
+                if (y) c->push(op, false, *y); else c->push(op, false, scalar);
+                detail::tls_pending = c.get();
+                ost.pending = std::move(c);
+            }
+            return out;
+        }
+    }
 
     void finish_owning(T *buffer) {
         ndim = _shape.size();
@@ -654,5 +853,107 @@ private:
         return v;
     }
 };
+
+namespace detail {
+
+// A recorded operator chain: r = leaf[0]; r = r op[k] leaf[k + 1] (swapped[k]: leaf[k + 1] op[k] r).  Owned by the Storage
+// of its (not yet computed) result; run() evaluates it there -- through smhip_chain (csrc/chain.hip: one pass where the
+// operands allow), or, for a chain that stayed one operator long, through the plain operator's own path.
+template <typename T>
+struct Chain final : PendingBase {
+    static constexpr int kMaxLeaves = 8;
+    struct Leaf {
+        SMArray<T> array;  // an alias: keeps the operand's storage alive, knows its offset / shape / strides
+        bool is_scalar = false;
+        T value{};
+        Leaf(SMArray<T> &&a) : array(std::move(a)) {}
+        Leaf(SMArray<T> &&a, T v) : array(std::move(a)), is_scalar(true), value(v) {}
+    };
+    Storage<T> *out;
+    std::vector<std::size_t> shape;  // of the result so far
+    int device;
+    std::vector<Leaf> leaves;
+    int ops[kMaxLeaves] = {}, swapped[kMaxLeaves] = {};
+
+    Chain(Storage<T> *o, const std::vector<std::size_t> &sh, int dev, const SMArray<T> &head) : out(o), shape(sh), device(dev) {
+        leaves.reserve(4);
+        leaves.emplace_back(head.alias());
+    }
+    bool full() const { return static_cast<int>(leaves.size()) == kMaxLeaves; }
+    void retarget(Storage<T> *o, const std::vector<std::size_t> &sh) { out = o; shape = sh; }
+    void push(int op, bool swap, const SMArray<T> &operand) {
+        ops[leaves.size() - 1] = op;
+        swapped[leaves.size() - 1] = swap;
+        leaves.emplace_back(operand.alias());
+    }
+    void push(int op, bool swap, T scalar) {
+        ops[leaves.size() - 1] = op;
+        swapped[leaves.size() - 1] = swap;
+        leaves.emplace_back(leaves[0].array.alias(), scalar);  // the alias is a placeholder: a scalar leaf has no array
+    }
+
+    void run() override {
+        std::unique_ptr<PendingBase> self = std::move(out->pending);  // the result is no longer pending; *this lives to the end of run()
+        if (tls_pending == this) tls_pending = nullptr;
+        SMArray<T> result;  // a handle on the result's storage for the duration of the call
+        result.data = HostPtr<T>(out->shared_from_this(), 0);
+        result._shape = shape;
+        result._strides = dense_strides(shape);
+        result.ndim = shape.size();
+        result.totalSize = calculateTotalSize(shape);
+        hip::DeviceGuard on(device);
+        const int n = static_cast<int>(leaves.size());
+        if (n == 2) {  // one operator after all: exactly what the operator did before chains existed
+            ++tls_fusion_stats.single_ops;
+            single(result);
+            return;
+        }
+        const std::size_t nd = shape.size();
+        std::vector<std::int64_t> strides(static_cast<std::size_t>(n) * nd, 0), sh(shape.begin(), shape.end());
+        const void *ptrs[kMaxLeaves] = {};
+        T scalars[kMaxLeaves] = {};
+        for (int k = 0; k < n; ++k) {
+            const Leaf &lf = leaves[k];
+            if (lf.is_scalar) { scalars[k] = lf.value; continue; }
+            const auto &ls = lf.array._shape;
+            const auto &lt = lf.array._strides;
+            const std::size_t shift = nd - ls.size();  // right-aligned, as sm::broadcast aligns them (SMUtils.h:51-72)
+            for (std::size_t i = 0; i < ls.size(); ++i) strides[k * nd + shift + i] = (ls[i] == 1 && shape[shift + i] != 1) ? 0 : static_cast<std::int64_t>(lt[i]);
+            ptrs[k] = lf.array.device_data();
+        }
+        ++tls_fusion_stats.chains;
+        tls_fusion_stats.fused_stages += static_cast<unsigned long long>(n - 1);
+        hip::check(smhip_chain(hip::dtype_of<T>::id, n, ptrs, strides.data(), scalars, ops, swapped, sh.data(), static_cast<int>(nd),
+                               result.device_data_mut()));
+    }
+
+private:
+    template <typename Op>
+    void single_op(SMArray<T> &result) {
+        const SMArray<T> &x = leaves[0].array;
+        if (leaves[1].is_scalar) {
+            x.template apply_scalar_into<Op>(leaves[1].value, result);
+        } else {
+            const SMArray<T> &y = leaves[1].array;
+            auto br = x._shape == y._shape ? BroadCastResult{{}, {}, x._strides, {}, y._strides, x.totalSize}
+                                           : sm::broadcast(x._shape, x._strides, y._shape, y._strides);
+            x.template apply_into<Op>(y, br, result);
+        }
+    }
+    void single(SMArray<T> &result) {
+        switch (ops[0]) {
+            case SMHIP_OP_ADD: single_op<AddOp<T>>(result); break;
+            case SMHIP_OP_SUB: single_op<SubtractOp<T>>(result); break;
+            case SMHIP_OP_MUL: single_op<MultiplyOp<T>>(result); break;
+            default: single_op<DivideOp<T>>(result); break;
+        }
+    }
+};
+
+}  // namespace detail
+
+// What the operator fusion did on the calling thread so far (chains evaluated as one call, operators inside them, deferred
+// operators that stayed alone).
+inline detail::FusionStats fusion_stats() { return detail::tls_fusion_stats; }
 
 }  // namespace sm

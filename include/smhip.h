@@ -195,6 +195,22 @@ int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, 
 int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const void *b, const void *c,
                            const void *c_scalar_host, void *out, size_t n);
 
+/* A CHAIN of broadcasted operators in as few passes as possible -- one, when every operand is dense, a row, a column /
+ * per-row value, periodic in the output, or a scalar:
+ *     r = x[0];   r = r ops[k] x[k+1]   (swapped[k] != 0:  r = x[k+1] ops[k] r),   k = 0 .. n_operands - 2;   out = r
+ * What the reference evaluates as n_operands - 1 operator calls with a fresh temporary each (SMArray.h:217-305, `new T[n]`
+ * at :219; element_wise_op / array_scalar_op, calculate.h:5-169) -- `(A * row + B) * 0.5f` is 28 bytes per f32 element
+ * there and 12 here.  operands[k] is a device pointer to operand k's first element with strides[k * ndim .. ) its strides
+ * broadcast against `shape` (0 where it broadcasts; as smhip_broadcast returns them), or NULL for a scalar whose value is
+ * element k of scalars_host (n_operands elements of the element type in host memory; entries of array operands are
+ * ignored).  operands[0] must be an array.  ops[k] in {ADD, SUB, MUL, DIV}.  `out` is dense row-major over `shape` and
+ * must not overlap an operand.  Each stage is the single rounded / wrapping operation the separate operator performs, so
+ * the result is bit-identical to the operator chain.  An operand the one-pass kernel has no index form for (a transposed
+ * or stepped view) cuts the chain: that operator runs through smhip_elementwise's kernels, the rest stays fused. */
+#define SMHIP_CHAIN_MAX_OPERANDS 16
+int smhip_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
+                const int *ops, const int *swapped, const int64_t *shape, int ndim, void *out);
+
 /* ----------------------------------------------------------- multi-GPU */
 /* The reference's only fan-out is the OpenMP `parallel for` over chunks of the output (calculate.h:47, :152).  Its
  * MI355X counterpart is the RESULT's outermost dimension cut into one block per GPU of the node: elementwise blocks

@@ -300,6 +300,54 @@ class Smhip:
                                                C.c_void_p(b.ptr), cp, sp, C.c_void_p(out.ptr), C.c_size_t(a.size)))
         return out
 
+    def chain_call(self, first: DeviceArray, *stages, out: DeviceArray | None = None):
+        """(callable, out): the prepared smhip_chain call for `chain(first, *stages)` -- timing loops call it without
+        paying the argument marshalling again."""
+        dt = first.dtype
+        shape = list(first.shape)
+        for st in stages:
+            x = st[1]
+            if isinstance(x, DeviceArray):
+                assert x.dtype == dt
+                res = self.broadcast(shape, [0] * len(shape), x.shape, x.strides)
+                if res is None:
+                    raise RuntimeError("Cannot broadcast shapes: incompatible dimensions")
+                shape = res[0]
+        nd = len(shape)
+        operands = [first] + [st[1] for st in stages]
+        strides, ptrs, scal = [], [], np.zeros(len(operands), dtype=dt)
+        for k, x in enumerate(operands):
+            if isinstance(x, DeviceArray):
+                res = self.broadcast(shape, [0] * nd, x.shape, x.strides)
+                strides += list(res[2])
+                ptrs.append(x.ptr)
+            else:
+                strides += [0] * nd
+                ptrs.append(None)
+                scal[k] = x
+        if out is None:
+            out = self.empty(shape, dt)
+        ops = (C.c_int * len(stages))(*[int(st[0]) for st in stages])
+        swp = (C.c_int * len(stages))(*[1 if len(st) > 2 and st[2] else 0 for st in stages])
+        args = (C.c_int(DTYPES[dt]), C.c_int(len(operands)), (C.c_void_p * len(operands))(*ptrs), _i64(strides),
+                scal.ctypes.data_as(C.c_void_p), ops, swp, _i64(shape), C.c_int(nd), C.c_void_p(out.ptr))
+        keep = (operands, scal, out)  # the arrays stay alive as long as the callable does
+        fn = self.c.smhip_chain
+
+        def call(_keep=keep):
+            rc = fn(*args)
+            if rc < 0:
+                self._ck(rc)
+        return call, out
+
+    def chain(self, first: DeviceArray, *stages, out: DeviceArray | None = None):
+        """An operator chain in as few passes as possible (smhip_chain): r = first; then for each stage (op, x) -- or
+        (op, x, True) for the swapped form x op r -- r = r op x with NumPy broadcasting; x a DeviceArray or a scalar.
+        What SMArray's operators queue when a temporary feeds the next operator of the same expression."""
+        call, out = self.chain_call(first, *stages, out=out)
+        call()
+        return out
+
     def fused_expr(self, expression: str, *arrays: DeviceArray, scalars=(), out: DeviceArray | None = None):
         """out = EXPR(a0, a1, ..., s0, ...) in one pass over dense, equal-sized operands (smhip_fused_expr)."""
         a0 = arrays[0]

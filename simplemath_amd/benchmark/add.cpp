@@ -66,6 +66,18 @@ int main() {
             char extra[112];
             std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s (28 B/elem over 3 launches)", n / r.ns_per_iter, 28.0 * n / r.ns_per_iter);
             print(r, extra);
+            // The same chain written as ONE expression: the temporaries are never written -- one kernel (smhip_chain),
+            // 12 bytes per element (A, B and the result; the 16 KiB row comes from the caches).
+            const auto before = sm::fusion_stats();
+            auto rf = run("chain_expr_check/" + std::to_string(rows) + "x4096", [&] {
+                auto t3 = (A * row + B) * 0.5f;
+                DoNotOptimize(t3);
+                ClobberMemory();
+            }, sync, 200);
+            const auto after = sm::fusion_stats();
+            std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s = %.1f %% of 8 TB/s (12 B/elem, %s)", n / rf.ns_per_iter, 12.0 * n / rf.ns_per_iter,
+                          12.0 * n / rf.ns_per_iter / 80.0, after.fused_stages - before.fused_stages == 3 * (after.chains - before.chains) ? "1 launch" : "NOT fused");
+            print(rf, extra);
         }
     }
     {

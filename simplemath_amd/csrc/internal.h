@@ -101,6 +101,7 @@ int stream_policy(std::initializer_list<Span> reads, Span write);
 // The same refinement for a policy word that was planned from sizes alone (broadcast.hip's plans are shared with the
 // run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
 int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
+int refine_policy(int policy, const Span *reads, size_t n_reads, Span write);
 
 // Large operands go out as several launches (contiguous.hip explains why).  piece_for(n_vec, streams) = the piece size in
 // 16-byte vectors for operands of n_vec of them, 0 for "one launch"; `streams` = the full-size streams the kernel moves
@@ -154,6 +155,9 @@ int jit_array_scalar(int op, int dtype, const void *a, const void *value_host, s
 inline bool user_op(int op) { return op >= SMHIP_OP_USER_BASE; }
 int launch_fused(int op1, int op2, int dtype, const void *a, const void *b, const void *c, const void *c_scalar_host, void *out,
                  size_t n, hipStream_t s);
+// chain.hip: r = x0; r = r op[k] x[k+1] (swapped[k]: x[k+1] op[k] r) over broadcast operands, as few passes as possible
+int launch_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
+                 const int *swapped, const int64_t *shape, int ndim, void *out, hipStream_t s);
 int launch_fill(int dtype, void *dst, const void *value_host, size_t n, hipStream_t s);
 int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi, hipStream_t s);
 int launch_sum(int dtype, const void *a, size_t n, double *out_dev, hipStream_t s);

@@ -349,7 +349,10 @@ int stream_policy(std::initializer_list<Span> reads, Span write) {
     return refine_policy(stream_policy(bytes_read, write.bytes), reads, write);
 }
 
-int refine_policy(int policy, std::initializer_list<Span> reads, Span write) {
+int refine_policy(int policy, std::initializer_list<Span> reads, Span write) { return refine_policy(policy, reads.begin(), reads.size(), write); }
+
+int refine_policy(int policy, const Span *reads_begin, size_t n_reads, Span write) {
+    struct Range { const Span *b, *e; const Span *begin() const { return b; } const Span *end() const { return e; } } reads{reads_begin, reads_begin + n_reads};
     size_t bytes_read = 0;
     for (const Span &r : reads) bytes_read += r.bytes;
     static const bool off = [] { const char *e = getenv("SMHIP_RESIDENCY"); return e && strcmp(e, "off") == 0; }();
@@ -890,6 +893,34 @@ int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const voi
     if (!a || !b || !out || (!c && !c_scalar_host)) return fail(SMHIP_ERR_INVALID, "fused: null buffer");
     SMHIP_ACQUIRE(s);
     return launch_fused(op1, op2, dtype, a, b, c, c_scalar_host, out, n, s);
+}
+
+int smhip_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
+                const int *swapped, const int64_t *shape, int ndim, void *out) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "chain: bad dtype %d", dtype);
+    if (n_operands < 2 || n_operands > SMHIP_CHAIN_MAX_OPERANDS) return fail(SMHIP_ERR_INVALID, "chain: %d operands outside 2..%d", n_operands, SMHIP_CHAIN_MAX_OPERANDS);
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "chain: ndim %d outside 1..%d", ndim, SMHIP_MAX_NDIM);
+    if (!operands || !strides || !ops || !swapped || !shape) return fail(SMHIP_ERR_INVALID, "chain: null argument");
+    if (!operands[0]) return fail(SMHIP_ERR_INVALID, "chain: the first operand must be an array");
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(SMHIP_ERR_INVALID, "chain: negative extent at dim %d", i);
+        n *= shape[i];
+    }
+    for (int k = 0; k < n_operands; ++k) {
+        if (!operands[k]) {
+            if (!scalars_host) return fail(SMHIP_ERR_INVALID, "chain: operand %d is a scalar but scalars_host is NULL", k);
+            continue;
+        }
+        for (int i = 0; i < ndim; ++i)
+            if (strides[(size_t)k * ndim + i] < 0) return fail(SMHIP_ERR_INVALID, "chain: negative stride (operand %d, dim %d)", k, i);
+    }
+    for (int k = 0; k + 1 < n_operands; ++k)
+        if (ops[k] < SMHIP_OP_ADD || ops[k] > SMHIP_OP_DIV) return fail(SMHIP_ERR_UNSUPPORTED, "chain: op %d (stage %d) is not one of add, sub, mul, div", ops[k], k);
+    if (n == 0) return SMHIP_OK;
+    if (!out) return fail(SMHIP_ERR_INVALID, "chain: null output");
+    SMHIP_ACQUIRE(s);
+    return launch_chain(dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, out, s);
 }
 
 int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev) {

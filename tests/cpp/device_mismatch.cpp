@@ -1,6 +1,9 @@
 // Operands resident on different GPUs must be refused, not launched on the calling thread's device: needs no
 // second GPU and no GPU at all -- the check is host-side and comes before any device call.  Storage::device is what
-// sm::Sharded<T>::part(g) hands out for GPU g; here it is set by hand.
+// sm::Sharded<T>::part(g) hands out for GPU g; here it (and a stand-in device buffer, so that the arrays count as resident)
+// is set by hand.  An array that exists only in host memory belongs to no GPU yet and adopts its partner's: two
+// host-born arrays stamped with different devices -- one built inside a per-GPU loop, a constant built outside it -- are
+// NOT refused.
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -27,6 +30,21 @@ int main() {
     b.data.storage()->device = 1;  // as if b lived on GPU 1
     ib.data.storage()->device = 1;
     int bad = 0;
+    {   // host-only operands: the stamp alone is no residence -- the operator goes on (and, on this GPU-less host, fails
+        // at its first device call with the library's "no device" error instead of the mismatch)
+        try {
+            auto r = a + b;
+            (void)r;
+        } catch (const std::runtime_error &e) {
+            if (std::string(e.what()).find("different GPUs") != std::string::npos) { std::printf("FAIL host-only a + b was refused: %s\n", e.what()); ++bad; }
+        }
+        if (b.data.storage()->device != a.data.storage()->device) { std::printf("FAIL host-only operand did not adopt its partner's device\n"); ++bad; }
+        a.data.storage()->device = 0;  // whichever adopted the other's: back to the two-GPU picture
+        b.data.storage()->device = 1;
+    }
+    // now as if every array had a device buffer on its GPU
+    for (auto *st : {a.data.storage().get(), b.data.storage().get(), c.data.storage().get()}) st->dev = reinterpret_cast<void *>(0x1000);
+    for (auto *st : {ia.data.storage().get(), ib.data.storage().get()}) st->dev = reinterpret_cast<void *>(0x1000);
     bad += expect_mismatch("a + b", [&] { auto r = a + b; });
     bad += expect_mismatch("b * a", [&] { auto r = b * a; });
     bad += expect_mismatch("a % b", [&] { volatile float r = a % b; (void)r; });
@@ -36,6 +54,8 @@ int main() {
     bad += expect_mismatch("fused(a, b, 2)", [&] { auto r = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, 2.0f); });
     bad += expect_mismatch("expr(a, c, b)", [&] { auto r = sm::expr("a0 + a1 * a2", a, c, b); });
     bad += expect_mismatch("expr_sum(a, b)", [&] { volatile double r = sm::expr_sum("a0 * a1", a, b); (void)r; });
+    for (auto *st : {a.data.storage().get(), b.data.storage().get(), c.data.storage().get()}) st->dev = nullptr;  // the stand-ins were never allocated
+    for (auto *st : {ia.data.storage().get(), ib.data.storage().get()}) st->dev = nullptr;
     std::printf(bad ? "%d FAILED\n" : "device_mismatch ok\n", bad);
     return bad ? 1 : 0;
 }

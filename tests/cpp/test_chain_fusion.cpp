@@ -1,0 +1,264 @@
+// test_chain_fusion.cpp -- operator chains through the drop-in surface: a temporary that feeds the next operator of the same
+// full-expression is fused into ONE smhip_chain call (include/SMArray.h "deferred operator chains"), named values are computed
+// by the end of their statement, and the values are bit-identical to the eager chain the reference evaluates (one operator
+// call and one temporary per step, reference SMArray.h:217-305).  Expected values: the same expression written with a
+// named value per step (which never fuses) -- itself pinned by the golden / oracle tests -- and, for small cases, the
+// statement evaluated on the host in T.
+#include <sm.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+static int g_failures = 0, g_checks = 0;
+#define CHECK(cond)                                                                   \
+    do {                                                                              \
+        ++g_checks;                                                                   \
+        if (!(cond)) {                                                                \
+            ++g_failures;                                                             \
+            if (g_failures <= 20) std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); \
+        }                                                                             \
+    } while (0)
+
+static std::uint64_t g_state = 0x9876543ull;
+static std::uint64_t rnd() {
+    std::uint64_t z = (g_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+static T sample() {
+    if constexpr (std::is_integral_v<T>) {
+        const T v = static_cast<T>(static_cast<std::int64_t>(rnd() % 2001) - 1000);
+        return v == 0 ? T(7) : v;
+    } else {
+        const double m = 0.25 + 3.75 * static_cast<double>(rnd() >> 11) / 9007199254740992.0;
+        return static_cast<T>((rnd() & 1) ? m : -m);
+    }
+}
+template <typename T, typename... D>
+static sm::SMArray<T> random_array(D... dims) {
+    std::vector<std::size_t> shape{static_cast<std::size_t>(dims)...};
+    std::size_t n = 1;
+    for (auto d : shape) n *= d;
+    T *p = new T[n];
+    for (std::size_t i = 0; i < n; ++i) p[i] = sample<T>();
+    return sm::SMArray<T>(p, std::move(shape));
+}
+template <typename T>
+static bool same_bits(const sm::SMArray<T> &x, const sm::SMArray<T> &y) {
+    if (x.shape() != y.shape()) return false;
+    return std::memcmp(x.cdata(), y.cdata(), x.totalSize * sizeof(T)) == 0;
+}
+struct Delta {
+    sm::detail::FusionStats at = sm::fusion_stats();
+    unsigned long long chains() const { return sm::fusion_stats().chains - at.chains; }
+    unsigned long long stages() const { return sm::fusion_stats().fused_stages - at.fused_stages; }
+    unsigned long long singles() const { return sm::fusion_stats().single_ops - at.single_ops; }
+};
+
+template <typename T>
+static void forms(std::size_t rows, std::size_t cols) {
+    const auto A = random_array<T>(rows, cols), B = random_array<T>(rows, cols);
+    const auto row = random_array<T>(1, cols), col = random_array<T>(rows, 1), one = random_array<T>(1, 1);
+    const T s = std::is_integral_v<T> ? T(3) : T(0.5);
+    // tiny host-built operands ride in the plain operator's launch packet and are not deferred: the counts below hold for
+    // arrays past that size (SMHIP_INLINE_MAX_OUTPUTS results)
+    const bool counted = rows * cols > SMHIP_INLINE_MAX_OUTPUTS;
+    {   // the harness's chain_check as ONE expression: one call, three operators inside
+        Delta d;
+        auto fused = (A * row + B) * s;
+        CHECK(!counted || (d.chains() == 1 && d.stages() == 3 && d.singles() == 0));
+        auto t1 = A * row;
+        auto t2 = t1 + B;
+        auto t3 = t2 * s;
+        CHECK(!counted || (d.chains() == 1 && d.singles() == 3));  // named values: one operator per statement, nothing deferred past its `;`
+        CHECK(same_bits(fused, t3));
+    }
+    {   // column, then a row on the LEFT of a non-commutative operator (the temporary is the right operand)
+        auto fused = row / ((A - col) / B + s);
+        auto t1 = A - col;
+        auto t2 = t1 / B;
+        auto t3 = t2 + s;
+        auto t4 = row / t3;
+        CHECK(same_bits(fused, t4));
+    }
+    {   // both operands of the last operator are temporaries: the left one is computed first, the right one's chain continues
+        Delta d;
+        auto fused = (A + B) * (A - row);
+        auto l = A + B;
+        auto r = A - row;
+        auto want = l * r;
+        CHECK(same_bits(fused, want));
+        CHECK(!counted || d.chains() == 1);  // one side ran alone, the other side's chain took the last operator in
+    }
+    {   // a one-element operand, and the result shape growing along the chain: (row + col) is (rows, cols)
+        auto fused = (row + col) * A - one;
+        auto t1 = row + col;
+        auto t2 = t1 * A;
+        auto t3 = t2 - one;
+        CHECK(same_bits(fused, t3));
+        auto grown = (row * s + one) * col;  // (1, cols) all the way until `* col`
+        auto g1 = row * s;
+        auto g2 = g1 + one;
+        auto g3 = g2 * col;
+        CHECK(grown.shape() == std::vector<std::size_t>({rows, cols}));
+        CHECK(same_bits(grown, g3));
+    }
+    {   // transposed views cut the chain (they run through the tile kernel) and it continues
+        const auto Sq = random_array<T>(cols, cols), Sq2 = random_array<T>(cols, cols);
+        auto fused = (Sq.transpose() + Sq2) * s - Sq;
+        auto t1 = Sq.transpose() + Sq2;
+        auto t2 = t1 * s;
+        auto t3 = t2 - Sq;
+        CHECK(same_bits(fused, t3));
+        auto fused2 = (Sq + Sq2) * Sq.transpose() - s;
+        auto u1 = Sq + Sq2;
+        auto u2 = u1 * Sq.transpose();
+        auto u3 = u2 - s;
+        CHECK(same_bits(fused2, u3));
+    }
+    {   // more operands than one chain records (8): cut and continued
+        auto fused = ((((((((A + B) * row - col) + A) * B - row) + col) * s + B) - A) * row + one) * s;
+        auto t = A + B;
+        auto t2 = t * row;
+        auto t3 = t2 - col;
+        auto t4 = t3 + A;
+        auto t5 = t4 * B;
+        auto t6 = t5 - row;
+        auto t7 = t6 + col;
+        auto t8 = t7 * s;
+        auto t9 = t8 + B;
+        auto t10 = t9 - A;
+        auto t11 = t10 * row;
+        auto t12 = t11 + one;
+        auto t13 = t12 * s;
+        CHECK(same_bits(fused, t13));
+    }
+}
+
+template <typename T>
+static void periodic_4d() {
+    // the reference tests' broadcast pattern, ones(32,224,224,3)(0, SLICE_ALL) o (1,224,1,3) (tests/add.cpp:59-92), in a chain
+    const auto big = random_array<T>(3, 28, 20, 3);
+    const auto small = random_array<T>(1, 28, 1, 3), rgb = random_array<T>(1, 1, 1, 3), per_sample = random_array<T>(3, 1, 1, 1);
+    const T s = T(2);
+    auto fused = (big + small) * rgb - per_sample * s;
+    auto t1 = big + small;
+    auto t2 = t1 * rgb;
+    auto p = per_sample * s;
+    auto t3 = t2 - p;
+    CHECK(same_bits(fused, t3));
+    auto v = big(0, SLICE_ALL);  // the view the reference tests use: (28, 20, 3) of the first sample
+    auto fused_v = (v * small + v) / s;
+    auto w1 = v * small;
+    auto w2 = w1 + v;
+    auto w3 = w2 / s;
+    CHECK(fused_v.shape() == std::vector<std::size_t>({1, 28, 20, 3}));
+    CHECK(same_bits(fused_v, w3));
+}
+
+static void host_values() {
+    // small enough to evaluate the statement on the host in T
+    sm::SMArray<float> a = {{1, 2, 3}, {4, 5, 6}};
+    sm::SMArray<float> r = {{10, 20, 30}};
+    sm::SMArray<float> c(new float[2]{0.5f, 0.25f}, {2, 1});  // ({{0.5f}, {0.25f}} would be the 1-D list {0.5f, 0.25f}: one-element braces)
+    auto out = ((a * r + a) * c - 1.0f) / 3.0f;
+    const float av[2][3] = {{1, 2, 3}, {4, 5, 6}}, rv[3] = {10, 20, 30}, cv[2] = {0.5f, 0.25f};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const float t1 = av[i][j] * rv[j], t2 = t1 + av[i][j], t3 = t2 * cv[i], t4 = t3 - 1.0f, want = t4 / 3.0f;
+            CHECK(out(i, j) == want);
+        }
+    sm::SMArray<int> ia = {{7, -7, 100}, {2147483647, -5, 9}};
+    sm::SMArray<int> ir = {{2, -3, 7}};
+    auto io = (ia / ir + ia) * 3;  // truncation toward zero, wrapping products
+    const int iav[2][3] = {{7, -7, 100}, {2147483647, -5, 9}}, irv[3] = {2, -3, 7};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const std::uint32_t q = static_cast<std::uint32_t>(iav[i][j] / irv[j]), t = q + static_cast<std::uint32_t>(iav[i][j]);
+            CHECK(io(i, j) == static_cast<int>(t * 3u));
+        }
+}
+
+static void ordering() {
+    const std::size_t n = 1 << 16;
+    // a host write between two statements: the first statement's value was computed at its `;`
+    auto a = sm::ones<float>(n), b = sm::ones<float>(n);
+    auto c = (a + b) * 2.0f;       // 4 everywhere
+    a.data[0] = 100.0f;            // must not reach c
+    CHECK(c(0) == 4.0f && c(1) == 4.0f);
+    auto d = (a + b) * 2.0f;       // sees the write
+    CHECK(d(0) == 202.0f && d(1) == 4.0f);
+    // assignment INTO an operand of the expression on its right-hand side
+    auto x = sm::ones<float>(8, 16), y = sm::ones<float>(8, 16);
+    x = (x + y) * 3.0f - x;        // 5 everywhere
+    CHECK(x(0, 0) == 5.0f && x(7, 15) == 5.0f);
+    x(SLICE(0, 2), SLICE_ALL) = (x(SLICE(0, 2), SLICE_ALL) * 2.0f + y(SLICE(0, 2), SLICE_ALL)) * 2.0f;  // 22 in rows 0-1
+    CHECK(x(0, 0) == 22.0f && x(1, 15) == 22.0f && x(2, 0) == 5.0f);
+    // a temporary's VIEW is somebody else looking at it: computed, not continued
+    auto tv = (x + y).transpose() * 2.0f;
+    CHECK(tv.shape() == std::vector<std::size_t>({16, 8}) && tv(0, 0) == 46.0f && tv(0, 2) == 12.0f);
+    // a discarded expression computes nothing and breaks nothing
+    (a + b) * 5.0f;
+    auto e = a + b;
+    CHECK(e(1) == 2.0f);
+    // an exception in the middle of an expression (shape mismatch) leaves the thread usable
+    auto p = sm::ones<float>(4, 4), q = sm::ones<float>(3, 4);
+    bool threw = false;
+    try {
+        auto bad = (p + p) * q;
+        (void)bad;
+    } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    auto ok = (p + p) * p;
+    CHECK(ok(3, 3) == 2.0f);
+    // pow, dot and sum look at a pending temporary: it is computed for them
+    auto pw = sm::pow((p + p) * p, 2.0f);
+    CHECK(pw(0, 0) == 4.0f);
+    CHECK(((p + p) * 2.0f) % p == 64.0f);
+    CHECK(((p + p) * 2.0f).sum() == 64.0);
+    // a function taking const SMArray& gets a computed value
+    auto f = [](const sm::SMArray<float> &v) { return v(0, 0) + v(3, 3); };
+    CHECK(f((p + p) * 3.0f) == 12.0f);
+    // std::move of a named value is a plain operand
+    auto m = p + p;
+    auto m2 = std::move(m) * 2.0f + p;
+    CHECK(m2(1, 1) == 5.0f);
+}
+
+static void sizes() {
+    // around the vector / workgroup boundaries, 1-D (the tail lane) and element types
+    for (std::size_t n : {std::size_t(1), std::size_t(3), std::size_t(5), std::size_t(257), std::size_t(4099), std::size_t(100003), std::size_t(1) << 20}) {
+        const auto a = random_array<double>(n), b = random_array<double>(n);
+        auto fused = (a - b) * a / 3.0;
+        auto t1 = a - b;
+        auto t2 = t1 * a;
+        auto t3 = t2 / 3.0;
+        CHECK(same_bits(fused, t3));
+    }
+}
+
+#define STEP(call) do { std::printf("%s\n", #call); std::fflush(stdout); call; } while (0)
+int main() {
+    STEP(forms<float>(67, 128));
+    STEP(forms<float>(129, 1000));
+    STEP(forms<double>(33, 64));
+    STEP(forms<std::int32_t>(67, 128));
+    STEP(forms<std::int64_t>(21, 34));
+    STEP(forms<float>(5, 3));
+    STEP(periodic_4d<float>());
+    STEP(periodic_4d<double>());
+    STEP(periodic_4d<std::int32_t>());
+    STEP(periodic_4d<std::int64_t>());
+    STEP(host_values());
+    STEP(ordering());
+    STEP(sizes());
+    const auto st = sm::fusion_stats();
+    std::printf("%d checks, %d failures; %llu chains with %llu operators inside, %llu operators alone\n", g_checks, g_failures, st.chains,
+                st.fused_stages, st.single_ops);
+    return g_failures ? 1 : 0;
+}

@@ -1,0 +1,198 @@
+"""Operator chains in one pass (smhip_chain, csrc/chain.hip) against the ORACLE'S chain: the reference evaluates
+`(A * row + B) * 0.5f` as one operator call and one temporary per step (SMArray.h:217-305), so the oracle's answer is its
+`binary` / `array_scalar` applied step by step.  Bar: bit-identical (each stage is the single rounded / wrapping operation).
+"""
+import numpy as np
+import pytest
+
+import simplemath_amd as sma
+from oracle import oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64, np.int32, np.int64]
+ORC_OP = {sma.OP_ADD: orc.ADD, sma.OP_SUB: orc.SUB, sma.OP_MUL: orc.MUL, sma.OP_DIV: orc.DIV}
+
+
+def _rand(rng, shape, dt):
+    if np.dtype(dt).kind == "f":
+        x = rng.uniform(-2.0, 2.0, size=shape).astype(dt)
+        x[np.abs(x) < 0.05] = 0.5  # divisors away from zero keep the chain finite; IEEE specials have a test of their own
+        return x
+    x = rng.integers(-1000, 1000, size=shape).astype(dt)
+    x[x == 0] = 7
+    return x
+
+
+def _oracle_chain(o, first, stages):
+    r = np.ascontiguousarray(first)
+    for st in stages:
+        op, x = ORC_OP[st[0]], st[1]
+        swapped = len(st) > 2 and st[2]
+        if isinstance(x, np.ndarray):
+            r = o.binary(op, x, r) if swapped else o.binary(op, r, x)
+        else:
+            assert not swapped
+            r = o.array_scalar(op, r.reshape(-1), x).reshape(r.shape)
+    return r
+
+
+def _device(smhip, x, keep):
+    """host operand -> device operand; `x` may be a (base, view) pair for a strided view"""
+    if isinstance(x, tuple):
+        base, view = x
+        d = smhip.to_device(base)
+        keep.append(d)
+        return d.view_like(view, base), view
+    if isinstance(x, np.ndarray):
+        d = smhip.to_device(x)
+        keep.append(d)
+        return d, x
+    return x, x
+
+
+def _run(smhip, oracle, first, stages, what):
+    keep = []
+    dfirst, hfirst = _device(smhip, first, keep)
+    dst, hst = [], []
+    for st in stages:
+        dx, hx = _device(smhip, st[1], keep)
+        dst.append((st[0], dx) + tuple(st[2:]))
+        hst.append((st[0], hx) + tuple(st[2:]))
+    got = smhip.chain(dfirst, *dst)
+    want = _oracle_chain(oracle, hfirst, hst)
+    assert list(got.shape) == list(want.shape), what
+    util.assert_same_bits(got.numpy(), want, what)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_chain_row_column_scalar(smhip, oracle, dt):
+    """(dense o row) o dense o scalar -- the harness's chain_check -- and its column / scalar / all-dense relatives."""
+    rng = np.random.default_rng(11)
+    for rows, cols in [(64, 128), (37, 52), (5, 3), (1, 7), (129, 1024)]:
+        A, B = _rand(rng, (rows, cols), dt), _rand(rng, (rows, cols), dt)
+        row, col = _rand(rng, (1, cols), dt), _rand(rng, (rows, 1), dt)
+        one = _rand(rng, (1, 1), dt)
+        s = dt(3) if np.dtype(dt).kind != "f" else dt(0.5)
+        tag = f"{np.dtype(dt).name} {rows}x{cols}"
+        _run(smhip, oracle, A, [(sma.OP_MUL, row), (sma.OP_ADD, B), (sma.OP_MUL, s)], tag + " (A*row+B)*s")
+        _run(smhip, oracle, A, [(sma.OP_SUB, col), (sma.OP_DIV, B), (sma.OP_ADD, s)], tag + " (A-col)/B+s")
+        _run(smhip, oracle, A, [(sma.OP_ADD, B), (sma.OP_MUL, A), (sma.OP_SUB, B), (sma.OP_DIV, s)], tag + " dense x4")
+        _run(smhip, oracle, A, [(sma.OP_DIV, row, True), (sma.OP_SUB, col, True)], tag + " col-(row/A)")
+        _run(smhip, oracle, A, [(sma.OP_MUL, one), (sma.OP_ADD, row), (sma.OP_SUB, col)], tag + " one-element operand")
+        _run(smhip, oracle, row, [(sma.OP_ADD, col), (sma.OP_MUL, A)], tag + " (row+col)*A: the head broadcasts too")
+        _run(smhip, oracle, col, [(sma.OP_MUL, s), (sma.OP_SUB, row, True)], tag + " row-(col*s): no dense operand at all")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_chain_periodic_4d(smhip, oracle, dt):
+    """The reference tests' broadcast pattern, (N,224,224,3) o (1,224,1,3) (tests/add.cpp:59-92), inside a chain; a
+    per-channel bias (1,C,1,1); a 3-element period (rows of 3 are not whole vectors)."""
+    rng = np.random.default_rng(12)
+    big = _rand(rng, (2, 24, 20, 3), dt)
+    small = _rand(rng, (1, 24, 1, 3), dt)
+    rgb = _rand(rng, (1, 1, 1, 3), dt)
+    s = dt(2)
+    _run(smhip, oracle, big, [(sma.OP_ADD, small), (sma.OP_MUL, rgb), (sma.OP_SUB, s)], "periodic (1,24,1,3) then rgb")
+    x = _rand(rng, (3, 8, 6, 10), dt)
+    bias = _rand(rng, (1, 8, 1, 1), dt)
+    scale = _rand(rng, (1, 8, 1, 1), dt)
+    _run(smhip, oracle, x, [(sma.OP_SUB, bias), (sma.OP_DIV, scale), (sma.OP_MUL, x)], "NCHW (x-mean)/std*x")
+    y = _rand(rng, (3, 8, 5, 7), dt)  # 35 elements per channel plane: the splat index is per element
+    bias2 = _rand(rng, (1, 8, 1, 1), dt)
+    _run(smhip, oracle, y, [(sma.OP_ADD, bias2), (sma.OP_MUL, s)], "NCHW with odd planes")
+    lead = _rand(rng, (3, 1, 1, 1), dt)
+    _run(smhip, oracle, y, [(sma.OP_MUL, lead), (sma.OP_ADD, bias2)], "per-sample value then per-channel value")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.int32], ids=lambda d: np.dtype(d).name)
+def test_chain_cut_by_views(smhip, oracle, dt):
+    """Transposed and stepped views are not leaves of the one-pass kernel: the chain is cut there and continues."""
+    rng = np.random.default_rng(13)
+    n = 96
+    A, B = _rand(rng, (n, n), dt), _rand(rng, (n, n), dt)
+    row = _rand(rng, (1, n), dt)
+    wide = _rand(rng, (n, 2 * n), dt)
+    s = dt(2)
+    _run(smhip, oracle, A, [(sma.OP_ADD, (B, B.T)), (sma.OP_MUL, row), (sma.OP_SUB, s)], "A + B.T first")
+    _run(smhip, oracle, A, [(sma.OP_MUL, row), (sma.OP_ADD, (B, B.T)), (sma.OP_SUB, s)], "B.T in the middle")
+    _run(smhip, oracle, A, [(sma.OP_MUL, row), (sma.OP_ADD, B), (sma.OP_SUB, (wide, wide[:, ::2]), True)], "stepped view last, swapped")
+    _run(smhip, oracle, (B, B.T), [(sma.OP_MUL, row), (sma.OP_ADD, A)], "the head is a transposed view")
+    _run(smhip, oracle, (B, B.T), [(sma.OP_MUL, s), (sma.OP_ADD, A)], "transposed head against a scalar")
+    _run(smhip, oracle, (wide, wide[:, 3:3 + n]), [(sma.OP_MUL, row), (sma.OP_ADD, A)], "a column block of a wider array as head")
+
+
+def test_chain_long_and_repeated_operands(smhip, oracle):
+    """More stages and more distinct operands than one kernel variant takes (4 dense, 1 row, 1 column): cut and continued."""
+    rng = np.random.default_rng(14)
+    dt = np.float32
+    shape = (48, 64)
+    arrs = [_rand(rng, shape, dt) for _ in range(7)]
+    rows = [_rand(rng, (1, 64), dt) for _ in range(3)]
+    cols = [_rand(rng, (48, 1), dt) for _ in range(2)]
+    stages = []
+    ops = [sma.OP_ADD, sma.OP_MUL, sma.OP_SUB, sma.OP_DIV]
+    for k, x in enumerate(arrs[1:] + rows + cols + [dt(1.5), arrs[0], arrs[0]]):
+        stages.append((ops[k % 4], x) + ((True,) if k % 3 == 2 and isinstance(x, np.ndarray) else ()))
+    _run(smhip, oracle, arrs[0], stages, "14-stage chain")
+    _run(smhip, oracle, arrs[0], [(sma.OP_MUL, arrs[0]), (sma.OP_ADD, arrs[0]), (sma.OP_MUL, rows[0]), (sma.OP_ADD, rows[0])], "a*a+a, row twice")
+
+
+def test_chain_ieee_specials_and_int_division(smhip, oracle):
+    spec = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1.0, -1.0, 2.5, 1e-38], dtype=np.float32)
+    A = np.tile(spec, (12, 1))
+    B = np.ascontiguousarray(A.T)
+    row = spec.reshape(1, -1)
+    _run(smhip, oracle, A, [(sma.OP_MUL, row), (sma.OP_ADD, B), (sma.OP_DIV, A), (sma.OP_SUB, np.float32(0.5))], "specials")
+    ia = np.array([[7, -7, 0, 2147483647, -2147483648, 5]], dtype=np.int32).repeat(6, 0)
+    ib = np.array([[2], [-2], [0], [-1], [1], [3]], dtype=np.int32)
+    keep = []
+    got = smhip.chain(smhip.to_device(ia), (sma.OP_DIV, smhip.to_device(ib)), (sma.OP_MUL, np.int32(3))).numpy()
+    # defined where the reference traps (ops.hip.h): x / 0 = 0, INT_MIN / -1 = INT_MIN; everything else C's truncation
+    one = smhip.binary(sma.OP_DIV, smhip.to_device(ia), smhip.to_device(ib))
+    want = smhip.array_scalar(sma.OP_MUL, one, np.int32(3)).numpy()
+    assert np.array_equal(got, want)
+    safe = (ib != 0) & ~((ia == -2147483648) & (ib == -1))
+    ref = (np.trunc(ia.astype(np.float64) / np.where(ib == 0, 1, ib)).astype(np.int64) * 3).astype(np.int32)
+    assert np.array_equal(got[safe], ref[safe])
+
+
+def test_chain_pieces_and_tail(smhip, oracle, monkeypatch):
+    """1-D chains with n % W != 0 (the tail lane) and sizes around the vector / workgroup boundaries."""
+    rng = np.random.default_rng(15)
+    for dt in (np.float32, np.float64):
+        for n in (1, 2, 3, 5, 255, 256, 257, 1023, 4099, 70001):
+            a, b = _rand(rng, (n,), dt), _rand(rng, (n,), dt)
+            one = _rand(rng, (1,), dt)
+            _run(smhip, oracle, a, [(sma.OP_ADD, b), (sma.OP_MUL, dt(0.25)), (sma.OP_SUB, one)], f"1-D n={n}")
+
+
+def test_chain_config3_size(smhip, oracle):
+    """The harness's chain at BASELINE config 3's size: (A * row + B) * 0.5 on 4096 x 4096, bit-identical to the three
+    operator calls on the GPU (which the golden and oracle tests pin), and to the oracle on a slice of rows."""
+    rows, cols = 4096, 4096
+    A = smhip.uniform_f32(rows * cols, 3, -1.0, 1.0)
+    B = smhip.uniform_f32(rows * cols, 9, -1.0, 1.0)
+    row = smhip.uniform_f32(cols, 4, -1.0, 1.0)
+    A2 = sma.DeviceArray(smhip, A.base_ptr, np.float32, (rows, cols), (cols, 1), 0, A._owner)
+    B2 = sma.DeviceArray(smhip, B.base_ptr, np.float32, (rows, cols), (cols, 1), 0, B._owner)
+    r2 = sma.DeviceArray(smhip, row.base_ptr, np.float32, (1, cols), (cols, 1), 0, row._owner)
+    got = smhip.chain(A2, (sma.OP_MUL, r2), (sma.OP_ADD, B2), (sma.OP_MUL, np.float32(0.5))).numpy()
+    t = smhip.binary(sma.OP_MUL, A2, r2)
+    t = smhip.binary(sma.OP_ADD, t, B2)
+    want = smhip.array_scalar(sma.OP_MUL, t, np.float32(0.5)).numpy()
+    util.assert_same_bits(got, want, "chain vs three launches")
+    hA = oracle.uniform_f32(rows * cols, 3, -1.0, 1.0).reshape(rows, cols)[1000:1016]
+    hB = oracle.uniform_f32(rows * cols, 9, -1.0, 1.0).reshape(rows, cols)[1000:1016]
+    hr = oracle.uniform_f32(cols, 4, -1.0, 1.0).reshape(1, cols)
+    util.assert_same_bits(got[1000:1016], _oracle_chain(oracle, hA, [(sma.OP_MUL, hr), (sma.OP_ADD, hB), (sma.OP_MUL, np.float32(0.5))]), "slice vs oracle")
+
+
+def test_chain_errors(smhip):
+    a = smhip.to_device(np.ones((4, 4), np.float32))
+    b = smhip.to_device(np.ones((3, 4), np.float32))
+    with pytest.raises(RuntimeError):
+        smhip.chain(a, (sma.OP_ADD, b))
+    with pytest.raises(sma.SmhipError):
+        smhip.chain(a, (sma.OP_POW, a))  # pow is not a chain stage

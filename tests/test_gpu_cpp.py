@@ -74,3 +74,12 @@ def test_dot_for_every_element_type_of_the_reference():
     r = subprocess.run([_exe("test_dot_types")], capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_operator_chains_fuse_through_the_cpp_surface():
+    """tests/cpp/test_chain_fusion.cpp: `(A * row + B) * s` written as one expression is ONE smhip_chain call, bit-identical to
+    the same expression with a named value per step; named values are computed at their `;`; host writes, assignment into
+    an operand, views of temporaries, exceptions and discarded expressions keep the eager meaning."""
+    r = subprocess.run([_exe("test_chain_fusion")], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
