@@ -623,6 +623,17 @@ public:
         return dx;
     }
 
+    // (a Op1 b) Op2 c (c == nullptr: Op2 scalar) as one recorded chain, evaluated before returning: what sm::fused is for
+    // operands that broadcast against each other.
+    template <typename Op1, typename Op2>
+    static SMArray chain_of(const SMArray &a, const SMArray &b, const SMArray *c, T scalar) {
+        detail::flush_pending();
+        SMArray t = deferred_arrays<Op1>(a, false, &b, false, T{});
+        SMArray r = deferred_arrays<Op2>(t, true, c, false, scalar);
+        detail::flush_pending();
+        return r;
+    }
+
     // A new dense array whose elements exist only in HBM so far.
     static SMArray device_empty(std::vector<std::size_t> &&shape) {
         SMArray a;
@@ -699,18 +710,21 @@ private:
     // + - * / on an element type with kernels.  See "deferred operator chains" at the top of this file.
     template <typename Op>
     static SMArray deferred(const SMArray &x, bool x_temporary, const detail::Operand<T> *rhs, T scalar) {
+        return deferred_arrays<Op>(x, x_temporary, rhs ? &rhs->array() : nullptr, rhs && rhs->temporary(), scalar);
+    }
+    template <typename Op>
+    static SMArray deferred_arrays(const SMArray &x, bool x_temporary, const SMArray *y, bool y_temporary, T scalar) {
         constexpr bool chainable = hip::on_device_v<T, Op> && hip::is_builtin_op<Op>::value && !std::is_same_v<Op, PowOp<T>>;
         if constexpr (!chainable) {
-            return rhs ? x.template apply<Op>(rhs->array()) : x.template apply_scalar<Op>(scalar);
+            return y ? x.template apply<Op>(*y) : x.template apply_scalar<Op>(scalar);
         } else {
-            const SMArray *y = rhs ? &rhs->array() : nullptr;
             std::vector<std::size_t> shape = (!y || x._shape == y->_shape) ? x._shape : sm::broadcast(x._shape, x._strides, y->_shape, y->_strides).resultShape;
             if (shape.size() > MAX_NDIM) throw std::runtime_error("rank exceeds MAX_NDIM");
             const std::size_t n = calculateTotalSize(shape);
             // nothing to gain from waiting: empty and 0-d results, and tiny host-built operands (they ride in the launch
             // packet of the plain operator, apply_into)
             detail::Chain<T> *cx = x_temporary ? x.continuable() : nullptr;
-            detail::Chain<T> *cy = (!cx && y && rhs->temporary()) ? y->continuable() : nullptr;
+            detail::Chain<T> *cy = (!cx && y && y_temporary) ? y->continuable() : nullptr;
             if (shape.empty() || n == 0 || (!cx && !cy && n <= SMHIP_INLINE_MAX_OUTPUTS && (x.host_only_small() || (y && y->host_only_small()))))
                 return y ? x.template apply<Op>(*y) : x.template apply_scalar<Op>(scalar);
             const int device = y ? common_device(x, *y) : x.device();

@@ -39,8 +39,10 @@ SMArray<T> pow(const SMArray<T> &arr, T val) {
 }
 
 // Fusion hook: (a Op1 b) Op2 c in ONE pass over HBM (the reference makes two passes and a
-// temporary).  Dense, equal-shaped operands take the fused kernel; anything else is evaluated
-// as the two operator calls it abbreviates -- same values either way.
+// temporary).  Dense, equal-shaped operands take the two-Op kernel; operands that broadcast against each other (a row, a
+// column, a scalar-like array, the reference tests' (1,224,1,3)) take the chain kernel (smhip_chain) -- what the operators
+// themselves do for `(a + b) * c` written as one expression; user-defined Ops and pow are evaluated as the two operator
+// calls.  Same values every way.
 //   auto r = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, c);   // (a + b) * c
 template <typename Op1, typename Op2, typename T>
 SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, const SMArray<T> &c) {
@@ -55,6 +57,7 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, const SMArray<T> &c) 
                                               nullptr, out.device_data_mut(), a.totalSize));
             return out;
         }
+        if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV) return SMArray<T>::template chain_of<Op1, Op2>(a, b, &c, T{});
     }
     return a.template apply<Op1>(b).template apply<Op2>(c);
 }
@@ -69,14 +72,17 @@ SMArray<T> fused(const SMArray<T> &a, const SMArray<T> &b, T c) {
                                               out.device_data_mut(), a.totalSize));
             return out;
         }
+        if (o1 <= SMHIP_OP_DIV && o2 <= SMHIP_OP_DIV) return SMArray<T>::template chain_of<Op1, Op2>(a, b, nullptr, c);
     }
     return a.template apply<Op1>(b).template apply_scalar<Op2>(c);
 }
 
 // A whole expression in ONE pass over HBM: sm::expr("(a0 + a1) * a2 - 3 * a3", a, b, c, d).  The operands appear as
-// a0 .. a7 in a HIP expression of the element type; all must have the same shape (views are made dense first).  Each
-// operation rounds as the separate operators do, so the values equal the operator chain's; the traffic is
-// (k + 1) * sizeof(T) bytes per element instead of 3 * sizeof(T) per operator.  Compiled by hipRTC on first use, cached.
+// a0 .. a7 in a HIP expression of the element type and broadcast against each other like the operators' (NumPy rule): a
+// row, a column, a per-channel value or a one-element array is read through the caches inside the pass, a transposed or
+// stepped view is copied dense first.  Each operation rounds as the separate operators do, so the values equal the operator
+// chain's; the traffic is (k + 1) * sizeof(T) bytes per element for k full-size operands instead of 3 * sizeof(T) per
+// operator.  Compiled by hipRTC on first use, cached.
 // Run-time scalars appear as s0 .. s3 and are passed at launch (changing them does not recompile):
 //     sm::expr("a0 * s0 + a1", {alpha}, x, y)        // axpy in one pass
 template <typename T, typename... Rest>
@@ -87,23 +93,37 @@ SMArray<T> expr(const char *expression, std::initializer_list<T> scalars, const 
     if (scalars.size() > 4) throw std::runtime_error("sm::expr: at most 4 scalars");
     const SMArray<T> *arrays[] = {&first, &rest...};
     constexpr int n = 1 + static_cast<int>(sizeof...(Rest));
-    std::vector<SMArray<T>> dense;  // dense copies of strided operands, kept alive until the launch is queued
-    dense.reserve(n);
     const void *ptrs[8] = {};
     for (int k = 1; k < n; ++k) SMArray<T>::common_device(first, *arrays[k]);  // all operands on one GPU, or it throws
     hip::DeviceGuard on(first.device());
-    for (int k = 0; k < n; ++k) {
-        if (arrays[k]->shape() != first.shape()) throw std::runtime_error("sm::expr: operands must have the same shape");
-        if (arrays[k]->is_dense()) {
-            ptrs[k] = arrays[k]->device_data();
-        } else {
-            dense.push_back(arrays[k]->contiguous());
-            ptrs[k] = dense.back().device_data();
-        }
+    bool flat = true;
+    for (int k = 0; k < n; ++k) flat = flat && arrays[k]->shape() == first.shape() && arrays[k]->is_dense();
+    if (flat) {
+        for (int k = 0; k < n; ++k) ptrs[k] = arrays[k]->device_data();
+        SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(first.shape()));
+        hip::check(smhip_fused_expr(expression, hip::dtype_of<T>::id, ptrs, n, scalars.size() ? scalars.begin() : nullptr,
+                                    static_cast<int>(scalars.size()), out.device_data_mut(), first.totalSize));
+        return out;
     }
-    SMArray<T> out = SMArray<T>::device_empty(std::vector<std::size_t>(first.shape()));
-    hip::check(smhip_fused_expr(expression, hip::dtype_of<T>::id, ptrs, n, scalars.size() ? scalars.begin() : nullptr,
-                                static_cast<int>(scalars.size()), out.device_data_mut(), first.totalSize));
+    // the common shape (sm::broadcast throws the reference's "Cannot broadcast shapes" on a mismatch), then every operand's
+    // strides against it
+    std::vector<std::size_t> shape = first.shape();
+    const std::vector<std::size_t> none;
+    for (int k = 1; k < n; ++k) shape = sm::broadcast(shape, std::vector<std::size_t>(shape.size(), 0), arrays[k]->shape(), arrays[k]->strides()).resultShape;
+    if (shape.size() > MAX_NDIM) throw std::runtime_error("rank exceeds MAX_NDIM");
+    if (shape.empty()) throw std::runtime_error("sm::expr: 0-d operands");
+    const std::size_t nd = shape.size();
+    std::vector<std::int64_t> strides(static_cast<std::size_t>(n) * nd, 0), sh(shape.begin(), shape.end());
+    for (int k = 0; k < n; ++k) {
+        const auto &ls = arrays[k]->shape();
+        const auto &lt = arrays[k]->strides();
+        const std::size_t shift = nd - ls.size();
+        for (std::size_t i = 0; i < ls.size(); ++i) strides[k * nd + shift + i] = (ls[i] == 1 && shape[shift + i] != 1) ? 0 : static_cast<std::int64_t>(lt[i]);
+        ptrs[k] = arrays[k]->device_data();
+    }
+    SMArray<T> out = SMArray<T>::device_empty(std::move(shape));
+    hip::check(smhip_fused_expr_bcast(expression, hip::dtype_of<T>::id, ptrs, strides.data(), n, scalars.size() ? scalars.begin() : nullptr,
+                                      static_cast<int>(scalars.size()), sh.data(), static_cast<int>(nd), out.device_data_mut()));
     return out;
 }
 template <typename T, typename... Rest>

@@ -145,6 +145,12 @@ int smhip_elementwise_inline(int op, int dtype, const void *a, size_t a_host_byt
  * smhip_register_op's kernels; each operation rounds as the separate operators do (no contraction). */
 int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *operands, int n_operands, const void *scalars_host,
                      int n_scalars, void *out, size_t n);
+/* smhip_fused_expr over operands that BROADCAST against the result: operands[k] is operand k's first element and
+ * strides[k * ndim .. ) its strides against `shape` (0 where it broadcasts, as smhip_broadcast returns them); `out` is dense
+ * row-major over `shape`.  A row, a column / per-row value, a per-channel value or any operand periodic in the output is
+ * read through the caches inside the one pass; a transposed or stepped view is copied dense first. */
+int smhip_fused_expr_bcast(const char *hip_expression, int dtype, const void *const *operands, const int64_t *strides, int n_operands,
+                           const void *scalars_host, int n_scalars, const int64_t *shape, int ndim, void *out);
 /* The same expression with the sum of its results, in the same single pass: *sum_dev (device memory, fp64; integer types:
  * the exact 64-bit total as a double, like smhip_sum) = sum_i EXPR(...).  out_or_null: also store the elementwise result, or
  * reduce only -- e.g. "(a0 - a1) * (a0 - a1)" with out_or_null = NULL is a squared distance at 8 bytes per element and no

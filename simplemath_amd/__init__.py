@@ -361,6 +361,29 @@ class Smhip:
                                          C.c_size_t(a0.size)))
         return out
 
+    def fused_expr_bcast(self, expression: str, *arrays: DeviceArray, scalars=(), out: DeviceArray | None = None):
+        """out = EXPR(a0, a1, ..., s0, ...) in one pass over operands that broadcast against each other (smhip_fused_expr_bcast)."""
+        a0 = arrays[0]
+        shape = list(a0.shape)
+        for a in arrays[1:]:
+            assert a.dtype == a0.dtype
+            res = self.broadcast(shape, [0] * len(shape), a.shape, a.strides)
+            if res is None:
+                raise RuntimeError("Cannot broadcast shapes: incompatible dimensions")
+            shape = res[0]
+        nd = len(shape)
+        strides = []
+        for a in arrays:
+            strides += list(self.broadcast(shape, [0] * nd, a.shape, a.strides)[2])
+        if out is None:
+            out = self.empty(shape, a0.dtype)
+        ptrs = (C.c_void_p * len(arrays))(*[a.ptr for a in arrays])
+        sc = np.array(list(scalars), dtype=a0.dtype)
+        self._ck(self.c.smhip_fused_expr_bcast(expression.encode(), C.c_int(DTYPES[a0.dtype]), ptrs, _i64(strides), C.c_int(len(arrays)),
+                                               sc.ctypes.data_as(C.c_void_p) if len(sc) else None, C.c_int(len(sc)), _i64(shape), C.c_int(nd),
+                                               C.c_void_p(out.ptr)))
+        return out
+
     def fused_expr_sum(self, expression: str, *arrays: DeviceArray, scalars=(), store=False):
         """sum_i EXPR(a0[i], ...) in one pass; store=True also returns the elementwise result.  Blocks for the value."""
         a0 = arrays[0]

@@ -413,11 +413,9 @@ struct Temps {
     }
 };
 
-}  // namespace
-
-int launch_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
-                 const int *ops, const int *swapped, const int64_t *shape, int ndim, void *out, hipStream_t s) {
-    Problem pb{};
+void make_problem(int dtype, const int64_t *shape, int ndim, Problem *out) {
+    Problem &pb = *out;
+    pb = Problem{};
     pb.dtype = dtype;
     pb.esz = (int)dtype_size(dtype);
     pb.W = 16 / pb.esz;
@@ -431,13 +429,79 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
             pb.axis[pb.ndim++] = i;
         }
     }
-    if (pb.n == 0) return SMHIP_OK;
-    {
-        int64_t acc = 1;
-        for (int j = pb.ndim; j-- > 0;) { pb.dense_strides[j] = acc; acc *= pb.shape[j]; }
-        acc = 1;
-        for (int i = ndim; i-- > 0;) { pb.full_dense[i] = acc; acc *= shape[i]; }
+    int64_t acc = 1;
+    for (int j = pb.ndim; j-- > 0;) { pb.dense_strides[j] = acc; acc *= pb.shape[j]; }
+    acc = 1;
+    for (int i = ndim; i-- > 0;) { pb.full_dense[i] = acc; acc *= shape[i]; }
+}
+
+// Classifies one array operand (lf.ptr / lf.strides set) and, for a row whose period needs it, writes the period out.
+int prepare_leaf(const Problem &pb, Leaf &lf, Temps &temps, hipStream_t s) {
+    bool writeout = false;
+    lf.kind = classify(pb, lf.strides, &lf.P, &lf.R, &lf.C, &writeout);
+    if (lf.kind == kRow && writeout) {
+        // the period, repeated to a whole number of vectors: (rep, axes from the first one the operand moves along)
+        // gathered through SMHIP_OP_LEFT
+        const uint64_t rep = pb.W / std::gcd<uint64_t, uint64_t>(lf.P, (uint64_t)pb.W);
+        int64_t sh[SMHIP_MAX_NDIM + 1], st[SMHIP_MAX_NDIM + 1], zero[SMHIP_MAX_NDIM + 1] = {};
+        int nd = 0;
+        uint64_t cover = 1;
+        int first = pb.ndim;
+        for (int j = pb.ndim; j-- > 0;) {
+            if (cover == lf.P) break;
+            cover *= (uint64_t)pb.shape[j];
+            first = j;
+        }
+        if (rep > 1) { sh[nd] = (int64_t)rep; st[nd++] = 0; }
+        for (int j = first; j < pb.ndim; ++j) { sh[nd] = pb.shape[j]; st[nd++] = lf.strides[pb.axis[j]]; }
+        if (nd > SMHIP_MAX_NDIM) { lf.kind = kComplex; return SMHIP_OK; }
+        void *buf;
+        if (int rc = temps.take(lf.P * rep * pb.esz, &buf)) return rc;
+        if (int rc = launch_broadcast(SMHIP_OP_LEFT, pb.dtype, lf.ptr, st, lf.ptr, zero, sh, nd, buf, s)) return rc;
+        lf.ptr = buf;
+        lf.P *= rep;
     }
+    return SMHIP_OK;
+}
+
+}  // namespace
+
+// smhip_fused_expr_bcast: the operands of a run-time compiled expression in the index forms above; an operand that has
+// none (a transposed or stepped view) is copied dense first (SMHIP_OP_LEFT through the broadcast kernels).
+int launch_expr_bcast(const char *expr, int dtype, const void *const *operands, const int64_t *strides, int n_operands,
+                      const void *scalars_host, int n_scalars, const int64_t *shape, int ndim, void *out, hipStream_t s) {
+    Problem pb;
+    make_problem(dtype, shape, ndim, &pb);
+    if (pb.n == 0) return SMHIP_OK;
+    Temps temps;
+    ExprLeaf forms[8];
+    for (int k = 0; k < n_operands; ++k) {
+        Leaf lf;
+        lf.ptr = operands[k];
+        lf.strides = strides + (size_t)k * ndim;
+        if (int rc = prepare_leaf(pb, lf, temps, s)) return rc;
+        if (lf.kind == kComplex) {
+            void *buf;
+            if (int rc = temps.take(pb.n * pb.esz, &buf)) return rc;
+            const int64_t zero[SMHIP_MAX_NDIM] = {};
+            if (int rc = launch_broadcast(SMHIP_OP_LEFT, dtype, lf.ptr, lf.strides, lf.ptr, zero, pb.full_shape, pb.full_ndim, buf, s)) return rc;
+            lf.ptr = buf;
+            lf.kind = kDense;
+        }
+        forms[k] = ExprLeaf{lf.kind == kDense ? 0 : lf.kind == kRow ? 1 : 2, lf.ptr, lf.P, lf.R, lf.C};
+    }
+    bool all_dense = true;
+    const void *dense[8] = {};
+    for (int k = 0; k < n_operands; ++k) { all_dense = all_dense && forms[k].kind == 0; dense[k] = forms[k].ptr; }
+    if (all_dense) return jit_fused_expr(expr, dtype, dense, n_operands, scalars_host, n_scalars, out, pb.n, nullptr, s);  // the flat kernel
+    return jit_fused_expr_bcast(expr, dtype, forms, n_operands, scalars_host, n_scalars, out, pb.n, s);
+}
+
+int launch_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
+                 const int *ops, const int *swapped, const int64_t *shape, int ndim, void *out, hipStream_t s) {
+    Problem pb;
+    make_problem(dtype, shape, ndim, &pb);
+    if (pb.n == 0) return SMHIP_OK;
     Temps temps;
     std::vector<Leaf> leaves((size_t)n_operands);
     for (int k = 0; k < n_operands; ++k) {
@@ -449,30 +513,7 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
         }
         lf.ptr = operands[k];
         lf.strides = strides + (size_t)k * ndim;
-        bool writeout = false;
-        lf.kind = classify(pb, lf.strides, &lf.P, &lf.R, &lf.C, &writeout);
-        if (lf.kind == kRow && writeout) {
-            // write the period out, repeated to a whole number of vectors: (rep, axes from the first one the operand moves
-            // along) gathered through SMHIP_OP_LEFT
-            const uint64_t rep = pb.W / std::gcd<uint64_t, uint64_t>(lf.P, (uint64_t)pb.W);
-            int64_t sh[SMHIP_MAX_NDIM + 1], st[SMHIP_MAX_NDIM + 1], zero[SMHIP_MAX_NDIM + 1] = {};
-            int nd = 0;
-            uint64_t cover = 1;
-            int first = pb.ndim;
-            for (int j = pb.ndim; j-- > 0;) {
-                if (cover == lf.P) break;
-                cover *= (uint64_t)pb.shape[j];
-                first = j;
-            }
-            if (rep > 1) { sh[nd] = (int64_t)rep; st[nd++] = 0; }
-            for (int j = first; j < pb.ndim; ++j) { sh[nd] = pb.shape[j]; st[nd++] = lf.strides[pb.axis[j]]; }
-            if (nd > SMHIP_MAX_NDIM) { lf.kind = kComplex; continue; }
-            void *buf;
-            if (int rc = temps.take(lf.P * rep * pb.esz, &buf)) return rc;
-            if (int rc = launch_broadcast(SMHIP_OP_LEFT, dtype, lf.ptr, st, lf.ptr, zero, sh, nd, buf, s)) return rc;
-            lf.ptr = buf;
-            lf.P *= rep;
-        }
+        if (int rc = prepare_leaf(pb, lf, temps, s)) return rc;
     }
     // Walk the stages, cutting the chain where a leaf is not fusable or a kernel variant's operand counts run out.
     const Leaf *head = &leaves[0];

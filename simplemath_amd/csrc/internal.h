@@ -158,6 +158,13 @@ int launch_fused(int op1, int op2, int dtype, const void *a, const void *b, cons
 // chain.hip: r = x0; r = r op[k] x[k+1] (swapped[k]: x[k+1] op[k] r) over broadcast operands, as few passes as possible
 int launch_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
                  const int *swapped, const int64_t *shape, int ndim, void *out, hipStream_t s);
+// An operand of smhip_fused_expr_bcast in the index form chain.hip found for it: kind 0 dense a[i], 1 row a[i mod P] (P a
+// whole number of vectors), 2 splat a[(i / R) mod C]
+struct ExprLeaf { int kind; const void *ptr; uint64_t P, R, C; };
+int launch_expr_bcast(const char *expr, int dtype, const void *const *operands, const int64_t *strides, int n_operands,
+                      const void *scalars_host, int n_scalars, const int64_t *shape, int ndim, void *out, hipStream_t s);
+int jit_fused_expr_bcast(const char *expr, int dtype, const ExprLeaf *leaves, int n_operands, const void *scalars_host, int n_scalars,
+                         void *out, size_t n, hipStream_t s);
 int launch_fill(int dtype, void *dst, const void *value_host, size_t n, hipStream_t s);
 int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi, hipStream_t s);
 int launch_sum(int dtype, const void *a, size_t n, double *out_dev, hipStream_t s);

@@ -622,4 +622,152 @@ int jit_fused_expr(const char *expr, int dtype, const void *const *operands, int
     return reduce_finish(dtype, scratch, grid, sum_dev, s);
 }
 
+// smhip_fused_expr_bcast: the n-ary expression kernel over operands that BROADCAST against the result -- each operand in
+// the index form chain.hip classified it into (dense / row / splat; internal.h: ExprLeaf).  The kernel text is generated
+// per combination of forms: dense operands load inside the read-policy branch (one block of loads), the small ones through
+// the caches behind it.  Same arithmetic as smhip_user_expr: each operation rounds as the separate operators do.
+namespace {
+const char *kExprBcastHead = R"SRC(
+typedef TYPE T;
+typedef T V0 __attribute__((ext_vector_type(WIDTH)));
+typedef V0 V __attribute__((aligned(sizeof(T))));
+typedef T H0 __attribute__((ext_vector_type(WIDTH / 2)));
+typedef H0 H __attribute__((aligned(sizeof(T))));
+#if WIDTH == 4
+#define SMHIP_JOIN(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3)
+#else
+#define SMHIP_JOIN(lo, hi) __builtin_shufflevector(lo, hi, 0, 1)
+#endif
+__device__ __forceinline__ V0 smhip_ld(const V* p, int nt) {
+    if (nt) return __builtin_nontemporal_load(p);
+    const H* h = (const H*)p;
+    const H0 lo = h[0], hi = h[1];
+    return SMHIP_JOIN(lo, hi);
+}
+__device__ __forceinline__ void smhip_st(V* p, V0 r, int pol) {
+    if (pol & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r));
+    else __builtin_nontemporal_store(r, p);
+}
+struct FastDiv {
+    unsigned d, mul, shr;
+    __device__ __forceinline__ unsigned div(unsigned n) const { return d == 1 ? n : (__umulhi(n, mul) >> shr); }
+    __device__ __forceinline__ unsigned mod(unsigned n) const { return n - div(n) * d; }
+};
+// row: a = the period in vectors, off = this launch's first vector within it.  splat: a = elements (vectors, when whole)
+// per value, b = values before the operand repeats, off / q0 = where this launch starts, elem = 1: one index per element.
+struct BOperand { const T* p; FastDiv a, b; unsigned off, q0, elem, pad; };
+struct Operands { BOperand o[8]; };
+struct Scalars { T v[4]; };
+__device__ __forceinline__ T smhip_eval(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7, T s0, T s1, T s2, T s3) { return (T)(EXPR); }
+__device__ __forceinline__ V0 smhip_row(const BOperand& o, unsigned v) { return ((const V*)o.p)[o.a.mod(o.off + v)]; }
+__device__ __forceinline__ V0 smhip_splat(const BOperand& o, unsigned v) {
+    V0 r;
+    if (o.elem) {
+        for (int e = 0; e < WIDTH; ++e) r[e] = o.p[o.b.mod(o.q0 + o.a.div(o.off + v * WIDTH + e))];
+    } else {
+        const T y = o.p[o.b.mod(o.q0 + o.a.div(o.off + v))];
+        for (int e = 0; e < WIDTH; ++e) r[e] = y;
+    }
+    return r;
+}
+)SRC";
+}  // namespace
+
+int jit_fused_expr_bcast(const char *expr, int dtype, const ExprLeaf *leaves, int n_operands, const void *scalars_host, int n_scalars,
+                         void *out, size_t n, hipStream_t s) {
+    const unsigned long long w = (dtype == SMHIP_F64 || dtype == SMHIP_I64) ? 2 : 4;
+    std::string kinds;
+    int n_dense = 0;
+    for (int k = 0; k < n_operands; ++k) { kinds += (char)('0' + leaves[k].kind); n_dense += leaves[k].kind == 0; }
+    hipFunction_t fn = nullptr;
+    if (int rc = get_function(std::string("exprb|") + kTypeName[dtype] + "|" + kinds + "|" + expr,
+                              [&](std::vector<char> *code) {
+                                  std::string dense_nt, dense_pl, small, tail;
+                                  for (int k = 0; k < n_operands; ++k) {
+                                      const std::string K = std::to_string(k);
+                                      if (leaves[k].kind == 0) {
+                                          dense_nt += "            v[" + K + "] = smhip_ld((const V*)in.o[" + K + "].p + i, 1);\n";
+                                          dense_pl += "            v[" + K + "] = smhip_ld((const V*)in.o[" + K + "].p + i, 0);\n";
+                                          tail += "            x[" + K + "] = in.o[" + K + "].p[j];\n";
+                                      } else {
+                                          const char *f = leaves[k].kind == 1 ? "smhip_row" : "smhip_splat";
+                                          small += std::string("        v[") + K + "] = " + f + "(in.o[" + K + "], (unsigned)i);\n";
+                                          if (leaves[k].kind == 1) tail += "            x[" + K + "] = in.o[" + K + "].p[(unsigned long long)in.o[" + K + "].a.mod(in.o[" + K + "].off + (unsigned)n_vec) * WIDTH + (j - n_vec * WIDTH)];\n";
+                                          else tail += "            x[" + K + "] = smhip_splat(in.o[" + K + "], (unsigned)n_vec)[j - n_vec * WIDTH];\n";
+                                      }
+                                  }
+                                  for (int k = n_operands; k < 8; ++k) {
+                                      small += "        v[" + std::to_string(k) + "] = v[0];\n";
+                                      tail += "            x[" + std::to_string(k) + "] = x[0];\n";
+                                  }
+                                  std::string source = kExprBcastHead;
+                                  source += "extern \"C\" __global__ __launch_bounds__(256) void smhip_user_expr_b(Operands in, Scalars sc, T* __restrict__ out,\n"
+                                            "        unsigned long long n_vec, unsigned long long n, int pol) {\n"
+                                            "    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;\n"
+                                            "    if (i < n_vec) {\n        V0 v[8];\n        if (pol & 1) {\n" + dense_nt + "        } else {\n" + dense_pl + "        }\n" + small +
+                                            "        V0 r;\n        for (int e = 0; e < WIDTH; ++e) r[e] = smhip_eval(v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);\n"
+                                            "        smhip_st((V*)out + i, r, pol);\n    } else if (i == n_vec) {\n        for (unsigned long long j = n_vec * WIDTH; j < n; ++j) {\n            T x[8];\n" + tail +
+                                            "            out[j] = smhip_eval(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], sc.v[0], sc.v[1], sc.v[2], sc.v[3]);\n        }\n    }\n}\n";
+                                  return hiprtc_build(source, {std::string("-DTYPE=") + kTypeName[dtype], std::string("-DWIDTH=") + (w == 2 ? "2" : "4"), std::string("-DEXPR=") + expr},
+                                                      kTypeName[dtype], expr, code);
+                              },
+                              "smhip_user_expr_b", &fn))
+        return rc;
+    struct FD { unsigned d, mul, shr; };
+    auto fastdiv = [](uint64_t div) {
+        const dev::FastDiv f((uint32_t)div);
+        return FD{f.d, f.mul, f.shr};
+    };
+    struct BOperand { const void *p; FD a, b; unsigned off, q0, elem, pad; };
+    struct { BOperand o[8]; } in;
+    memset(&in, 0, sizeof in);
+    const size_t esz = dtype_size(dtype);
+    unsigned char sc[32] = {};
+    if (n_scalars > 0) memcpy(sc, scalars_host, (size_t)n_scalars * esz);
+    const size_t n_vec = n / w;
+    int pol = stream_policy((size_t)n_dense * n * esz, n * esz);
+    for (int k = 0; k < n_operands; ++k)
+        if (leaves[k].kind == 0) pol |= refine_policy(pol, {{leaves[k].ptr, n * esz}}, {nullptr, 0});
+    // pieces: the large-array rule of the streaming kernels; with row / splat operands a launch also stays within the
+    // 32-bit index arithmetic's reach
+    size_t piece = piece_for(n_vec, n_dense + 1 < 3 ? n_dense + 1 : 3);
+    const size_t reach = ((size_t)1 << 31) / w / 2;
+    if (n_dense < n_operands && (piece == 0 || piece > reach) && n_vec > reach) piece = reach;
+    if (piece == 0 || piece >= n_vec) piece = n_vec ? n_vec : 1;
+    for (size_t v0 = 0;; v0 += piece) {
+        const bool last = v0 + piece >= n_vec;
+        unsigned long long nv = last ? n_vec - v0 : piece, ne = last ? n - v0 * w : piece * w;
+        for (int k = 0; k < 8; ++k) {
+            const ExprLeaf &lf = leaves[k < n_operands ? k : 0];
+            BOperand &o = in.o[k];
+            o = BOperand{};
+            o.a = o.b = FD{1, 0, 0};
+            if (lf.kind == 0) {
+                o.p = static_cast<const char *>(lf.ptr) + v0 * 16;
+            } else if (lf.kind == 1) {
+                const uint64_t pv = lf.P / w;
+                o.p = lf.ptr;
+                o.a = fastdiv(pv);
+                o.off = (unsigned)(v0 % pv);
+            } else {
+                const bool elem = lf.R % w != 0;
+                const uint64_t r = elem ? lf.R : lf.R / w, at = elem ? (uint64_t)v0 * w : (uint64_t)v0;
+                o.p = lf.ptr;
+                o.a = fastdiv(r);
+                o.b = fastdiv(lf.C);
+                o.off = (unsigned)(at % r);
+                o.q0 = (unsigned)((at / r) % lf.C);
+                o.elem = elem;
+            }
+        }
+        void *po = static_cast<char *>(out) + v0 * 16;
+        const size_t grid = (nv + 1 + 255) / 256;
+        if (grid > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "fused expression: array too large for one launch");
+        void *args[] = {&in, sc, &po, &nv, &ne, &pol};
+        SMHIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        if (last) break;
+    }
+    return SMHIP_OK;
+}
+
 }  // namespace smhip

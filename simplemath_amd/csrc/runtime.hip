@@ -895,6 +895,30 @@ int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const voi
     return launch_fused(op1, op2, dtype, a, b, c, c_scalar_host, out, n, s);
 }
 
+int smhip_fused_expr_bcast(const char *hip_expression, int dtype, const void *const *operands, const int64_t *strides, int n_operands,
+                           const void *scalars_host, int n_scalars, const int64_t *shape, int ndim, void *out) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: bad dtype %d", dtype);
+    if (!hip_expression || !*hip_expression) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: empty expression");
+    if (n_operands < 1 || n_operands > 8) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: %d operands outside 1..8", n_operands);
+    if (n_scalars < 0 || n_scalars > 4 || (n_scalars && !scalars_host)) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: %d scalars outside 0..4 (or none given)", n_scalars);
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: ndim %d outside 1..%d", ndim, SMHIP_MAX_NDIM);
+    if (!operands || !strides || !shape) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: null argument");
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: negative extent at dim %d", i);
+        n *= shape[i];
+    }
+    for (int k = 0; k < n_operands; ++k) {
+        if (!operands[k]) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: operand %d is NULL", k);
+        for (int i = 0; i < ndim; ++i)
+            if (strides[(size_t)k * ndim + i] < 0) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: negative stride (operand %d, dim %d)", k, i);
+    }
+    if (n == 0) return SMHIP_OK;
+    if (!out) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: null output");
+    SMHIP_ACQUIRE(s);
+    return launch_expr_bcast(hip_expression, dtype, operands, strides, n_operands, scalars_host, n_scalars, shape, ndim, out, s);
+}
+
 int smhip_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
                 const int *swapped, const int64_t *shape, int ndim, void *out) {
     if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "chain: bad dtype %d", dtype);

@@ -230,6 +230,50 @@ static void ordering() {
     CHECK(m2(1, 1) == 5.0f);
 }
 
+template <typename T>
+static void hooks() {
+    // sm::fused and sm::expr take operands that broadcast against each other (smhip_chain / smhip_fused_expr_bcast)
+    const std::size_t rows = 70, cols = 96;
+    const auto A = random_array<T>(rows, cols), B = random_array<T>(rows, cols);
+    const auto row = random_array<T>(1, cols), col = random_array<T>(rows, 1);
+    const T s = T(3);
+    {
+        Delta d;
+        auto f = sm::fused<MultiplyOp<T>, AddOp<T>>(A, row, B);
+        CHECK(d.chains() == 1 && d.stages() == 2);
+        auto t1 = A * row;
+        auto t2 = t1 + B;
+        CHECK(same_bits(f, t2));
+        auto g = sm::fused<SubtractOp<T>, DivideOp<T>>(A, col, s);
+        auto u1 = A - col;
+        auto u2 = u1 / s;
+        CHECK(same_bits(g, u2));
+        auto h = sm::fused<AddOp<T>, MultiplyOp<T>>(A, B, A);  // equal dense shapes: the two-Op kernel
+        auto v1 = A + B;
+        auto v2 = v1 * A;
+        CHECK(same_bits(h, v2));
+    }
+    {
+        auto e = sm::expr("(a0 * a1 + a2) * s0 - a3", {s}, A, row, B, col);
+        auto t1 = A * row;
+        auto t2 = t1 + B;
+        auto t3 = t2 * s;
+        auto t4 = t3 - col;
+        CHECK(same_bits(e, t4));
+        auto e2 = sm::expr("a0 + a1", row, col);  // (1, cols) and (rows, 1): the result is (rows, cols)
+        auto w = row + col;
+        CHECK(e2.shape() == std::vector<std::size_t>({rows, cols}) && same_bits(e2, w));
+        const auto Sq = random_array<T>(cols, cols);
+        auto e3 = sm::expr("a0 - a1 * a2", Sq, Sq.transpose(), row);
+        auto x1 = Sq.transpose() * row;
+        auto x2 = Sq - x1;
+        CHECK(same_bits(e3, x2));
+        bool threw = false;
+        try { auto bad = sm::expr("a0 + a1", A, random_array<T>(rows + 1, cols)); (void)bad; } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+    }
+}
+
 static void sizes() {
     // around the vector / workgroup boundaries, 1-D (the tail lane) and element types
     for (std::size_t n : {std::size_t(1), std::size_t(3), std::size_t(5), std::size_t(257), std::size_t(4099), std::size_t(100003), std::size_t(1) << 20}) {
@@ -254,6 +298,10 @@ int main() {
     STEP(periodic_4d<double>());
     STEP(periodic_4d<std::int32_t>());
     STEP(periodic_4d<std::int64_t>());
+    STEP(hooks<float>());
+    STEP(hooks<double>());
+    STEP(hooks<std::int32_t>());
+    STEP(hooks<std::int64_t>());
     STEP(host_values());
     STEP(ordering());
     STEP(sizes());

@@ -196,3 +196,37 @@ def test_chain_errors(smhip):
         smhip.chain(a, (sma.OP_ADD, b))
     with pytest.raises(sma.SmhipError):
         smhip.chain(a, (sma.OP_POW, a))  # pow is not a chain stage
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_fused_expr_with_broadcast_operands(smhip, oracle, dt):
+    """smhip_fused_expr_bcast: the run-time compiled n-ary expression over operands that broadcast against each other --
+    a row, a column, the reference tests' periodic (1,H,1,C), a one-element array, a transposed view (copied dense first) --
+    bit-identical to the oracle's operator-by-operator evaluation (no contraction: each operation rounds alone)."""
+    rng = np.random.default_rng(21)
+    rows, cols = 45, 72
+    A, B = _rand(rng, (rows, cols), dt), _rand(rng, (rows, cols), dt)
+    row, col, one = _rand(rng, (1, cols), dt), _rand(rng, (rows, 1), dt), _rand(rng, (1, 1), dt)
+    s = dt(3)
+    dA, dB, drow, dcol, done = (smhip.to_device(x) for x in (A, B, row, col, one))
+    got = smhip.fused_expr_bcast("(a0 * a1 + a2) * s0", dA, drow, dB, scalars=[s]).numpy()
+    util.assert_same_bits(got, _oracle_chain(oracle, A, [(sma.OP_MUL, row), (sma.OP_ADD, B), (sma.OP_MUL, s)]), "(A*row+B)*s")
+    got = smhip.fused_expr_bcast("(a0 + a1) * (a2 - a3) / a4", dA, dcol, dB, drow, done).numpy()
+    want = oracle.binary(orc.DIV, oracle.binary(orc.MUL, oracle.binary(orc.ADD, A, col), oracle.binary(orc.SUB, B, row)), one)
+    util.assert_same_bits(got, want, "tree expression")
+    # no full-size operand at all: (row, col) -> (rows, cols)
+    got = smhip.fused_expr_bcast("a0 - a1 * a2", drow, dcol, done).numpy()
+    util.assert_same_bits(got, oracle.binary(orc.SUB, row, oracle.binary(orc.MUL, col, one)), "row - col*one")
+    # a transposed view among the operands
+    S = _rand(rng, (cols, cols), dt)
+    dS = smhip.to_device(S)
+    got = smhip.fused_expr_bcast("a0 + a1 * a2", dS, dS.view_like(S.T, S), drow).numpy()
+    util.assert_same_bits(got, oracle.binary(orc.ADD, S, oracle.binary(orc.MUL, S.T, row)), "S + S.T*row")
+    # 4-D: the reference tests' pattern and a 3-element period, ragged total (n % W != 0 for f32)
+    big, small, rgb = _rand(rng, (3, 7, 5, 3), dt), _rand(rng, (1, 7, 1, 3), dt), _rand(rng, (1, 1, 1, 3), dt)
+    dbig, dsmall, drgb = smhip.to_device(big), smhip.to_device(small), smhip.to_device(rgb)
+    got = smhip.fused_expr_bcast("(a0 + a1) * a2", dbig, dsmall, drgb).numpy()
+    util.assert_same_bits(got, oracle.binary(orc.MUL, oracle.binary(orc.ADD, big, small), rgb), "4-D periodic")
+    # equal dense shapes fall through to the flat kernel
+    got = smhip.fused_expr_bcast("a0 * a1 - a0", dA, dB).numpy()
+    util.assert_same_bits(got, oracle.binary(orc.SUB, oracle.binary(orc.MUL, A, B), A), "dense")
