@@ -33,6 +33,8 @@ configs  the N = 1 line also carries BASELINE configs 3, 4 and 5's per-GPU step 
                    256 MiB Infinity Cache, so `bound` reads "hbm+infinity_cache": the rate is cache-fed.
            cold    launches rotate through K disjoint operand sets, K x footprint >= 2.5 GiB: nothing a launch reads or writes
                    was touched recently -- an operator's realistic first call.  `bound` "hbm".
+         "chain" is the harness's operator chain (A * row + B) * 0.5f on 4096 x 4096 as ONE smhip_chain call -- what
+         SMArray's operators queue for that expression (12 B/elem; the reference's three operator calls move 28).
          plus that config's cpu_baseline, and -- c5_shard -- the one-rank run of config 5's exchange step through libsmhip's
          own device group (smhip_set_devices(1) + smhip_sharded_contiguous_sum: the ncclAllReduce is issued for real, with
          one rank; no torch).  "rccl" says what RCCL itself reports: its version and the ranks the communicator counts
@@ -67,6 +69,7 @@ WORKLOADS = {
     "pow": (8, "1D float32 pow(a, 2.5), N=2^26 (BASELINE config 4)"),
     "add_sum": (12, "1D float32 fused add + sum, 2^28 per GPU (BASELINE config 5 shard)"),
     "transpose_add": (12, "2D float32 (8192x8192).T + (8192x8192): a transpose() view operand (SURVEY 8f rank 1)"),
+    "chain": (12, "2D float32 (A * row + B) * 0.5 on 4096x4096, ONE smhip_chain call: the harness's chain_check (SURVEY 8f rank 4)"),
 }
 
 
@@ -253,6 +256,22 @@ def cpu_baseline(wl, log2n):
         res.update(kind="port", value=r["best"], cores=cores, one_core=r["shipped"],
                    note="the reference's float pow has no array body that links (pow.h:12-13); its arithmetic is PowOp<float>::apply = "
                         "std::pow per element (pow.h:8-10), run here as array_scalar_op's OpenMP loop would (calculate.h:152) on all usable cores")
+    elif wl == "chain":
+        rows, cols = 1024, 4096  # a quarter of the 4096 x 4096 workload: the reference's general loop takes ~0.25 s per call at full size
+        o.set_threads(cores)
+        A, B = o.uniform_f32(rows * cols, 3, -1.0, 1.0), o.uniform_f32(rows * cols, 9, -1.0, 1.0)
+        row = o.uniform_f32(cols, 4, -1.0, 1.0)
+        res["sample"] = "(A * row + B) * 0.5f on 1024 x 4096 float32 (1/4 of the 4096 x 4096 workload), seeds 3/9/4"
+        eng = ref if ref is not None else o
+        def fn():
+            t1 = eng.elementwise(orc.MUL, A, [cols, 1], row, [0, 1], [rows, cols])
+            t2 = eng.elementwise(orc.ADD, t1, [cols, 1], B, [cols, 1], [rows, cols])
+            return eng.array_scalar(orc.MUL, t2, np.float32(0.5))
+        r = both(fn, cores, fn, rows * cols, reps=3)
+        res.update(kind="reference" if ref is not None else "port", value=r["best"], cores=cores,
+                   note="the three operator calls the reference makes for this expression (SMArray.h:217-305): element_wise_op's general loop "
+                        "for A * row (OpenMP), its contiguous fast path for + B (one thread, calculate.h:101-134), array_scalar_op for * 0.5f "
+                        "(OpenMP), a fresh result per operator")
     elif wl == "transpose_add":
         rows = cols = 2048  # a 2048 x 2048 sample of the 8192 x 8192 workload: the reference's loop takes ~1 s per call at full size
         o.set_threads(cores)
@@ -459,6 +478,27 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound, setting="replay", log
                                C.c_void_p(r.ptr), i64([0, 1]), i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr)))
         return (steps, rows * cols, 4 * (2 * rows * cols + cols), "flat_tile_kernel<float, MultiplyOp<float>, 3, 2, *>",
                 "2D float32 (4096x4096) * (1x4096) broadcast multiply, HBM-resident", keep, {})
+    if wl == "chain":
+        # (A * row + B) * 0.5f -- what SMArray's operators queue for that expression: ONE kernel, A and B streamed, the row
+        # from the caches, the two temporaries of the reference's three operator calls (SMArray.h:217-305) never written
+        rows = cols = 4096
+        r = lib.uniform_f32(cols, 4, -1.0, 1.0)
+        half = np.zeros(4, dtype=F32)
+        half[3] = 0.5
+        ops, swp = (C.c_int * 3)(sma.OP_MUL, sma.OP_ADD, sma.OP_MUL), (C.c_int * 3)(0, 0, 0)
+        keep += [r, half, ops, swp]
+        for k in range(sets_for(12 * rows * cols)):
+            A = lib.uniform_f32(rows * cols, 3 + 100 * k, -1.0, 1.0)
+            B = lib.uniform_f32(rows * cols, 9 + 100 * k, -1.0, 1.0)
+            out = lib.empty((rows, cols), F32)
+            ptrs = (C.c_void_p * 4)(A.ptr, r.ptr, B.ptr, None)
+            strides = i64([cols, 1, 0, 1, cols, 1, 0, 0])
+            keep.append((A, B, out, ptrs, strides))
+            steps.append(bound(lib.c.smhip_chain, C.c_int(sma.F32), C.c_int(4), ptrs, strides, half.ctypes.data_as(C.c_void_p), ops, swp,
+                               i64([rows, cols]), C.c_int(2), C.c_void_p(out.ptr)))
+        return (steps, rows * cols, 4 * (3 * rows * cols + cols), "chain_kernel<float, 2, 1, 0, 1>",
+                "2D float32 (A * row + B) * 0.5 on 4096x4096 as one smhip_chain call (3 operators, 1 launch), HBM-resident", keep,
+                {"operators": 3, "eager_bytes_per_element": 28})
     if wl == "transpose_add":
         rows = cols = 8192
         for k in range(sets_for(12 * rows * cols)):
@@ -486,7 +526,7 @@ def build_workload(lib, sma, np, C, wl, args, rank, bound, setting="replay", log
 
 def bound_reads(wl, setting, alg_bytes):
     """`roofline.bound`: what feeds the kernel.  A replayed workload whose reads fit the 256 MiB Infinity Cache is cache-fed."""
-    read_bytes = {"add": alg_bytes * 2 // 3, "add_sum": alg_bytes * 2 // 3, "transpose_add": alg_bytes * 2 // 3,
+    read_bytes = {"add": alg_bytes * 2 // 3, "add_sum": alg_bytes * 2 // 3, "transpose_add": alg_bytes * 2 // 3, "chain": alg_bytes * 2 // 3,
                   "bcast_mul": alg_bytes // 2, "pow": alg_bytes // 2}[wl]
     return "hbm+infinity_cache" if setting == "replay" and read_bytes <= (256 << 20) else "hbm"
 
@@ -514,7 +554,7 @@ def time_steps(lib, steps, n_steps, warmup, barrier=None):
 def config_legs(lib, sma, np, C, args, bound):
     """BASELINE configs 3, 4 and 5's per-GPU step, each replayed and cold, on the current device (rank 0, N = 1)."""
     legs = {}
-    for key, wl, n_steps in (("c3", "bcast_mul", 200), ("c4", "pow", 100), ("c5_shard", "add_sum", 60)):
+    for key, wl, n_steps in (("c3", "bcast_mul", 200), ("c4", "pow", 100), ("c5_shard", "add_sum", 60), ("chain", "chain", 200)):
         leg = None
         for setting in ("replay", "cold"):
             steps, units, alg_bytes, kernel, workload, keep, info = build_workload(lib, sma, np, C, wl, args, 0, bound, setting, log2n=0)
@@ -827,7 +867,7 @@ def run_rank(args):
             legs["c5_shard"]["one_rank_rccl"], extra["rccl"] = one_rank_rccl_leg(lib, sma, np, C)
             lib.pool_trim()
             if not args.no_cpu_baseline:
-                for key, cwl in (("c3", "bcast_mul"), ("c4", "pow"), ("c5_shard", "add_sum")):
+                for key, cwl in (("c3", "bcast_mul"), ("c4", "pow"), ("c5_shard", "add_sum"), ("chain", "chain")):
                     legs[key]["cpu_baseline"] = cpu_baseline(cwl, args.cpu_log2n)
             extra["configs"] = legs
         if world == 1 and not args.no_cpu_baseline:

@@ -12,11 +12,11 @@ import sys
 from collections import defaultdict
 
 DOMINANT = {"add": "contiguous_vec_kernel", "bcast_mul": "flat_tile_kernel", "pow": "flat_tile_kernel", "add_sum": "reduce_kernel",
-            "transpose_add": "tile_kernel"}
+            "transpose_add": "tile_kernel", "chain": "chain_kernel"}
 # per LAUNCH of the dominant kernel: since round 3 the library issues operands above 512 MiB in pieces -- the 2^28-element add
 # and fused add+sum are two launches of 2^27 elements each
 ALGORITHMIC = {"add": 12 * 2 ** 27, "bcast_mul": 4 * (2 * 4096 * 4096 + 4096), "pow": 8 * 2 ** 26, "add_sum": 12 * 2 ** 27,
-               "transpose_add": 12 * 8192 * 8192}
+               "transpose_add": 12 * 8192 * 8192, "chain": 4 * (3 * 4096 * 4096 + 4096)}
 
 
 def per_launch(dirname, kernel_substr, counter):
