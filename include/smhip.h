@@ -299,6 +299,13 @@ int smhip_allreduce_sum_async(int dtype, void *inout_dev, size_t count);
  * operands).  Like a launch it records the spans as touched.  Host-only arithmetic on the pointer VALUES (nothing is
  * dereferenced, no device is needed): the residency rule's test hook. */
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy);
+/* The calling thread's device runs the library's operators on two hardware queues (independent operators overlap their
+ * tails and heads; an operator that depends on another's result, or overwrites what another still reads, is ordered behind
+ * it by queue order or an event edge -- the reference's threads likewise run whatever chunk is ready, calculate.h:47).
+ * *queues: 2, or 1 once the second queue is off for the device (SMHIP_QUEUES=1, smhip_get_stream handed the stream out, the
+ * device group is in use); *alternations: operators that took "the other" queue because they depended on nothing
+ * unfinished; *edges: cross-queue event edges issued so far.  Any output may be NULL. */
+int smhip_queue_stats(int *queues, unsigned long long *alternations, unsigned long long *edges);
 /* How a dense streaming operator over operands of `bytes_per_operand` bytes is launched: *pieces = the number of kernel
  * launches it goes out as.  `streams` = the full-size streams it moves: 3 for smhip_contiguous and the fused op+sum (two
  * reads, one write), 2 for smhip_array_scalar and smhip_dot, 1 for smhip_sum.  Three-stream operators are cut above

@@ -341,7 +341,9 @@ template <int KIND> struct HeavyTile<double, KIND> { static constexpr int value 
 template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s);
 
+#if SMHIP_POW64_BANKED
 constexpr int kBankedBlock = 1024;
+#endif
 template <typename T, typename Op, int KIND>
 void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, int nt, hipStream_t s);
 
@@ -416,7 +418,8 @@ int run_heavy_rows(const void *a, const void *b, void *out, size_t rows, size_t 
     // twice its size 44.2 -> 42.5 us (75.9 -> 79.0 %) -- while replayed and chained operands keep two (19.27 against 19.41 us;
     // tools/cold_rates.py, profiles/r03_rows_u.txt): twice the workgroups retire, and free their slots, half a tile earlier.
     const bool cold = (nt & kLoadNt) != 0;  // cold by the residency rule, or simply larger than the cache
-    if (!IsHeavy<Op>::value && U > 1 && cold) launch_rows<T, Op, 1>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
+    static const int cold_u = [] { const char *e = getenv("SMHIP_FLAT_ROWS_COLD_U"); return e && *e ? atoi(e) : 1; }();  // experiments
+    if (!IsHeavy<Op>::value && U > 1 && cold && cold_u == 1) launch_rows<T, Op, 1>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
     else launch_rows<T, Op, U>(pa, pb, po, n_vec, b_is_row, nt, cv, s);
     SMHIP_LAUNCH_CHECK("heavy rows");
     return SMHIP_OK;

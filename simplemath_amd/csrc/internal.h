@@ -16,7 +16,30 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // Makes sure this thread has a usable gfx950 device selected and returns the
 // stream its work goes to.  SMHIP_OK or SMHIP_ERR_NO_DEVICE / SMHIP_ERR_HIP.
+// Outside an operator's scope (OpScope below) it also switches the device to ONE library queue: a caller that asks for "the"
+// stream -- the sharded entry points -- relies on stream order.
 int acquire(hipStream_t *stream);
+// The same without touching the queues: the caller's stream, or the device's first library queue.
+int acquire_stream(hipStream_t *stream);
+// Second library queue of `dev` off (true) / on again (false); see runtime.hip "two queues per device".
+void dispatch_single_queue(int dev, bool single);
+
+struct Span { const void *p; size_t bytes; };
+// One operator of the C ABI: which library queue it runs on and what it is ordered behind (runtime.hip: two queues per
+// device).  begin() with the operator's operand spans lets independent operators overlap; begin_barrier() is for entry
+// points whose spans are not declared: ordered behind everything, everything later behind them.  The scope keeps the
+// device's dispatcher locked until the operator's launches are queued.
+class OpScope {
+public:
+    OpScope() = default;
+    OpScope(const OpScope &) = delete;
+    OpScope &operator=(const OpScope &) = delete;
+    ~OpScope();
+    int begin(const Span *reads, size_t n_reads, Span write, hipStream_t *stream, bool barrier = false);
+    int begin_barrier(hipStream_t *stream);
+private:
+    void *locked_ = nullptr;
+};
 
 // A recycled (or new) timing-disabled event of device `dev` (nullptr if none can be made) / its return to the pool.
 hipEvent_t pool_event_take(int dev);
@@ -95,7 +118,6 @@ int stream_policy(size_t bytes_read, size_t bytes_written);
 // and wrote, each stamped with the device's running byte count (runtime.hip: residency tracker).  A span is WARM when a
 // launch touched it within the last kWarmWindow bytes of library traffic on that device.  Also records this launch's
 // touches.  A hint only: a wrong guess costs a few percent, never a wrong result.  SMHIP_RESIDENCY=off restores round 2's rule.
-struct Span { const void *p; size_t bytes; };
 constexpr size_t kWarmWindow = (size_t)192 << 20, kTrackFloor = (size_t)2 << 20;
 int stream_policy(std::initializer_list<Span> reads, Span write);
 // The same refinement for a policy word that was planned from sizes alone (broadcast.hip's plans are shared with the

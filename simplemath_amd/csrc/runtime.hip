@@ -28,6 +28,8 @@ struct ThreadState {
     bool checked[kMaxDevices] = {};
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
+    int op_depth = 0;   // > 0: inside an operator's scope (OpScope); allocations made there are that operator's scratch
+    int op_queue = 0;   // the library queue the operator in progress runs on
     std::string error;
     // pinned staging ring for small uploads (per thread and device): copy in, enqueue, return
     unsigned char *ring[kMaxDevices] = {};
@@ -203,14 +205,19 @@ void tag_stream(Tag &tag, int dev, hipStream_t t) {
 }
 
 // Orders stream `s` (device `dev`) after everything `tag` names.
+void queues_join(int dev);
+void queues_after_external_wait(int dev);
 int order_after(Tag &tag, int dev, hipStream_t s) {
     hipError_t err = hipSuccess;
     if (tag.unknown) {
         err = hipDeviceSynchronize();
     } else {
+        bool waited = false;
         for (const Pending &p : tag.pending)
-            if (err == hipSuccess && p.stream != s) err = hipStreamWaitEvent(s, p.rec->ev, 0);
+            if (err == hipSuccess && p.stream != s) { err = hipStreamWaitEvent(s, p.rec->ev, 0); waited = true; }
+        if (waited && s == g_streams[dev]) queues_after_external_wait(dev);  // the library's second queue orders itself behind this as well
         if (err == hipSuccess && tag.lib && s != g_streams[dev] && g_streams[dev]) {
+            queues_join(dev);  // "the library stream" = both of its queues
             hipEvent_t e = take_event(dev);
             if (!e) {
                 err = hipStreamSynchronize(g_streams[dev]);
@@ -226,7 +233,237 @@ int order_after(Tag &tag, int dev, hipStream_t s) {
     return SMHIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ two queues per device
+// The reference's threads run whatever chunk is ready (calculate.h:47); a GPU stream runs its kernels strictly one after
+// the other, and between two kernels sits a fixed ~2.2 us -- dispatch, the cache write-back / invalidate at the kernel
+// boundary, the completion signal (cold operands).  A 500 us kernel hides that, a 20 us kernel shows it as ten
+// points.  Independent operators therefore go out on TWO hardware queues per device, so that one's tail overlaps the
+// next one's head: the library knows every operand span of an operator, keeps (per device) who last wrote and who last read
+// which span on which queue, puts an operator on the queue its dependencies already sit on, and on the other queue -- the
+// one the previous independent operator did NOT take -- when it has none.  A dependency that crosses queues becomes an
+// event edge (record on the producer's queue, wait on the consumer's): RAW, WAR and WAW alike.  What the tracker cannot see
+// falls back to order: operators whose spans are not declared run as BARRIER operators on queue 0 (they wait for everything
+// and everything later waits for them); a span that drops out of the tracker's ring raises a floor every later operator
+// orders itself behind; the caller's own stream (smhip_set_stream) is outside all this -- operators run there in the
+// order they were called, as before -- and a caller that takes the library's stream handle (smhip_get_stream) or drives
+// the device group (sharded entry points) turns the second queue off for that device.  SMHIP_QUEUES=1 turns it off everywhere.
+constexpr int kUses = 256;
+constexpr size_t kOverlapMinBytes = (size_t)1 << 20;   // smaller operators are barrier operators: nothing to overlap, nothing to track
+// Larger operators stay on queue 0 (tracked like the others).  Two queues do not just overlap a kernel's tail with the next
+// one's head: the hardware runs the two kernels side by side, which halves the fixed cost per launch and doubles the streams
+// the memory side sees at once.  Cold operands, % of peak with one / two queues (tools/cold_rates.py, profiles/r04_cold_rates_queues.txt):
+// a + b at 16 / 32 / 64 MiB per array 63 / 71 / 78 -> 77 / 79 / 80, at 128 / 256 MiB 80.9 / 82.5 -> 79.7 / 78.8;
+// (R, 4096) * (1, 4096) at 16 / 32 / 64 MiB 56 / 68 / 75.2 -> 65 / 74 / 75.8, at 128 MiB 79.2 -> 76.8; a * s gains up to 128 MiB.
+// (A second queue of another PRIORITY, high or low, ran like one queue: no overlap at all.)
+constexpr size_t kOverlapMaxBytes = (size_t)224 << 20;
+struct Dispatch {
+    std::recursive_mutex m;
+    hipStream_t q1 = nullptr;
+    uint64_t seq[2] = {0, 0};      // operators issued per queue
+    uint64_t synced[2][2] = {};    // synced[q][p]: queue q is ordered behind queue p's operators up to this one
+    uint64_t floor[2] = {0, 0};    // every later operator is ordered behind these (evicted spans, barrier operators)
+    // who last wrote / read which span: structure of arrays, so that the overlap scan of an operator (its <= 17 spans against
+    // every span on record) is a handful of vector compares
+    uintptr_t lo[kUses] = {}, hi[kUses] = {};
+    uint64_t wseq[kUses] = {}, rseq[kUses][2] = {};
+    unsigned char wq[kUses] = {};
+    int used = 0, next = 0;
+    int last = 1;                  // the queue the last independent operator took
+    bool single = false;           // second queue off (the stream handle was handed out, sharded use, SMHIP_QUEUES=1)
+    unsigned long long edges = 0, alternations = 0;  // diagnostics
+};
+Dispatch g_dispatch[kMaxDevices];
+bool queues_enabled() {
+    static const bool on = [] { const char *e = getenv("SMHIP_QUEUES"); return !(e && atoi(e) == 1); }();
+    return on;
+}
+hipStream_t queue_stream(int dev, int q) { return q == 0 ? g_streams[dev] : g_dispatch[dev].q1; }
+
+// Orders queue q behind queue p's operators up to `need` (no-op when it already is).  Caller holds d.m.
+int queue_wait(Dispatch &d, int dev, int q, int p, uint64_t need) {
+    if (q == p || need <= d.synced[q][p] || !queue_stream(dev, p) || !queue_stream(dev, q)) return SMHIP_OK;
+    hipEvent_t e = take_event(dev);
+    if (!e) {
+        SMHIP_TRY(hipStreamSynchronize(queue_stream(dev, p)));
+    } else {
+        hipError_t err = hipEventRecord(e, queue_stream(dev, p));
+        if (err == hipSuccess) err = hipStreamWaitEvent(queue_stream(dev, q), e, 0);
+        give_event(dev, e);
+        if (err != hipSuccess) return fail(SMHIP_ERR_HIP, "queues: ordering queue %d behind queue %d: %s", q, p, hipGetErrorString(err));
+    }
+    d.synced[q][p] = d.seq[p];  // the event covers everything queued on p so far
+    ++d.edges;
+    return SMHIP_OK;
+}
+// Queue 0 waits for everything on queue 1 and becomes the point everything later is ordered behind: what an operator
+// with undeclared spans, a read-back, a timing event or a hand-over to a caller's stream needs.  Caller holds d.m.
+int queue_barrier(Dispatch &d, int dev) {
+    if (d.q1) {
+        if (int rc = queue_wait(d, dev, 0, 1, d.seq[1])) return rc;
+    }
+    d.floor[0] = ++d.seq[0];
+    return SMHIP_OK;
+}
+// The record of span [lo, hi): the one that names exactly it, or a fresh one (what drops out of the table becomes a floor).
+int use_slot(Dispatch &d, uintptr_t lo, uintptr_t hi) {
+    for (int i = 0; i < d.used; ++i)
+        if (d.lo[i] == lo && d.hi[i] == hi) return i;
+    int i;
+    if (d.used < kUses) {
+        i = d.used++;
+    } else {
+        i = d.next;
+        d.next = (d.next + 1) % kUses;
+        if (d.wseq[i] > d.floor[d.wq[i]]) d.floor[d.wq[i]] = d.wseq[i];
+        for (int k = 0; k < 2; ++k)
+            if (d.rseq[i][k] > d.floor[k]) d.floor[k] = d.rseq[i][k];
+    }
+    d.lo[i] = lo;
+    d.hi[i] = hi;
+    d.wseq[i] = d.rseq[i][0] = d.rseq[i][1] = 0;
+    d.wq[i] = 0;
+    return i;
+}
+// What an operator that reads `reads` and writes `write` must be ordered behind, per queue -- on top of the floors, which
+// every operator is behind and which therefore say nothing about the queue that suits it.
+void dependencies(const Dispatch &d, const Span *reads, size_t n_reads, Span write, uint64_t (&need)[2]) {
+    need[0] = need[1] = 0;
+    const int n = d.used;
+    if (write.p && write.bytes) {  // WAW and WAR
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(write.p), hi = lo + write.bytes;
+        for (int i = 0; i < n; ++i) {
+            if (d.lo[i] < hi && lo < d.hi[i]) {
+                if (d.wseq[i] > need[d.wq[i]]) need[d.wq[i]] = d.wseq[i];
+                if (d.rseq[i][0] > need[0]) need[0] = d.rseq[i][0];
+                if (d.rseq[i][1] > need[1]) need[1] = d.rseq[i][1];
+            }
+        }
+    }
+    for (size_t r = 0; r < n_reads; ++r) {  // RAW
+        if (!reads[r].p || !reads[r].bytes) continue;
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(reads[r].p), hi = lo + reads[r].bytes;
+        for (int i = 0; i < n; ++i)
+            if (d.lo[i] < hi && lo < d.hi[i] && d.wseq[i] > need[d.wq[i]]) need[d.wq[i]] = d.wseq[i];
+    }
+}
 }  // namespace
+
+// An operator's scope: picks its queue, orders it behind what it depends on, and keeps the device's dispatcher locked
+// until the operator's launches are queued (another thread's operator cannot slip an event between the bookkeeping and
+// the launch it describes).
+OpScope::~OpScope() {
+    if (locked_) {
+        --tls.op_depth;
+        static_cast<Dispatch *>(locked_)->m.unlock();
+    }
+}
+int OpScope::begin_barrier(hipStream_t *s) { return begin(nullptr, 0, Span{nullptr, 0}, s, true); }
+int OpScope::begin(const Span *reads, size_t n_reads, Span write, hipStream_t *s, bool barrier) {
+    if (int rc = acquire_stream(s)) return rc;
+    if (tls.use_user_stream) return SMHIP_OK;  // the caller's stream: operators run there in call order
+    const int dev = tls.device;
+    Dispatch &d = g_dispatch[dev];
+    d.m.lock();
+    locked_ = &d;
+    if (tls.op_depth++ > 0) {  // an entry point called from inside another operator: part of that operator
+        *s = queue_stream(dev, tls.op_queue);
+        return SMHIP_OK;
+    }
+    tls.op_queue = 0;
+    size_t bytes = write.bytes;
+    for (size_t i = 0; i < n_reads; ++i) bytes += reads[i].bytes;
+    if (barrier || d.single || !queues_enabled() || bytes < kOverlapMinBytes) return queue_barrier(d, dev);
+    if (!d.q1) {
+        hipStream_t q = nullptr;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            d.single = true;
+            return queue_barrier(d, dev);
+        }
+        d.q1 = q;
+    }
+    uint64_t need[2];
+    dependencies(d, reads, n_reads, write, need);
+    // the queue that costs no event edge; an operator that depends on nothing unfinished elsewhere takes the queue the
+    // previous such operator did not
+    const bool edge0 = need[1] > d.synced[0][1], edge1 = need[0] > d.synced[1][0];  // what running on queue 0 / 1 would have to wait for
+    int q;
+    static const size_t overlap_max = [] { const char *e = getenv("SMHIP_OVERLAP_MAX_MIB"); return e && *e ? (size_t)atol(e) << 20 : kOverlapMaxBytes; }();  // experiments
+    if (bytes > overlap_max) q = 0;
+    else if (edge0 != edge1) q = edge0 ? 1 : 0;
+    else if (!edge0) { q = d.last ^ 1; d.last = q; ++d.alternations; }
+    else q = 0;
+    if (int rc = queue_wait(d, dev, q, q ^ 1, need[q ^ 1] > d.floor[q ^ 1] ? need[q ^ 1] : d.floor[q ^ 1])) return rc;
+    const uint64_t my = ++d.seq[q];
+    if (write.p && write.bytes) {
+        const int w = use_slot(d, reinterpret_cast<uintptr_t>(write.p), reinterpret_cast<uintptr_t>(write.p) + write.bytes);
+        d.wq[w] = (unsigned char)q;
+        d.wseq[w] = my;
+        d.rseq[w][0] = d.rseq[w][1] = 0;
+    }
+    for (size_t i = 0; i < n_reads; ++i) {
+        if (!reads[i].p || !reads[i].bytes) continue;
+        const int r = use_slot(d, reinterpret_cast<uintptr_t>(reads[i].p), reinterpret_cast<uintptr_t>(reads[i].p) + reads[i].bytes);
+        d.rseq[r][q] = my;
+    }
+    tls.op_queue = q;
+    *s = queue_stream(dev, q);
+    return SMHIP_OK;
+}
+
+namespace {
+// Bytes an operator in progress allocated for itself (partial sums, written-out periods, the temporaries of a cut chain): a
+// write of that operator, ordered behind whoever used those bytes before.
+int note_scratch(void *p, size_t bytes) {
+    if (tls.op_depth <= 0 || tls.use_user_stream) return SMHIP_OK;
+    const int dev = tls.device;
+    Dispatch &d = g_dispatch[dev];
+    std::lock_guard<std::recursive_mutex> lock(d.m);
+    if (d.single || !d.q1) return SMHIP_OK;  // one queue: stream order
+    const int q = tls.op_queue;
+    uint64_t need[2];
+    dependencies(d, nullptr, 0, Span{p, bytes}, need);
+    if (int rc = queue_wait(d, dev, q, q ^ 1, need[q ^ 1] > d.floor[q ^ 1] ? need[q ^ 1] : d.floor[q ^ 1])) return rc;
+    const int w = use_slot(d, reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes);
+    d.wq[w] = (unsigned char)q;
+    d.wseq[w] = d.seq[q];
+    d.rseq[w][0] = d.rseq[w][1] = 0;
+    return SMHIP_OK;
+}
+// The library's stream handle is about to order something OUTSIDE the dispatcher (a caller's stream, a host wait, a peer
+// copy): make queue 0's tail stand for all the library's work on the device.
+void queues_join(int dev) {
+    Dispatch &d = g_dispatch[dev];
+    std::lock_guard<std::recursive_mutex> lock(d.m);
+    if (d.q1) (void)queue_wait(d, dev, 0, 1, d.seq[1]);
+}
+// The host has just waited for queue 0 behind a barrier: everything either queue was given is finished, so nothing on
+// record constrains the choice of queue any more.  (Without this an operator whose operands were last written long ago
+// on queue 0 would stay on queue 0 for ever: an edge to a finished operator costs nothing on the GPU, but the policy avoids
+// edges.)
+void queues_all_complete(int dev) {
+    Dispatch &d = g_dispatch[dev];
+    std::lock_guard<std::recursive_mutex> lock(d.m);
+    d.synced[0][1] = d.seq[1];
+    d.synced[1][0] = d.seq[0];
+}
+// Queue 0 was just made to wait for something outside the dispatcher: queue 1's next operator orders itself behind that.
+void queues_after_external_wait(int dev) {
+    Dispatch &d = g_dispatch[dev];
+    std::lock_guard<std::recursive_mutex> lock(d.m);
+    d.floor[0] = ++d.seq[0];
+}
+}  // namespace
+
+void dispatch_single_queue(int dev, bool single) {
+    if (dev < 0 || dev >= kMaxDevices) return;
+    Dispatch &d = g_dispatch[dev];
+    std::lock_guard<std::recursive_mutex> lock(d.m);
+    if (single && d.q1) (void)queue_wait(d, dev, 0, 1, d.seq[1]);
+    if (single) d.floor[0] = ++d.seq[0];
+    d.single = single;
+}
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -238,7 +475,15 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// A caller outside an operator's scope that wants "the" library stream of the device (the sharded entry points, which walk
+// the device group from one host thread): from then on the device runs on one queue.
 int acquire(hipStream_t *stream) {
+    if (int rc = acquire_stream(stream)) return rc;
+    if (!tls.use_user_stream && tls.op_depth == 0) dispatch_single_queue(tls.device, true);
+    return SMHIP_OK;
+}
+
+int acquire_stream(hipStream_t *stream) {
     {
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_device_count < 0) {
@@ -424,9 +669,30 @@ ThreadState::~ThreadState() {
 
 using namespace smhip;
 
+// An entry point whose operand spans are not declared: a barrier operator (ordered behind everything, everything later
+// behind it) for as long as the function runs.
 #define SMHIP_ACQUIRE(stream_var)  \
     hipStream_t stream_var;        \
-    if (int rc_ = acquire(&stream_var)) return rc_
+    OpScope op_scope_;             \
+    if (int rc_ = op_scope_.begin_barrier(&stream_var)) return rc_
+// An operator with declared spans: reads {ptr, bytes}..., one write.
+#define SMHIP_ACQUIRE_OP(stream_var, write_span, ...)                                                         \
+    hipStream_t stream_var;                                                                                  \
+    OpScope op_scope_;                                                                                       \
+    {                                                                                                        \
+        const Span reads_[] = {__VA_ARGS__};                                                                 \
+        if (int rc_ = op_scope_.begin(reads_, sizeof reads_ / sizeof reads_[0], write_span, &stream_var)) return rc_; \
+    }
+
+namespace {
+// Bytes from an operand's first element to its last, through `strides` over `shape`.
+size_t span_bytes(const int64_t *shape, const int64_t *strides, int ndim, size_t esz) {
+    size_t last = 0;
+    for (int i = 0; i < ndim; ++i)
+        if (shape[i] > 0) last += (size_t)(shape[i] - 1) * (size_t)strides[i];
+    return (last + 1) * esz;
+}
+}  // namespace
 
 extern "C" {
 
@@ -450,7 +716,7 @@ int smhip_set_device(int device) {
     const int prev = tls.device;
     tls.device = device;
     hipStream_t s;
-    if (int rc = acquire(&s)) {
+    if (int rc = acquire_stream(&s)) {
         tls.device = prev;
         return rc;
     }
@@ -471,12 +737,14 @@ int smhip_set_stream(void *hip_stream) {
         hipStream_t prev = tls.use_user_stream ? tls.user_stream : g_streams[tls.device];
         hipStream_t now = next ? next : g_streams[tls.device];
         if (prev && now && prev != now) {
+            if (prev == g_streams[tls.device]) queues_join(tls.device);  // the library's first queue speaks for both
             hipEvent_t e = take_event(tls.device);
             if (e) {
                 if (hipEventRecord(e, prev) == hipSuccess) (void)hipStreamWaitEvent(now, e, 0);
                 (void)hipGetLastError();  // a previous stream that is already gone has nothing left to order
                 give_event(tls.device, e);
             }
+            if (now == g_streams[tls.device]) queues_after_external_wait(tls.device);
         }
     }
     tls.user_stream = next;
@@ -486,14 +754,16 @@ int smhip_set_stream(void *hip_stream) {
 
 int smhip_get_stream(void **hip_stream) {
     if (!hip_stream) return fail(SMHIP_ERR_INVALID, "get_stream: null");
-    SMHIP_ACQUIRE(s);
+    hipStream_t s;
+    if (int rc = acquire(&s)) return rc;  // the handle leaves the library: the device runs on ONE queue from here on (stream order is what the caller sees)
     *hip_stream = s;
     return SMHIP_OK;
 }
 
 int smhip_synchronize(void) {
-    SMHIP_ACQUIRE(s);
+    SMHIP_ACQUIRE(s);  // a barrier: queue 0 is behind everything on queue 1
     SMHIP_TRY(hipStreamSynchronize(s));
+    if (!tls.use_user_stream) queues_all_complete(tls.device);
     return SMHIP_OK;
 }
 
@@ -501,7 +771,8 @@ int smhip_synchronize(void) {
 
 int smhip_alloc(void **dptr, size_t bytes) {
     if (!dptr) return fail(SMHIP_ERR_INVALID, "alloc: null");
-    SMHIP_ACQUIRE(s);
+    hipStream_t s;  // no operator: the queues are not touched (who uses the bytes, and on which queue, is the operators' business)
+    if (int rc = acquire_stream(&s)) return rc;
     const size_t cls = size_class(bytes);
     const int dev = tls.device;
     void *p = nullptr;
@@ -573,12 +844,14 @@ int smhip_alloc(void **dptr, size_t bytes) {
         else g_free[{dev, cls}].push_back({p, std::move(lost)});
         return rc;
     }
-    std::lock_guard<std::mutex> lock(g_mutex);
-    g_live[p] = Block{cls, dev, arena, off, s, std::this_thread::get_id()};
-    g_bytes_live += cls;
-    g_bytes_cached -= cls;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        g_live[p] = Block{cls, dev, arena, off, s, std::this_thread::get_id()};
+        g_bytes_live += cls;
+        g_bytes_cached -= cls;
+    }
     *dptr = p;
-    return SMHIP_OK;
+    return note_scratch(p, cls);  // inside an operator: its scratch, ordered behind the bytes' previous users on the other queue
 }
 
 int smhip_free(void *dptr) {
@@ -702,13 +975,14 @@ int smhip_download(void *dst_host, const void *src, size_t bytes) {
     SMHIP_ACQUIRE(s);
     SMHIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, s));
     SMHIP_TRY(hipStreamSynchronize(s));
+    if (!tls.use_user_stream) queues_all_complete(tls.device);
     return SMHIP_OK;
 }
 
 int smhip_copy(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return SMHIP_OK;
     if (!dst || !src) return fail(SMHIP_ERR_INVALID, "copy: null");
-    SMHIP_ACQUIRE(s);
+    SMHIP_ACQUIRE_OP(s, (Span{dst, bytes}), Span{src, bytes});
     // the array kernel streams a copy at 82 % of HBM peak; hipMemcpyAsync device-to-device gave 67 % (tools/misc_rates.py)
     if (bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 4 == 0) {
         const int32_t unused = 0;
@@ -722,14 +996,14 @@ int smhip_fill(int dtype, void *dst, const void *value_host, size_t n) {
     if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fill: bad dtype %d", dtype);
     if (n == 0) return SMHIP_OK;
     if (!dst || !value_host) return fail(SMHIP_ERR_INVALID, "fill: null");
-    SMHIP_ACQUIRE(s);
+    SMHIP_ACQUIRE_OP(s, (Span{dst, n * dtype_size(dtype)}), Span{nullptr, 0});
     return launch_fill(dtype, dst, value_host, n, s);
 }
 
 int smhip_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t first, float lo, float hi) {
     if (n == 0) return SMHIP_OK;
     if (!dst) return fail(SMHIP_ERR_INVALID, "fill_uniform_f32: null");
-    SMHIP_ACQUIRE(s);
+    SMHIP_ACQUIRE_OP(s, (Span{dst, n * sizeof(float)}), Span{nullptr, 0});
     return launch_fill_uniform_f32(dst, n, seed, first, lo, hi, s);
 }
 
@@ -791,7 +1065,8 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     }
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
-    SMHIP_ACQUIRE(s);
+    const size_t esz = dtype_size(dtype);
+    SMHIP_ACQUIRE_OP(s, (Span{out, (size_t)n * esz}), Span{a, span_bytes(shape, stride_a, ndim, esz)}, Span{b, span_bytes(shape, stride_b, ndim, esz)});
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
 }
 
@@ -829,7 +1104,11 @@ int smhip_fused_expr(const char *hip_expression, int dtype, const void *const *o
     if (!operands || !out) return fail(SMHIP_ERR_INVALID, "fused_expr: null buffer");
     for (int k = 0; k < n_operands; ++k)
         if (!operands[k]) return fail(SMHIP_ERR_INVALID, "fused_expr: operand %d is null", k);
-    SMHIP_ACQUIRE(s);
+    Span reads[8];
+    for (int k = 0; k < n_operands; ++k) reads[k] = Span{operands[k], n * dtype_size(dtype)};
+    hipStream_t s;
+    OpScope op_scope_;
+    if (int rc = op_scope_.begin(reads, (size_t)n_operands, Span{out, n * dtype_size(dtype)}, &s)) return rc;
     return jit_fused_expr(hip_expression, dtype, operands, n_operands, scalars_host, n_scalars, out, n, nullptr, s);
 }
 
@@ -864,7 +1143,8 @@ int smhip_copy_strided(int dtype, const void *src, const int64_t *src_strides, v
     }
     if (n == 0) return SMHIP_OK;
     if (!src || !dst) return fail(SMHIP_ERR_INVALID, "copy_strided: null buffer");
-    SMHIP_ACQUIRE(s);
+    const size_t esz = dtype_size(dtype);
+    SMHIP_ACQUIRE_OP(s, (Span{dst, span_bytes(shape, dst_strides, ndim, esz)}), Span{src, span_bytes(shape, src_strides, ndim, esz)});
     return launch_copy_strided(dtype, src, src_strides, dst, dst_strides, shape, ndim, s);
 }
 
@@ -872,7 +1152,8 @@ int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out,
     if ((!valid_op(op) && !user_op(op)) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "contiguous: bad op %d / dtype %d", op, dtype);
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "contiguous: null buffer");
-    SMHIP_ACQUIRE(s);
+    const size_t nbytes = n * dtype_size(dtype);
+    SMHIP_ACQUIRE_OP(s, (Span{out, nbytes}), Span{a, nbytes}, Span{b, nbytes});
     if (user_op(op)) return jit_contiguous(op, dtype, a, b, out, n, s);
     return launch_contiguous(op, dtype, a, b, out, n, s);
 }
@@ -881,7 +1162,8 @@ int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host,
     if ((!valid_op(op) && !user_op(op)) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "array_scalar: bad op %d / dtype %d", op, dtype);
     if (n == 0) return SMHIP_OK;
     if (!a || !value_host || !out) return fail(SMHIP_ERR_INVALID, "array_scalar: null buffer");
-    SMHIP_ACQUIRE(s);
+    const size_t nbytes = n * dtype_size(dtype);
+    SMHIP_ACQUIRE_OP(s, (Span{out, nbytes}), Span{a, nbytes});
     if (user_op(op)) return jit_array_scalar(op, dtype, a, value_host, n, out, s);
     return launch_array_scalar(op, dtype, a, value_host, n, out, s);
 }
@@ -891,7 +1173,8 @@ int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const voi
     if (!valid_op(op1) || !valid_op(op2) || !valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fused: bad op %d/%d or dtype %d", op1, op2, dtype);
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out || (!c && !c_scalar_host)) return fail(SMHIP_ERR_INVALID, "fused: null buffer");
-    SMHIP_ACQUIRE(s);
+    const size_t nbytes = n * dtype_size(dtype);
+    SMHIP_ACQUIRE_OP(s, (Span{out, nbytes}), Span{a, nbytes}, Span{b, nbytes}, Span{c, c ? nbytes : 0});
     return launch_fused(op1, op2, dtype, a, b, c, c_scalar_host, out, n, s);
 }
 
@@ -915,7 +1198,11 @@ int smhip_fused_expr_bcast(const char *hip_expression, int dtype, const void *co
     }
     if (n == 0) return SMHIP_OK;
     if (!out) return fail(SMHIP_ERR_INVALID, "fused_expr_bcast: null output");
-    SMHIP_ACQUIRE(s);
+    Span reads[8];
+    for (int k = 0; k < n_operands; ++k) reads[k] = Span{operands[k], span_bytes(shape, strides + (size_t)k * ndim, ndim, dtype_size(dtype))};
+    hipStream_t s;
+    OpScope op_scope_;
+    if (int rc = op_scope_.begin(reads, (size_t)n_operands, Span{out, (size_t)n * dtype_size(dtype)}, &s)) return rc;
     return launch_expr_bcast(hip_expression, dtype, operands, strides, n_operands, scalars_host, n_scalars, shape, ndim, out, s);
 }
 
@@ -943,7 +1230,12 @@ int smhip_chain(int dtype, int n_operands, const void *const *operands, const in
         if (ops[k] < SMHIP_OP_ADD || ops[k] > SMHIP_OP_DIV) return fail(SMHIP_ERR_UNSUPPORTED, "chain: op %d (stage %d) is not one of add, sub, mul, div", ops[k], k);
     if (n == 0) return SMHIP_OK;
     if (!out) return fail(SMHIP_ERR_INVALID, "chain: null output");
-    SMHIP_ACQUIRE(s);
+    Span reads[SMHIP_CHAIN_MAX_OPERANDS];
+    for (int k = 0; k < n_operands; ++k)
+        reads[k] = operands[k] ? Span{operands[k], span_bytes(shape, strides + (size_t)k * ndim, ndim, dtype_size(dtype))} : Span{nullptr, 0};
+    hipStream_t s;
+    OpScope op_scope_;
+    if (int rc = op_scope_.begin(reads, (size_t)n_operands, Span{out, (size_t)n * dtype_size(dtype)}, &s)) return rc;
     return launch_chain(dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, out, s);
 }
 
@@ -983,9 +1275,13 @@ int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host)
     if (!out_host || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot: null buffer");
     void *d = nullptr;
     if (int rc = smhip_alloc(&d, 16)) return rc;
-    hipStream_t s;
-    int rc = acquire(&s);
-    if (!rc) rc = launch_dot(dtype, a, b, n, nullptr, d, s);
+    int rc;
+    {
+        hipStream_t s;
+        OpScope op_scope_;
+        rc = op_scope_.begin_barrier(&s);
+        if (!rc) rc = launch_dot(dtype, a, b, n, nullptr, d, s);
+    }
     if (!rc) rc = smhip_download(out_host, d, dtype_size(dtype));
     smhip_free(d);
     return rc;
@@ -1033,6 +1329,16 @@ int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host) {
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy) {
     if (!policy) return fail(SMHIP_ERR_INVALID, "policy_probe: null");
     *policy = stream_policy({{a, a ? a_bytes : 0}, {b, b ? b_bytes : 0}}, {out, out ? out_bytes : 0});
+    return SMHIP_OK;
+}
+
+int smhip_queue_stats(int *queues, unsigned long long *alternations, unsigned long long *edges) {
+    const int dev = tls.device < 0 ? 0 : tls.device;
+    Dispatch &d = g_dispatch[dev];
+    std::lock_guard<std::recursive_mutex> lock(d.m);
+    if (queues) *queues = (d.single || !queues_enabled()) ? 1 : 2;
+    if (alternations) *alternations = d.alternations;
+    if (edges) *edges = d.edges;
     return SMHIP_OK;
 }
 

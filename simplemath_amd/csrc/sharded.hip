@@ -226,7 +226,12 @@ int smhip_shard_outer(const int64_t *shape, const int64_t *stride_a, const int64
 int smhip_set_devices(int n) {
     if (n < 0 || n > kMaxGroup) return fail(SMHIP_ERR_INVALID, "set_devices: %d", n);
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (g_ndev > 0) dissolve_group();
+    if (g_ndev > 0) {
+        const int had = g_ndev;
+        dissolve_group();
+        if (n == 0)  // no group any more: the devices' second library queues may be used again (runtime.hip: two queues per device)
+            for (int g = 0; g < had; ++g) dispatch_single_queue(g, false);
+    }
     if (n == 0) return SMHIP_OK;
     int have = 0;
     smhip_device_count(&have);

@@ -6,6 +6,9 @@
 //   4. two asynchronous reductions queued from one thread on two streams (their partials must not share a buffer);
 //   5. a sharded entry point (library streams) called by a thread that is on its OWN stream: it must see what that stream
 //      has queued before it and the stream must see its results.
+//   6. the library's TWO queues per device (runtime.hip): independent operators alternate between them, and every
+//      dependency that crosses them -- read after write, write after read, write after write, a consumer on another host
+//      thread, an operator's pooled scratch -- is an event edge.
 // The reference has nothing like this (new[]/delete[] per operator, SMArray.h:219,342-346).  Exit code 0 = all held.
 #include <hip/hip_runtime.h>
 #include <smhip.h>
@@ -32,12 +35,12 @@ static void busy(float *x, int passes) {  // x += 1, `passes` times, on the call
     for (int i = 0; i < passes; ++i) OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, x, &one, N, x));
 }
 
-static bool all_equal(const float *dev, float want) {  // checked on the calling thread's stream
-    std::vector<float> h(N);
-    if (smhip_download(h.data(), dev, N * sizeof(float)) != SMHIP_OK) return false;
-    for (size_t i = 0; i < N; i += 4099)
+static bool all_equal(const float *dev, float want, size_t count = N) {  // checked on the calling thread's stream
+    std::vector<float> h(count);
+    if (smhip_download(h.data(), dev, count * sizeof(float)) != SMHIP_OK) return false;
+    for (size_t i = 0; i < count; i += 4099)
         if (h[i] != want) { std::printf("  element %zu is %g, expected %g\n", i, h[i], want); return false; }
-    return h[N - 1] == want;
+    return h[count - 1] == want;
 }
 
 int main() {
@@ -175,6 +178,76 @@ int main() {
         OK(smhip_free(y));
         OK(smhip_set_stream(nullptr));
         OK(smhip_set_devices(0));
+    }
+    std::printf("case 6\n");
+    {  // 6. two library queues: x and y are produced by two long, independent chains (one per queue); everything below
+       // depends on both, so whichever queue it lands on it needs an event edge to the other
+        OK(smhip_set_stream(nullptr));
+        const size_t M = 8u << 20;  // 32 MiB of f32 per array: operators small enough for the second queue (runtime.hip: kOverlapMaxBytes)
+        int queues = 0;
+        unsigned long long alt0 = 0, edges0 = 0, alt1 = 0, edges1 = 0;
+        OK(smhip_queue_stats(&queues, &alt0, &edges0));
+        void *x = nullptr, *y = nullptr, *z = nullptr, *u = nullptr;
+        OK(smhip_alloc(&x, M * sizeof(float)));
+        OK(smhip_alloc(&y, M * sizeof(float)));
+        OK(smhip_alloc(&z, M * sizeof(float)));
+        OK(smhip_alloc(&u, M * sizeof(float)));
+        const float one = 1.0f, two = 2.0f;
+        for (int rep = 0; rep < 3; ++rep) {
+            OK(smhip_fill(SMHIP_F32, x, &zero, M));
+            OK(smhip_fill(SMHIP_F32, y, &zero, M));
+            OK(smhip_fill(SMHIP_F32, u, &seven, M));
+            for (int i = 0; i < 30; ++i) {  // interleaved: each chain stays on the queue of its own last writer
+                OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, x, &one, M, x));
+                OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, y, &two, M, y));
+                OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, u, &one, M, u));
+            }
+            OK(smhip_contiguous(SMHIP_OP_ADD, SMHIP_F32, x, y, z, M));   // RAW on both chains: 30 + 60
+            OK(smhip_fill(SMHIP_F32, x, &seven, M));                     // WAR: z's launch still reads x
+            OK(smhip_contiguous(SMHIP_OP_MUL, SMHIP_F32, z, y, u, M));   // WAW on u (37 by then), RAW on z and y: 90 * 60
+            bool ok_thread = false;
+            void *w = nullptr;
+            std::thread consumer([&] {  // another host thread consumes u without any host-side wait in between
+                OK(smhip_set_device(0));
+                OK(smhip_alloc(&w, M * sizeof(float)));
+                OK(smhip_array_scalar(SMHIP_OP_SUB, SMHIP_F32, u, &one, M, w));
+                ok_thread = all_equal(static_cast<float *>(w), 5399.0f, M);
+                OK(smhip_free(w));
+            });
+            consumer.join();
+            CHECK(ok_thread);
+            CHECK(all_equal(static_cast<float *>(z), 90.0f, M));
+            CHECK(all_equal(static_cast<float *>(x), 7.0f, M));
+            CHECK(all_equal(static_cast<float *>(u), 5400.0f, M));
+        }
+        // a chain that is cut (a transposed operand) allocates its temporary inside the operator: the bytes come from the pool
+        // and may have been another queue's scratch a moment ago
+        {
+            const int64_t shape[2] = {2048, 2048}, dense[2] = {2048, 1}, turned[2] = {1, 2048};
+            const size_t n = 2048u * 2048u;
+            const void *ops_[3] = {x, y, nullptr};
+            int64_t strides[6] = {dense[0], dense[1], turned[0], turned[1], 0, 0};
+            const int opc[2] = {SMHIP_OP_ADD, SMHIP_OP_MUL}, swp[2] = {0, 0};
+            const float scal[3] = {0, 0, 3.0f};
+            OK(smhip_fill(SMHIP_F32, x, &one, M));
+            OK(smhip_fill(SMHIP_F32, y, &two, M));
+            for (int rep = 0; rep < 8; ++rep) {
+                OK(smhip_chain(SMHIP_F32, 3, ops_, strides, scal, opc, swp, shape, 2, rep % 2 ? z : u));  // (x + y.T) * 3
+                OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, rep % 2 ? u : z, &one, n, rep % 2 ? u : z));  // something independent in between
+            }
+            std::vector<float> h(n);
+            OK(smhip_download(h.data(), z, n * sizeof(float)));
+            bool nine = true;
+            for (size_t i = 0; i < n; i += 997) nine = nine && h[i] == 9.0f;
+            CHECK(nine);
+        }
+        OK(smhip_queue_stats(&queues, &alt1, &edges1));
+        std::printf("  queues %d, alternations %llu, event edges %llu\n", queues, alt1 - alt0, edges1 - edges0);
+        if (queues == 2) CHECK(alt1 > alt0 && edges1 > edges0);
+        OK(smhip_free(x));
+        OK(smhip_free(y));
+        OK(smhip_free(z));
+        OK(smhip_free(u));
     }
     OK(smhip_synchronize());
     hipStreamDestroy(s1);
