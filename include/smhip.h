@@ -121,7 +121,10 @@ int smhip_is_contiguous(int ndim, const int64_t *shape, const int64_t *strides);
  * op b[sum idx_k*sb_k], idx from the row-major unravel of `linear` over
  * `shape`; `out` is dense row-major with prod(shape) elements.  Unlike
  * calculate.h:10 a 1-D call walks its strides, and
- * ndim > SMHIP_MAX_NDIM is rejected instead of overflowing (quirk 6). */
+ * ndim > SMHIP_MAX_NDIM is rejected instead of overflowing (quirk 6).
+ * `out` may BE an operand (same first element, the operand dense in the output's order: in-place a = a op b) -- every
+ * element is then read before it is written and computed once; any other overlap of `out` with an operand is undefined,
+ * as it is in the reference (calculate.h:96 writes result[linear] while other threads still read a and b). */
 int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
                       const void *b, const int64_t *stride_b,
                       const int64_t *shape, int ndim, void *out);
@@ -178,7 +181,9 @@ int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host)
  * it) to out2_host.  Synchronous. */
 int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host);
 /* The generic dot_product<T> (product.h:8-20) with T = std::complex<float>: a, b hold n {re, im} pairs of floats (8-byte
- * aligned); {re, im} of sum a[i]*b[i] to out2_host.  Accumulated in fp64 (the reference adds in float, sequentially), rounded
+ * aligned -- the kernel's 16-byte loads are legal at any element-aligned address on gfx950 and run within 2 % of aligned
+ * ones, profiles/r01_sweep_unaligned.txt, so a view that starts on an odd complex element needs no peeling);
+ * {re, im} of sum a[i]*b[i] to out2_host.  Accumulated in fp64 (the reference adds in float, sequentially), rounded
  * to float once.  Synchronous; the _async form leaves the fp64 {re, im} in device memory (out2_dev: 2 doubles). */
 int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host);
 int smhip_dot_c32_async(const void *a, const void *b, size_t n, double *out2_dev);
@@ -299,6 +304,11 @@ int smhip_allreduce_sum_async(int dtype, void *inout_dev, size_t count);
  * operands).  Like a launch it records the spans as touched.  Host-only arithmetic on the pointer VALUES (nothing is
  * dereferenced, no device is needed): the residency rule's test hook. */
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy);
+/* The same answer WITHOUT recording the spans as touched: looking does not change what the next launch is told. */
+int smhip_policy_peek(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy);
+/* For the test-suite: honour the failure-injection variables SMHIP_TEST_FAIL_COMM_INIT / SMHIP_TEST_FAIL_ALLREDUCE (the
+ * group's error paths on a one-GPU box).  Off by default: the variables alone do nothing. */
+int smhip_enable_test_hooks(int on);
 /* The calling thread's device runs the library's operators on two hardware queues (independent operators overlap their
  * tails and heads; an operator that depends on another's result, or overwrites what another still reads, is ordered behind
  * it by queue order or an event edge -- the reference's threads likewise run whatever chunk is ready, calculate.h:47).

@@ -554,6 +554,19 @@ class Smhip:
                                            C.c_size_t(out_bytes), C.byref(pol)))
         return pol.value
 
+    def policy_peek(self, a=0, a_bytes=0, b=0, b_bytes=0, out=0, out_bytes=0):
+        """policy_probe without recording the spans as touched."""
+        pol = C.c_int(0)
+        self._ck(self.c.smhip_policy_peek(C.c_void_p(a), C.c_size_t(a_bytes), C.c_void_p(b), C.c_size_t(b_bytes), C.c_void_p(out),
+                                          C.c_size_t(out_bytes), C.byref(pol)))
+        return pol.value
+
+    def queue_stats(self):
+        """(queues in use on this thread's device, operators that took the other queue, cross-queue event edges)"""
+        q, alt, edges = C.c_int(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        self._ck(self.c.smhip_queue_stats(C.byref(q), C.byref(alt), C.byref(edges)))
+        return q.value, alt.value, edges.value
+
     def launch_pieces(self, bytes_per_operand, streams=3):
         """Kernel launches a dense streaming operator over operands of this size goes out as (streams: 3 a op b, 2 a op s / dot, 1 sum)."""
         k = C.c_int(0)

@@ -576,6 +576,7 @@ struct TileParams {
     uint32_t tiles_p, tiles_q;
     uint32_t nt;                // streamed reads carry the non-temporal hint (the launch reads more than the Infinity Cache holds)
     uint32_t order;             // walk of the patches: 1 diagonal, 0 row-major (q fastest, p unshifted)
+    uint32_t in_place;          // the output overlaps an operand: no patch may compute an element twice (see the pull-back below)
 };
 
 // One workgroup = one 64 x TQ patch (i along p, j along q) of one slice of the remaining axes.
@@ -632,8 +633,11 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
         // 8192 x 8192 runs at 87 %; before the vector form took ragged extents at all, at 28 %.)
         // (only where the second helping is small change: four patches and more along the axis -- pulled back inside
         // 100 x 100 planes, short patches did 1.6 times the work)
-        if (i0 + kTileP > p.np && p.np >= 4u * kTileP) i0 = p.np - kTileP;
-        if (j0 + TQ > p.nq && p.nq >= 4u * TQ) j0 = p.nq - TQ;
+        // Storing "the same values" twice needs the operands to be what they were: an output that overlaps an operand
+        // (smhip_elementwise(ADD, a, b.T, out = a)) would feed the second computation its own results, so in-place
+        // problems keep their hanging patches on the guarded path.
+        if (i0 + kTileP > p.np && p.np >= 4u * kTileP && !p.in_place) i0 = p.np - kTileP;
+        if (j0 + TQ > p.nq && p.nq >= 4u * TQ && !p.in_place) j0 = p.nq - TQ;
     }
     const bool full = i0 + kTileP <= p.np && j0 + TQ <= p.nq;  // workgroup-uniform
     // patch origins

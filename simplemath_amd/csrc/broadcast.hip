@@ -1424,6 +1424,13 @@ int launch_plan(int op, int dtype, const void *a, const void *b, void *out, cons
                          : L.kind == Launch::kStrided ? &L.p.strided.nt : nullptr;
         const int refined = refine_policy(word ? (int)*word : 0, {span(a, pl.sa), span(b, pl.sb)}, Span{out, pl.n * esz});
         if (word) *word = (uint32_t)refined;
+        if (L.kind == Launch::kTile) {  // an output that overlaps an operand: every element is computed exactly once (bcast_kernels.hip.h: tile_body)
+            auto meets = [&](const Span &x) {
+                const char *lo = static_cast<const char *>(x.p), *o = static_cast<const char *>(out);
+                return lo < o + pl.n * esz && o < lo + x.bytes;
+            };
+            L.p.tile.in_place = meets(span(a, pl.sa)) || meets(span(b, pl.sb));
+        }
     }
     if (user) return jit_launch(op, dtype, L, a, b, out, s);
     // rows of 2..15 elements against one value per row: x dense (r, 1), y a dense vector (1, 0)

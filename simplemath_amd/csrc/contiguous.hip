@@ -392,7 +392,7 @@ void launch_rows(const T *pa, const T *pb, T *po, size_t n_vec, bool b_is_row, i
     if (b_is_row) {
         // few long rows (the broadcast row outlives no row in the L2): the kernel walks them column block by column block
         const size_t rows = n_vec / cv.d, row_bytes = (size_t)cv.d * 16;
-        static const int lg = [] { const char *e = getenv("SMHIP_ROWS_WALK_LOG2"); return e && *e ? atoi(e) : 10; }();  // workgroups per visit of a row: 2^lg (-1: flat walk)
+        static const int lg = [] { const char *e = getenv("SMHIP_ROWS_WALK_LOG2"); const int v = e && *e ? atoi(e) : 10; return v < -1 ? -1 : (v > 15 ? 15 : v); }();  // workgroups per visit of a row: 2^lg (-1: flat walk)
         const int walk = (lg >= 0 && rows >= 2 && rows <= 4096 && row_bytes >= ((size_t)4 << 20) && cv.d % ((uint32_t)(kTileBlock * U) << lg) == 0) ? (int)rows | (lg << 16) : 0;
         if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, true>), grid, block, 0, s, pa, pb, T{}, po, n_vec, walk, nt, cv);
         else hipLaunchKernelGGL((flat_tile_kernel<T, Op, 3, U, false>), grid, block, 0, s, pa, pb, T{}, po, n_vec, walk, nt, cv);

@@ -124,6 +124,8 @@ int stream_policy(std::initializer_list<Span> reads, Span write);
 // run-time compiled kernels and know no pointers): ORs in the non-temporal read hint for cold operands, records the touches.
 int refine_policy(int policy, std::initializer_list<Span> reads, Span write);
 int refine_policy(int policy, const Span *reads, size_t n_reads, Span write);
+// [p, p + bytes) on device `dev` no longer holds what a library kernel left there (freed, uploaded, peer-copied into)
+void residency_forget(int dev, const void *p, size_t bytes);
 
 // Large operands go out as several launches (contiguous.hip explains why).  piece_for(n_vec, streams) = the piece size in
 // 16-byte vectors for operands of n_vec of them, 0 for "one launch"; `streams` = the full-size streams the kernel moves

@@ -527,7 +527,7 @@ size_t piece_for(size_t n_vec, int streams) {
         const char *e = getenv("SMHIP_PIECE_LOG2VEC");
         if (!e) return -1L;
         const long k = atol(e);
-        return k <= 0 ? 0L : (k < 12 ? 12L : k);
+        return k <= 0 ? 0L : (k < 12 ? 12L : (k > 40 ? 40L : k));  // 1 << k below: keep it a shift the type can hold
     }();
     if (forced == 0) return 0;
     if (forced > 0) return n_vec > ((size_t)1 << forced) ? (size_t)1 << forced : 0;
@@ -587,6 +587,17 @@ void touch(Tracker &t, const Span &sp) {
     t.next = (t.next + 1) % 32;
 }
 }  // namespace
+
+// Bytes whose contents did not come from a library kernel -- a block handed back to the pool (its next owner's data is
+// somebody else's), an upload, a peer copy's destination -- are in no cache: the records that say otherwise go.
+void residency_forget(int dev, const void *p, size_t bytes) {
+    if (!p || bytes < kTrackFloor || dev < 0 || dev >= kMaxDevices) return;
+    Tracker &t = g_track[dev];
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+    std::lock_guard<std::mutex> lock(t.m);
+    for (Touch &e : t.ring)
+        if (e.hi > e.lo && e.lo < hi && lo < e.hi) e = Touch{};
+}
 
 int stream_policy(std::initializer_list<Span> reads, Span write) {
     size_t bytes_read = 0;
@@ -866,6 +877,7 @@ int smhip_free(void *dptr) {
         g_bytes_live -= b.cls;
         g_bytes_cached += b.cls;
     }
+    residency_forget(b.device, dptr, b.cls);
     // Who may still be working on it: the stream it was handed to, and the stream this thread's work goes to now.
     //   handed to the library stream                      -> flag, ordered lazily at reuse;
     //   handed to the stream this thread is on            -> an event recorded on it now;
@@ -934,6 +946,7 @@ int smhip_upload(void *dst, const void *src_host, size_t bytes) {
     if (bytes == 0) return SMHIP_OK;
     if (!dst || !src_host) return fail(SMHIP_ERR_INVALID, "upload: null");
     SMHIP_ACQUIRE(s);
+    residency_forget(tls.device, dst, bytes);
     // Small uploads (the reference's simple_check builds 25-element arrays per iteration) go through a
     // pinned ring: the caller's buffer is free again on return and nothing waits for the GPU.  The
     // stream is drained only when the ring wraps (every kRingBytes of small uploads) or changes stream.
@@ -1329,6 +1342,26 @@ int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host) {
 int smhip_policy_probe(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy) {
     if (!policy) return fail(SMHIP_ERR_INVALID, "policy_probe: null");
     *policy = stream_policy({{a, a ? a_bytes : 0}, {b, b ? b_bytes : 0}}, {out, out ? out_bytes : 0});
+    return SMHIP_OK;
+}
+
+int smhip_policy_peek(const void *a, size_t a_bytes, const void *b, size_t b_bytes, const void *out, size_t out_bytes, int *policy) {
+    if (!policy) return fail(SMHIP_ERR_INVALID, "policy_peek: null");
+    const Span reads[2] = {{a, a ? a_bytes : 0}, {b, b ? b_bytes : 0}};
+    int pol = stream_policy(reads[0].bytes + reads[1].bytes, out ? out_bytes : 0);
+    if (!(pol & kPolicyLoadNt)) {  // refine_policy's rule without its bookkeeping
+        Tracker &t = g_track[current_device()];
+        std::lock_guard<std::mutex> lock(t.m);
+        size_t considered = 0, cold = 0;
+        for (const Span &r : reads) {
+            if (!r.p || r.bytes < kTrackFloor) continue;
+            considered += r.bytes;
+            if (!warm(t, r)) cold += r.bytes;
+        }
+        static const bool off = [] { const char *e = getenv("SMHIP_RESIDENCY"); return e && strcmp(e, "off") == 0; }();
+        if (!off && considered && 2 * cold > considered) pol |= kPolicyLoadNt;
+    }
+    *policy = pol;
     return SMHIP_OK;
 }
 

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "internal.h"
@@ -81,9 +82,13 @@ int load_rccl() {  // caller holds g_mutex
     return SMHIP_OK;
 }
 
+// Failure injection for the test-suite.  Off unless the process has called smhip_enable_test_hooks(1): a stray environment
+// variable in a job cannot abort its communicators, and a production call pays one relaxed load.
+std::atomic<int> g_test_hooks{0};
 // SMHIP_TEST_FAIL_COMM_INIT=1 makes smhip_set_devices behave as if ncclCommInitAll had failed: the error path's
 // clean-up (slots back to the pool, no group left behind) is then testable on a one-GPU box.
 bool test_hook_fail_comm_init() {
+    if (!g_test_hooks.load(std::memory_order_relaxed)) return false;
     const char *e = getenv("SMHIP_TEST_FAIL_COMM_INIT");
     return e && e[0] == '1';
 }
@@ -91,6 +96,7 @@ bool test_hook_fail_comm_init() {
 // SMHIP_TEST_FAIL_ALLREDUCE=<g>: the group all-reduce fails when it reaches device g (after devices 0..g-1 have queued
 // their half) -- the "partly issued collective" path.
 bool test_hook_fail_allreduce(int g) {
+    if (!g_test_hooks.load(std::memory_order_relaxed)) return false;
     const char *e = getenv("SMHIP_TEST_FAIL_ALLREDUCE");
     return e && e[0] && atoi(e) == g;
 }
@@ -435,6 +441,7 @@ int smhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, 
         hipError_t e = hipSuccess;
         if (!rc) e = hipStreamWaitEvent(s_dst, ready, 0);
         if (!rc && e == hipSuccess) e = hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, s_dst);
+        residency_forget(dst_device, dst, bytes);  // what arrives over xGMI is in no cache of this GPU
         if (!rc && e == hipSuccess && !(done = pool_event_take(dst_device))) e = hipErrorOutOfMemory;
         if (!rc && e == hipSuccess) e = hipEventRecord(done, s_dst);
         if (!rc && e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "copy_peer %d -> %d: %s", src_device, dst_device, hipGetErrorString(e));
@@ -505,6 +512,11 @@ int smhip_group_info(int index, int *nranks, int *rank, int *device) {
     if (nranks) *nranks = n;
     if (rank) *rank = r;
     if (device) *device = d;
+    return SMHIP_OK;
+}
+
+int smhip_enable_test_hooks(int on) {
+    g_test_hooks.store(on ? 1 : 0, std::memory_order_relaxed);
     return SMHIP_OK;
 }
 

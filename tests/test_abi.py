@@ -148,3 +148,17 @@ def test_residency_rule_can_be_switched_off():
     env = dict(os.environ, SMHIP_RESIDENCY="off", PYTHONPATH=sma.ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "2", r.stdout + r.stderr   # round 2's size-only rule: plain reads, kept stores
+
+
+def test_policy_peek_does_not_touch(lib):
+    """looking at the residency rule must not change it -- smhip_policy_peek answers like smhip_policy_probe
+    without recording the spans; only the probe (like a launch) makes an operand warm."""
+    MiB = 1 << 20
+    NT, KEEP = 1, 2
+    base = 0x7100_0000_0000
+    a, out = base, base + 64 * MiB
+    assert lib.policy_peek(a, 64 * MiB, 0, 0, out, 64 * MiB) == NT | KEEP
+    assert lib.policy_peek(a, 64 * MiB, 0, 0, out, 64 * MiB) == NT | KEEP       # still cold: peeking recorded nothing
+    assert lib.policy_probe(a, 64 * MiB, 0, 0, out, 64 * MiB) == NT | KEEP      # the probe records ...
+    assert lib.policy_peek(a, 64 * MiB, 0, 0, out, 64 * MiB) == KEEP            # ... and now it is warm
+    assert lib.policy_peek(out, 64 * MiB, 0, 0, a, 64 * MiB) == KEEP

@@ -1677,3 +1677,16 @@ def test_store_policy_keep_arm_other_types(smhip, dtn):
         dAT = sma.DeviceArray(smhip, da.base_ptr, dt, (cols, rows), (1, cols), 0, da._owner)
         dB = sma.DeviceArray(smhip, db.base_ptr, dt, (cols, rows), (rows, 1), 0, db._owner)
         assert np.array_equal(smhip.binary(sma.OP_ADD, dAT, dB).numpy(), A.T + b.reshape(cols, rows))
+
+
+def test_in_place_against_a_transposed_operand_with_ragged_extents(smhip, oracle):
+    """smhip_elementwise(ADD, a, b.T, out = a) on extents the tile kernel's patches do not divide (a hanging
+    patch is normally pulled back inside and recomputes its neighbour's elements -- with the output in an operand's place
+    that would apply the Op twice).  Every element must be computed exactly once."""
+    for n, dt in ((1031, np.float32), (517, np.float64), (1031, np.int32)):
+        a = gen.gen(dt, n * n, 71, "uniform").reshape(n, n)
+        b = gen.gen(dt, n * n, 72, "uniform").reshape(n, n)
+        want = oracle.binary(orc.ADD, a, b.T)
+        da, db = smhip.to_device(a), smhip.to_device(b)
+        smhip.binary(sma.OP_ADD, da, db.view_like(b.T, b), out=da)
+        util.assert_same_bits(da.numpy(), want, f"in place, {n} x {n} {np.dtype(dt).name}")

@@ -168,8 +168,14 @@ def test_failed_group_setup_leaves_nothing_behind(smhip, monkeypatch):
     lib.synchronize()
     in_use_before, _ = lib.pool_stats()
     monkeypatch.setenv("SMHIP_TEST_FAIL_COMM_INIT", "1")
-    with pytest.raises(sma.SmhipError, match="ncclCommInitAll"):
-        lib.set_devices(1)
+    lib.set_devices(1)  # the variable alone does nothing: the hooks have to be switched on
+    lib.set_devices(0)
+    lib.c.smhip_enable_test_hooks(1)
+    try:
+        with pytest.raises(sma.SmhipError, match="ncclCommInitAll"):
+            lib.set_devices(1)
+    finally:
+        lib.c.smhip_enable_test_hooks(0)
     assert lib.get_devices() == 0
     assert lib.pool_stats()[0] == in_use_before
     monkeypatch.delenv("SMHIP_TEST_FAIL_COMM_INIT")
@@ -192,8 +198,12 @@ def test_partly_issued_collective_dissolves_the_group(smhip, monkeypatch):
     lib.set_devices(1)
     x = lib.to_device(np.arange(1000, dtype=np.float32))
     monkeypatch.setenv("SMHIP_TEST_FAIL_ALLREDUCE", "0")
-    with pytest.raises(sma.SmhipError, match="the device group was dissolved"):
-        lib.sharded_sum(np.float32, [x.ptr], [1000])
+    lib.c.smhip_enable_test_hooks(1)
+    try:
+        with pytest.raises(sma.SmhipError, match="the device group was dissolved"):
+            lib.sharded_sum(np.float32, [x.ptr], [1000])
+    finally:
+        lib.c.smhip_enable_test_hooks(0)
     assert lib.get_devices() == 0
     monkeypatch.delenv("SMHIP_TEST_FAIL_ALLREDUCE")
     with pytest.raises(sma.SmhipError, match="smhip_set_devices"):

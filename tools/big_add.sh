@@ -13,6 +13,6 @@ done
 for lg in 30; do
   for piece in 0 24; do
     r=$(SMHIP_PIECE_LOG2VEC=$piece timeout -k 10 120 python bench.py --workload pow --log2n $lg --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f us  %.1f %%' % (d['roofline']['kernel_ms']*1000, d['roofline']['frac']*100))")
-    echo "pow f32 N=2^$lg (heavy tile kernel: never split) piece=$piece: $r"
+    echo "pow f32 N=2^$lg (heavy tile kernel; two streams: by default split only above 2 GiB per operand) piece=$piece: $r"
   done
 done

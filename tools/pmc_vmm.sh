@@ -14,7 +14,7 @@ done
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-names = [ln.strip().rsplit("4 launches", 1)[0].strip() for ln in open(f"{out}/pmc_vmm_utcl1.log") if "4 launches" in ln]
+names = [ln.strip().split("4 launches", 1)[0].strip() for ln in open(f"{out}/pmc_vmm_utcl1.log") if "4 launches" in ln]
 table = collections.defaultdict(dict)
 for name in ("utcl1", "utcl2"):
     for f in glob.glob(f"{out}/pmc_vmm_{name}/**/*counter_collection.csv", recursive=True):

@@ -57,16 +57,34 @@ static bool vmm_alloc(Slab &s, size_t bytes, size_t handle_bytes, size_t va_alig
     if (e != hipSuccess) { printf("  hipMemSetAccess: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); return false; }
     return true;
 }
+// Round 3: two of six runs of this tool under `rocprofv3 --pmc` ended in a GPU memory access fault and a hang, both right
+// after the "1 GiB handles" variant at 2^30, i.e. while that mapping was torn down or the next variant -- ONE 12 GiB handle,
+// reserved right afterwards and, as the driver hands addresses out, at the SAME virtual address -- was brought up
+// (gpurun_out/r03x/pmc_vmm_utcl2.log:17, gpurun_out/r03final/pmc_vmm_utcl1.log:17).  The teardown discarded every return
+// code and the pmc mode did not print addresses, so the logs could not say whose address faulted.  Now: every call is
+// checked and reported, the device is synchronised before the unmap, a torn-down reservation is NOT handed back until
+// the program ends (the next variant cannot get the same virtual address: no stale translation can alias it), and every
+// variant prints its address range and handle count in both modes.
+static std::vector<std::pair<void *, size_t>> g_retired_va;
+static void report(const char *what, hipError_t e) {
+    if (e != hipSuccess) { printf("  %s: %s\n", what, hipGetErrorString(e)); (void)hipGetLastError(); }
+}
 static void slab_free(Slab &s) {
     if (!s.ptr) return;
+    report("hipDeviceSynchronize before teardown", hipDeviceSynchronize());
     if (s.vmm) {
-        (void)hipMemUnmap(s.ptr, s.bytes);
-        for (auto h : s.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(s.ptr, s.bytes);
+        report("hipMemUnmap", hipMemUnmap(s.ptr, s.bytes));
+        for (auto h : s.handles) report("hipMemRelease", hipMemRelease(h));
+        g_retired_va.push_back({s.ptr, s.bytes});  // the reservation stays until the end: its address is not reused
     } else {
-        (void)hipFree(s.ptr);
+        report("hipFree", hipFree(s.ptr));
     }
     s = Slab();
+}
+static void retire_all() {
+    report("hipDeviceSynchronize at exit", hipDeviceSynchronize());
+    for (auto &va : g_retired_va) report("hipMemAddressFree", hipMemAddressFree(va.first, va.second));
+    g_retired_va.clear();
 }
 
 int main(int argc, char **argv) {
@@ -111,7 +129,7 @@ int main(int argc, char **argv) {
             if (pmc) {
                 for (int i = 0; i < 4; ++i) add_k<<<grid, 1024>>>((const f4 *)a, (const f4 *)b, (f4 *)o);
                 CK(hipDeviceSynchronize());
-                printf("2^%d %-30s 4 launches\n", lg, h.name);
+                printf("2^%d %-30s 4 launches   [%p, %p)  %zu handle(s)\n", lg, h.name, s.ptr, (void *)((char *)s.ptr + s.bytes), s.handles.size());
                 fflush(stdout);
                 slab_free(s);
                 continue;
@@ -133,5 +151,6 @@ int main(int argc, char **argv) {
             slab_free(s);
         }
     }
+    retire_all();
     return 0;
 }
