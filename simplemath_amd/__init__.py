@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 
@@ -59,6 +60,12 @@ class DeviceArray:
 
     @property
     def ptr(self):
+        # `lib.to_device(x).ptr` hands out the address of a block that returns to the pool the moment the expression ends
+        # (two of round 3's red runs were that).  A temporary has no reference beyond the ones this call itself holds:
+        # the evaluation stack, `self`, and getrefcount's argument.
+        if sys.getrefcount(self) <= 3 and sys.getrefcount(self._owner) <= 2:  # (a temporary VIEW of a live array is fine: the owner lives on)
+            raise RuntimeError("DeviceArray.ptr on a temporary: its memory goes back to the pool when this expression ends -- "
+                               "keep the array in a variable for as long as the pointer is in use")
         return self.base_ptr + self.offset * self.dtype.itemsize
 
     @property

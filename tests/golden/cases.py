@@ -263,6 +263,41 @@ def powf_input(c):
     return gen.gen(np.float32, c["n"], c["seed"], c["kind"])
 
 
+# ------------------------------------------------- the sizes the reference benchmarks and tests at
+# million_check: ones<float>(1'000'000) + ones (benchmark/add.cpp:21-29); the scalar forms at 100 003 (just past the
+# n > 100 000 OpenMP gate, calculate.h:152) and 1 000 000; tests/pow.cpp:46-61: empty<int>(1000, 1000, 2) filled with 5, ^3.
+# Recorded as 64-value head + tail and the sha256 of the full output (make_golden.py bench_sizes -> bench_sizes.npz).
+def bench_size_cases():
+    return [
+        {"id": "million-ones-f32-add", "kind": "contig", "dtype": "f32", "op": "add", "n": 1_000_000, "fill": "ones"},
+        {"id": "million-f32-add", "kind": "contig", "dtype": "f32", "op": "add", "n": 1_000_000, "seed_a": 21001, "seed_b": 21002},
+        {"id": "million-f32-div", "kind": "contig", "dtype": "f32", "op": "div", "n": 1_000_000, "seed_a": 21003, "seed_b": 21004},
+        {"id": "million-i32-mul", "kind": "contig", "dtype": "i32", "op": "mul", "n": 1_000_000, "seed_a": 21005, "seed_b": 21006},
+        {"id": "scalar-f32-mul-100003", "kind": "scalar", "dtype": "f32", "op": "mul", "n": 100_003, "scalar": 2.5, "seed": 21011},
+        {"id": "scalar-f32-div-1000000", "kind": "scalar", "dtype": "f32", "op": "div", "n": 1_000_000, "scalar": 3.0, "seed": 21012},
+        {"id": "scalar-f64-add-100003", "kind": "scalar", "dtype": "f64", "op": "add", "n": 100_003, "scalar": 0.1, "seed": 21013},
+        {"id": "scalar-i32-sub-1000000", "kind": "scalar", "dtype": "i32", "op": "sub", "n": 1_000_000, "scalar": 7, "seed": 21014},
+        {"id": "ipow-fives-2000000-3", "kind": "ipow", "n": 2_000_000, "exp": 3, "fill": 5},
+        {"id": "ipow-2000000-3", "kind": "ipow", "n": 2_000_000, "exp": 3, "seed": 21021},
+        {"id": "ipow-2000000--2", "kind": "ipow", "n": 2_000_000, "exp": -2, "seed": 21022},
+    ]
+
+
+def bench_size_inputs(c):
+    """-> (a, b or None)"""
+    if c["kind"] == "contig":
+        dt = DT[c["dtype"]]
+        if c.get("fill") == "ones":
+            return np.ones(c["n"], dtype=dt), np.ones(c["n"], dtype=dt)
+        kb = "nonzero" if c["dtype"] == "i32" and c["op"] == "div" else "uniform"
+        return gen.gen(dt, c["n"], c["seed_a"], "uniform"), gen.gen(dt, c["n"], c["seed_b"], kb)
+    if c["kind"] == "scalar":
+        return gen.gen(DT[c["dtype"]], c["n"], c["seed"], "uniform"), None
+    if "fill" in c:
+        return np.full(c["n"], c["fill"], dtype=np.int32), None
+    return (gen.gen(np.int32, c["n"], c["seed"], "uniform") % np.int32(60) - np.int32(30)).astype(np.int32), None
+
+
 def digest(*arrays) -> str:
     h = hashlib.sha256()
     for a in arrays:

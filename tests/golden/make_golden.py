@@ -15,6 +15,8 @@ through oracle/_ref/libsmref.so (oracle/ref_shim.cpp).  Outputs:
     tests/golden/ipow.npz         PowOp<int> via array_scalar_op (pow.h:70-81, crafted_pow.h:54-103)
     tests/golden/dot.npz          dot_product<T>             (product.h)
     tests/golden/dot_extra.npz    dot_product<std::complex<double>> and the generic dot_product<T> (product.h:168-224, :8-20)
+    tests/golden/bench_sizes.npz  the contiguous / scalar / int-pow loops at the sizes the reference benchmarks and tests at
+                                  (benchmark/add.cpp:21-29: N = 1 000 000; calculate.h:152's gate: 100 003; tests/pow.cpp:46-61: 2 000 000)
     tests/golden/powf.npz         PowOp<float>::apply = glibc powf (pow.h:8-10) AND the
                                   correctly-rounded value computed in fp64 (the parity target;
                                   the reference itself pins no float pow -- SURVEY 8c)
@@ -70,10 +72,29 @@ def make_dot_extra(ref):
     print("dot_extra:", len(st) // 4, "cases")
 
 
+def make_bench_sizes(ref):
+    """The reference's own outputs at the sizes it benchmarks and tests at (cases.bench_size_cases): head + tail + sha256."""
+    st = {}
+    for c in cases.bench_size_cases():
+        a, b = cases.bench_size_inputs(c)
+        if c["kind"] == "contig":
+            out = ref.elementwise(orc.OPS[c["op"]], a, [1], b, [1], [c["n"]])  # ndim == 1: handle_contiguous_arrays (calculate.h:10)
+            _put(st, c["id"], out, (a, b), big=True)
+        elif c["kind"] == "scalar":
+            _put(st, c["id"], ref.array_scalar(orc.OPS[c["op"]], a, c["scalar"]), (a,), big=True)
+        else:
+            _put(st, c["id"], ref.array_scalar(orc.POW, a, c["exp"]), (a,), big=True)
+    np.savez_compressed(os.path.join(HERE, "bench_sizes.npz"), **st)
+    print("bench_sizes:", len(st) // 4, "cases")
+
+
 def main():
     ref = orc.Reference()
     if sys.argv[1:] == ["dot_extra"]:  # only the file added in round 3 (the others stay byte-identical in git)
         make_dot_extra(ref)
+        return
+    if sys.argv[1:] == ["bench_sizes"]:  # only the file added in round 4
+        make_bench_sizes(ref)
         return
     OPS = orc.OPS
 
@@ -127,6 +148,7 @@ def main():
     print("dot:", len(st) // 4, "cases")
 
     make_dot_extra(ref)
+    make_bench_sizes(ref)
 
     st = {}
     for c in cases.powf_cases():

@@ -89,6 +89,26 @@ def test_golden_scalar(smhip):
         _check_fixture(st, c["id"], out)
 
 
+def test_golden_bench_sizes(smhip):
+    """Reference-recorded fixtures at the sizes the reference benchmarks and tests at: contiguous add /
+    div / mul at N = 1 000 000 (benchmark/add.cpp:21-29: ones, and seeded), the scalar forms at 100 003 and 1 000 000,
+    int pow on 2 000 000 elements (tests/pow.cpp:46-61).  Head, tail and the sha256 of the whole output."""
+    st = util.load_npz("bench_sizes.npz")
+    for c in cases.bench_size_cases():
+        a, b = cases.bench_size_inputs(c)
+        da = smhip.to_device(a)
+        if c["kind"] == "contig":
+            db = smhip.to_device(b)
+            _check_fixture(st, c["id"], smhip.contiguous(sma.OPS[c["op"]], da, db).numpy(), big=True)
+            _check_fixture(st, c["id"], smhip.binary(sma.OPS[c["op"]], da, db).numpy(), big=True)  # through element_wise_op's dispatch
+        elif c["kind"] == "scalar":
+            _check_fixture(st, c["id"], smhip.array_scalar(sma.OPS[c["op"]], da, c["scalar"]).numpy(), big=True)
+        else:
+            # n is a multiple of 8: no libm tail in the reference (calculate.h:166-168), the vector body everywhere
+            assert c["n"] % 8 == 0
+            _check_fixture(st, c["id"], smhip.array_scalar(sma.OP_POW, da, c["exp"]).numpy(), big=True)
+
+
 def _pow_fits_i32(base, e):
     if e < 0 and base == 0:
         return False  # the reference's libm tail turns 0^negative = inf into INT_MIN; its vector body gives 0
