@@ -305,6 +305,12 @@ def cpu_baseline(wl, log2n):
         if ref is not None:
             c1["reference_ns"] = med(lambda: ref.bench_add_f32(am, bm), 200) * 1e9
         res["config1_million_check"] = c1
+        if ref is not None and hasattr(ref.lib, "ref_bench_tiny"):
+            # the reference's tiny benchmarks on THIS host (BASELINE.md quotes them from a Ryzen 5 3600): the bodies of simple_check
+            # (benchmark/add.cpp:4-19), BM_SMArrayPow_1D / _2D (benchmark/pow.cpp:5-28); the GPU side of the same bodies is what
+            # simplemath_amd/bin/benchmark_add / benchmark_pow print (profiles/r04_small_array_breakdown.txt puts them side by side)
+            res["tiny_benchmarks_reference_ns"] = {"simple_check": ref.bench_tiny(0), "BM_SMArrayPow_1D": ref.bench_tiny(1),
+                                                   "BM_SMArrayPow_2D": ref.bench_tiny(2), "cores": 1}
     return res
 
 

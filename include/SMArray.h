@@ -872,95 +872,103 @@ namespace detail {
 
 // A recorded operator chain: r = leaf[0]; r = r op[k] leaf[k + 1] (swapped[k]: leaf[k + 1] op[k] r).  Owned by the Storage
 // of its (not yet computed) result; run() evaluates it there -- through smhip_chain (csrc/chain.hip: one pass where the
-// operands allow), or, for a chain that stayed one operator long, through the plain operator's own path.
+// operands allow), or, for a chain that stayed one operator long, through the plain operator's entry point.  A leaf keeps
+// the operand's storage alive and a copy of its offset / shape / strides in place (no allocation per operand: recording an
+// operator costs one allocation, the chain itself).
 template <typename T>
 struct Chain final : PendingBase {
     static constexpr int kMaxLeaves = 8;
     struct Leaf {
-        SMArray<T> array;  // an alias: keeps the operand's storage alive, knows its offset / shape / strides
+        std::shared_ptr<Storage<T>> st;
+        std::size_t offset = 0, total = 0;
+        int ndim = 0;
+        std::size_t shape[MAX_NDIM] = {}, strides[MAX_NDIM] = {};
         bool is_scalar = false;
         T value{};
-        Leaf(SMArray<T> &&a) : array(std::move(a)) {}
-        Leaf(SMArray<T> &&a, T v) : array(std::move(a)), is_scalar(true), value(v) {}
+        bool dense() const {
+            std::size_t expect = 1;
+            for (int i = ndim; i-- > 0;) {
+                if (strides[i] != expect) return false;
+                expect *= shape[i];
+            }
+            return true;
+        }
     };
     Storage<T> *out;
-    std::vector<std::size_t> shape;  // of the result so far
+    int out_ndim = 0;
+    std::size_t out_shape[MAX_NDIM] = {};
     int device;
-    std::vector<Leaf> leaves;
+    int n_leaves = 0;
+    Leaf leaves[kMaxLeaves];
     int ops[kMaxLeaves] = {}, swapped[kMaxLeaves] = {};
 
-    Chain(Storage<T> *o, const std::vector<std::size_t> &sh, int dev, const SMArray<T> &head) : out(o), shape(sh), device(dev) {
-        leaves.reserve(4);
-        leaves.emplace_back(head.alias());
+    Chain(Storage<T> *o, const std::vector<std::size_t> &sh, int dev, const SMArray<T> &head) : out(o), device(dev) {
+        retarget(o, sh);
+        set(leaves[n_leaves++], head);
     }
-    bool full() const { return static_cast<int>(leaves.size()) == kMaxLeaves; }
-    void retarget(Storage<T> *o, const std::vector<std::size_t> &sh) { out = o; shape = sh; }
+    bool full() const { return n_leaves == kMaxLeaves; }
+    void retarget(Storage<T> *o, const std::vector<std::size_t> &sh) {
+        out = o;
+        out_ndim = static_cast<int>(sh.size());
+        for (int i = 0; i < out_ndim; ++i) out_shape[i] = sh[i];
+    }
     void push(int op, bool swap, const SMArray<T> &operand) {
-        ops[leaves.size() - 1] = op;
-        swapped[leaves.size() - 1] = swap;
-        leaves.emplace_back(operand.alias());
+        ops[n_leaves - 1] = op;
+        swapped[n_leaves - 1] = swap;
+        set(leaves[n_leaves++], operand);
     }
     void push(int op, bool swap, T scalar) {
-        ops[leaves.size() - 1] = op;
-        swapped[leaves.size() - 1] = swap;
-        leaves.emplace_back(leaves[0].array.alias(), scalar);  // the alias is a placeholder: a scalar leaf has no array
+        ops[n_leaves - 1] = op;
+        swapped[n_leaves - 1] = swap;
+        Leaf &lf = leaves[n_leaves++];
+        lf.is_scalar = true;
+        lf.value = scalar;
     }
 
     void run() override {
         std::unique_ptr<PendingBase> self = std::move(out->pending);  // the result is no longer pending; *this lives to the end of run()
         if (tls_pending == this) tls_pending = nullptr;
-        SMArray<T> result;  // a handle on the result's storage for the duration of the call
-        result.data = HostPtr<T>(out->shared_from_this(), 0);
-        result._shape = shape;
-        result._strides = dense_strides(shape);
-        result.ndim = shape.size();
-        result.totalSize = calculateTotalSize(shape);
         hip::DeviceGuard on(device);
-        const int n = static_cast<int>(leaves.size());
-        if (n == 2) {  // one operator after all: exactly what the operator did before chains existed
-            ++tls_fusion_stats.single_ops;
-            single(result);
-            return;
-        }
-        const std::size_t nd = shape.size();
-        std::vector<std::int64_t> strides(static_cast<std::size_t>(n) * nd, 0), sh(shape.begin(), shape.end());
+        const int n = n_leaves, nd = out_ndim;
+        std::int64_t strides[kMaxLeaves * MAX_NDIM] = {}, sh[MAX_NDIM];
+        for (int i = 0; i < nd; ++i) sh[i] = static_cast<std::int64_t>(out_shape[i]);
         const void *ptrs[kMaxLeaves] = {};
         T scalars[kMaxLeaves] = {};
         for (int k = 0; k < n; ++k) {
             const Leaf &lf = leaves[k];
             if (lf.is_scalar) { scalars[k] = lf.value; continue; }
-            const auto &ls = lf.array._shape;
-            const auto &lt = lf.array._strides;
-            const std::size_t shift = nd - ls.size();  // right-aligned, as sm::broadcast aligns them (SMUtils.h:51-72)
-            for (std::size_t i = 0; i < ls.size(); ++i) strides[k * nd + shift + i] = (ls[i] == 1 && shape[shift + i] != 1) ? 0 : static_cast<std::int64_t>(lt[i]);
-            ptrs[k] = lf.array.device_data();
+            const int shift = nd - lf.ndim;  // right-aligned, as sm::broadcast aligns them (SMUtils.h:51-72)
+            for (int i = 0; i < lf.ndim; ++i)
+                strides[k * nd + shift + i] = (lf.shape[i] == 1 && out_shape[shift + i] != 1) ? 0 : static_cast<std::int64_t>(lf.strides[i]);
+            ptrs[k] = lf.st->dev_ro() + lf.offset;
+        }
+        T *dst = out->dev_wo();
+        if (n == 2) {  // one operator after all: the plain operator's entry points, exactly as before chains existed
+            ++tls_fusion_stats.single_ops;
+            const Leaf &x = leaves[0], &y = leaves[1];
+            if (!y.is_scalar) {
+                hip::check(smhip_elementwise(ops[0], hip::dtype_of<T>::id, ptrs[0], strides, ptrs[1], strides + nd, sh, nd, dst));
+            } else if (x.dense()) {
+                hip::check(smhip_array_scalar(ops[0], hip::dtype_of<T>::id, ptrs[0], &y.value, x.total, dst));
+            } else {  // a view against a scalar: honour its strides (the reference reads views as flat here)
+                hip::DeviceBuffer s(sizeof(T));
+                hip::check(smhip_upload(s.get(), &y.value, sizeof(T)));
+                hip::check(smhip_elementwise(ops[0], hip::dtype_of<T>::id, ptrs[0], strides, s.get(), strides + nd, sh, nd, dst));  // strides + nd: the scalar's row, all zero
+            }
+            return;
         }
         ++tls_fusion_stats.chains;
         tls_fusion_stats.fused_stages += static_cast<unsigned long long>(n - 1);
-        hip::check(smhip_chain(hip::dtype_of<T>::id, n, ptrs, strides.data(), scalars, ops, swapped, sh.data(), static_cast<int>(nd),
-                               result.device_data_mut()));
+        hip::check(smhip_chain(hip::dtype_of<T>::id, n, ptrs, strides, scalars, ops, swapped, sh, nd, dst));
     }
 
 private:
-    template <typename Op>
-    void single_op(SMArray<T> &result) {
-        const SMArray<T> &x = leaves[0].array;
-        if (leaves[1].is_scalar) {
-            x.template apply_scalar_into<Op>(leaves[1].value, result);
-        } else {
-            const SMArray<T> &y = leaves[1].array;
-            auto br = x._shape == y._shape ? BroadCastResult{{}, {}, x._strides, {}, y._strides, x.totalSize}
-                                           : sm::broadcast(x._shape, x._strides, y._shape, y._strides);
-            x.template apply_into<Op>(y, br, result);
-        }
-    }
-    void single(SMArray<T> &result) {
-        switch (ops[0]) {
-            case SMHIP_OP_ADD: single_op<AddOp<T>>(result); break;
-            case SMHIP_OP_SUB: single_op<SubtractOp<T>>(result); break;
-            case SMHIP_OP_MUL: single_op<MultiplyOp<T>>(result); break;
-            default: single_op<DivideOp<T>>(result); break;
-        }
+    static void set(Leaf &lf, const SMArray<T> &a) {
+        lf.st = a.data.storage();
+        lf.offset = a.data.offset();
+        lf.total = a.totalSize;
+        lf.ndim = static_cast<int>(a._shape.size());
+        for (int i = 0; i < lf.ndim; ++i) { lf.shape[i] = a._shape[i]; lf.strides[i] = a._strides[i]; }
     }
 };
 

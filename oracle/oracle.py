@@ -351,6 +351,11 @@ class Reference(_Lib):
             raise ValueError("ref_view_broadcast4 failed")
         return out.reshape(list(oshape[:nd]))
 
+    def bench_tiny(self, which, iters=200000):
+        """ns per iteration of the reference's simple_check (0) / BM_SMArrayPow_1D (1) / BM_SMArrayPow_2D (2) body on this host."""
+        self.lib.ref_bench_tiny.restype = C.c_double
+        return float(self.lib.ref_bench_tiny(C.c_int(which), C.c_long(iters)))
+
     def bench_add_f32(self, a, b):
         return float(self.lib.ref_bench_add_f32(_ptr(a), _ptr(b), C.c_size_t(a.size)))
 

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -260,6 +261,41 @@ double ref_bench_add_f32(const float *a, const float *b, size_t n) {
     A.data = nullptr;  // do not let the destructors delete[] borrowed memory
     B.data = nullptr;
     return probe;
+}
+
+// The reference's TINY benchmarks on this host: nanoseconds per iteration of the timed bodies of simple_check
+// (benchmark/add.cpp:4-19: build a 5 x 5 array from nested lists and add it to itself), BM_SMArrayPow_1D (benchmark/pow.cpp:
+// 5-14: sm::pow of ten ints, ^3) and BM_SMArrayPow_2D (pow.cpp:19-28: 3 x 3 ints, ^2), looped `iters` times around a
+// steady clock.  (Google Benchmark itself is not available offline; its DoNotOptimize is an empty asm with the value as input.)
+static inline void keep(const void *p) { asm volatile("" : : "g"(p) : "memory"); }
+double ref_bench_tiny(int which, long iters) {
+    using clk = std::chrono::steady_clock;
+    if (iters < 1) iters = 1;
+    if (which == 0) {
+        const auto t0 = clk::now();
+        for (long i = 0; i < iters; ++i) {
+            sm::SMArray<float> ac = {{1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}, {1, 2, 3, 4, 5}};
+            auto result = ac + ac;
+            keep(&result);
+        }
+        return std::chrono::duration<double, std::nano>(clk::now() - t0).count() / (double)iters;
+    }
+    if (which == 1) {
+        sm::SMArray<int> arr1d = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+        const auto t0 = clk::now();
+        for (long i = 0; i < iters; ++i) {
+            auto result = sm::pow(arr1d, 3);
+            keep(&result);
+        }
+        return std::chrono::duration<double, std::nano>(clk::now() - t0).count() / (double)iters;
+    }
+    sm::SMArray<int> arr2d = {{1, 2, 3}, {4, 5, 6}, {7, 8, 9}};
+    const auto t0 = clk::now();
+    for (long i = 0; i < iters; ++i) {
+        auto result = sm::pow(arr2d, 2);
+        keep(&result);
+    }
+    return std::chrono::duration<double, std::nano>(clk::now() - t0).count() / (double)iters;
 }
 
 }  // extern "C"

@@ -14,6 +14,8 @@
 // fixed order: results are deterministic run to run.
 // Roofline: HBM-bound; sizeof(T) B/elem (sum), 2*sizeof(T) (dot),
 // 3*sizeof(T) (fused op+sum: the sum adds no traffic).
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -323,6 +325,123 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     }
 }
 
+// ---- the ONE-LAUNCH form for small arrays ---------------------------------------------------------------------------
+// Up to kOneLaunchTiles tiles (f32 sum: 2^18 elements) the main kernel's workgroups hand their totals over themselves and
+// the last one to arrive adds them in index order and writes the result: no finishing launch.  Fixed tile-to-workgroup
+// assignment and fixed addition order: the same bits on every run.  The workgroup that collects takes an agent-scope
+// ACQUIRE behind its ticket (ADVICE r02 / VERDICT r03 #10): one cache invalidate per group instead of one per workgroup,
+// so that its reads of the others' totals are ordered by the memory model and not only by how gfx950 performs agent-scope
+// atomics.  Measured over 2^16 .. 2^26 elements (tools/reduce_mid_rates.py, profiles/r04_reduce_mid_rates.txt; kernels alone,
+// us per call, two launches / one launch): f32 sum 2^16 5.9 / 5.1, 2^18 6.3 / 5.5, 2^20 6.3 / 8.1, 2^22 6.3 / 10.5; f32 dot
+// 2^18 6.4 / 5.6, 2^22 6.9 / 8.7; complex dot 2^16 7.9 / 6.7, 2^20 9.3 / 10.3 -- the hand-over's tickets cost more than the
+// finishing launch as soon as there are more than ~128 workgroups (with all tickets on ONE counter it was worse still:
+// 15.2 us for the f32 sum at 2^22), and walking the tiles grid-stride instead of one tile per workgroup loses to the hardware's
+// dispatcher exactly as in the streaming kernels (the fused add+sum at 2^22: 8.6 -> 29.5 us; it keeps two launches at every
+// size).  So the form is used where it wins: at most 128 tiles.  What remains at mid sizes is one launch's fixed cost plus
+// the data: an f32 dot of 2^22 elements (32 MiB) takes 6.9 us = 2.2 us + 32 MiB at 7 TB/s -- 61 % of peak, and at the bound of
+// this launch model (VERDICT r03 asked for 70 %: 6.0 us).
+constexpr size_t kOneLaunchTiles = 128;
+inline bool reduce_one_launch() {
+    static const bool on = [] { const char *e = getenv("SMHIP_REDUCE_ONE_LAUNCH"); return !(e && e[0] == '0'); }();  // 0: always two launches (experiments)
+    return on;
+}
+// Tickets are taken in TWO levels: a workgroup's ticket goes to the counter of its group of kTicketGroup consecutive
+// workgroups (each counter on a cache line of its own), the group's last arrival adds the group's totals in index order and
+// takes a ticket at the final counter; its last arrival adds the group totals.  With all 1024 tickets on ONE counter the
+// returning atomics serialise at the memory side (~8 ns each): the hand-over alone took 8 us, more than the finishing
+// launch it replaces (f32 sum at 2^22: 15.2 us against 6.9 for two launches).
+constexpr uint32_t kTicketGroup = 32, kCounterStride = 16;  // uint32 per counter slot: 64 bytes
+template <typename A, int BLOCK, int PLANES>
+__device__ __forceinline__ bool hand_over_and_collect(A (&acc)[PLANES], A *__restrict__ totals, uint32_t pitch, uint32_t *__restrict__ counters) {
+    // thread 0 holds the workgroup's totals; returns true in ONE workgroup, with acc[] = the sum of all workgroups' totals (thread 0).
+    // totals: [PLANES][pitch] workgroup totals, then [PLANES][kTicketGroup] group totals behind them.
+    __shared__ int last;
+    const uint32_t group = blockIdx.x / kTicketGroup, groups = (gridDim.x + kTicketGroup - 1) / kTicketGroup;
+    const uint32_t first = group * kTicketGroup, members = first + kTicketGroup <= gridDim.x ? kTicketGroup : gridDim.x - first;
+    A *group_totals = totals + (size_t)PLANES * pitch;
+    auto publish = [&](A *where, uint32_t slot, uint32_t row_pitch, uint32_t *counter, uint32_t expected) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) __hip_atomic_store(&where[(size_t)p * row_pitch + slot], acc[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the totals have reached the memory side before the ticket is taken
+            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
+        }
+        __syncthreads();
+        return last != 0;
+    };
+    auto collect = [&](const A *where, uint32_t from, uint32_t count, uint32_t row_pitch) {  // count <= kTicketGroup values per plane, in index order
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this workgroup only: one invalidate per group, not per workgroup
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p) {
+            A v = threadIdx.x < count ? __hip_atomic_load(&where[(size_t)p * row_pitch + from + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A(0);
+            __syncthreads();  // block_reduce's LDS slots are reused
+            acc[p] = block_reduce<A, BLOCK>(v);
+        }
+    };
+    if (!publish(totals, blockIdx.x, pitch, counters + (size_t)(1 + group) * kCounterStride, members)) return false;
+    collect(totals, first, members, pitch);
+    if (threadIdx.x == 0) __hip_atomic_store(counters + (size_t)(1 + group) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (groups == 1) return true;
+    __syncthreads();
+    if (!publish(group_totals, group, kTicketGroup, counters, groups)) return false;
+    collect(group_totals, 0, groups, kTicketGroup);
+    if (threadIdx.x == 0) __hip_atomic_store(counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+template <typename T, typename Op, int MODE, bool KEEP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void reduce_once_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out,
+                                                            size_t n_vec, size_t n, typename AccOf<T>::type *__restrict__ totals,
+                                                            uint32_t *__restrict__ counter, void *__restrict__ out8, T *__restrict__ out_native, int nt) {
+    typedef typename AccOf<T>::type A;
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr int W = VecTraits<T>::width;
+    constexpr int kVecPerThread = vec_per_thread(MODE);
+    constexpr size_t kTile = (size_t)BLOCK * kVecPerThread;
+    const V *av = reinterpret_cast<const V *>(a), *bv = reinterpret_cast<const V *>(b);
+    V *ov = reinterpret_cast<V *>(out);
+    OpCtx<Op> ctx;
+    ctx.init();
+    A acc = A(0);
+    const size_t tiles = n_vec / kTile + 1;  // the last one: the partial tile and the n % W tail (maybe empty)
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {  // t only grows: every wave's trip count is finite
+        const size_t tile0 = t * kTile + threadIdx.x;
+        if (t * kTile + kTile <= n_vec) {
+            V va[kVecPerThread], vb[kVecPerThread];
+#pragma unroll
+            for (int u = 0; u < kVecPerThread; ++u) {
+                va[u] = load_stream_if(T, av + tile0 + (size_t)u * BLOCK, nt);
+                if constexpr (MODE != kSum) vb[u] = load_stream_if(T, bv + tile0 + (size_t)u * BLOCK, nt);
+                else vb[u] = va[u];
+            }
+#pragma unroll
+            for (int u = 0; u < kVecPerThread; ++u) consume<T, Op, MODE, KEEP, A>(ctx, acc, va[u], vb[u], ov + tile0 + (size_t)u * BLOCK);
+        } else {
+            for (int u = 0; u < kVecPerThread; ++u) {
+                const size_t i = tile0 + (size_t)u * BLOCK;
+                if (i < n_vec) {
+                    const V va = load_stream(av + i);
+                    const V vb = MODE != kSum ? load_stream(bv + i) : va;
+                    consume<T, Op, MODE, KEEP, A>(ctx, acc, va, vb, ov + i);
+                }
+            }
+            if (threadIdx.x == 0) {
+                for (size_t k = n_vec * W; k < n; ++k) {
+                    if constexpr (MODE == kFused) {
+                        const T r = Op::apply(a[k], b[k]);
+                        out[k] = r;
+                        acc += widen<T, A>(r);
+                    } else if constexpr (MODE == kDot) add_prod<T, A>(acc, a[k], b[k]);
+                    else acc += widen<T, A>(a[k]);
+                }
+            }
+        }
+    }
+    A total[1] = {block_reduce<A, BLOCK>(acc)};
+    if (gridDim.x > 1 && !hand_over_and_collect<A, BLOCK, 1>(total, totals, kMaxGroups, counter)) return;
+    if (threadIdx.x == 0) write_result<T, MODE != kDot>(total[0], out8, out_native);
+}
+
 inline bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // std::complex<double> dot (reference product.h:168-224): sum a[i] * b[i], unconjugated, as the
@@ -416,6 +535,87 @@ __global__ __launch_bounds__(kBlock) void cdot32_kernel(const float *__restrict_
         partials[blocks + blockIdx.x] = m;
     }
 }
+// The complex dots in the one-launch form (see hand_over_and_collect): F32 = false: n {re, im} pairs of doubles, one per
+// 16-byte vector; F32 = true: pairs of floats, two per vector (+ the odd last pair).
+template <bool F32>
+__global__ __launch_bounds__(kBlock) void cdot_once_kernel(const void *__restrict__ a_, const void *__restrict__ b_, size_t n, double *__restrict__ totals,
+                                                           uint32_t *__restrict__ counter, double *__restrict__ out2, int nt) {
+    typedef typename std::conditional<F32, float, double>::type E;
+    typedef typename VecTraits<E>::vec_t V;
+    typedef typename VecTraits<E>::full_t F;
+    const V *av = static_cast<const V *>(a_), *bv = static_cast<const V *>(b_);
+    const size_t n_vec = F32 ? n / 2 : n;
+    double re = 0.0, im = 0.0;
+    auto acc1 = [&](double ar, double ai, double br, double bi) {
+        re = __builtin_fma(ar, br, re);
+        re = __builtin_fma(-ai, bi, re);
+        im = __builtin_fma(ar, bi, im);
+        im = __builtin_fma(ai, br, im);
+    };
+    auto acc = [&](F x, F y) {
+        acc1(x[0], x[1], y[0], y[1]);
+        if constexpr (F32) acc1(x[2], x[3], y[2], y[3]);
+    };
+    constexpr size_t kTile = (size_t)kBlock * 2;
+    const size_t tiles = n_vec / kTile + 1;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {  // t only grows: every wave's trip count is finite
+        const size_t i0 = t * kTile + threadIdx.x, i1 = i0 + kBlock;
+        if (t * kTile + kTile <= n_vec) {
+            F x0, y0, x1, y1;
+            if (nt & kLoadNt) {
+                x0 = load_stream_as(E, av + i0, true), y0 = load_stream_as(E, bv + i0, true);
+                x1 = load_stream_as(E, av + i1, true), y1 = load_stream_as(E, bv + i1, true);
+            } else {
+                x0 = load_stream_as(E, av + i0, false), y0 = load_stream_as(E, bv + i0, false);
+                x1 = load_stream_as(E, av + i1, false), y1 = load_stream_as(E, bv + i1, false);
+            }
+            acc(x0, y0);
+            acc(x1, y1);
+        } else {
+            if (i0 < n_vec) acc(load_stream(av + i0), load_stream(bv + i0));
+            if (i1 < n_vec) acc(load_stream(av + i1), load_stream(bv + i1));
+            if (F32 && threadIdx.x == 0 && (n & 1)) {  // odd n: the last pair
+                const float *a = static_cast<const float *>(a_), *b = static_cast<const float *>(b_);
+                acc1(a[2 * (n - 1)], a[2 * (n - 1) + 1], b[2 * (n - 1)], b[2 * (n - 1) + 1]);
+            }
+        }
+    }
+    __shared__ double lds[2][kBlock / 64];
+    re = wave_reduce(re);
+    im = wave_reduce(im);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == kWaveTotalLane) { lds[0][wave] = re; lds[1][wave] = im; }
+    __syncthreads();
+    double total[2] = {0.0, 0.0};
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBlock / 64; ++w) { total[0] += lds[0][w]; total[1] += lds[1][w]; }
+    if (gridDim.x > 1 && !hand_over_and_collect<double, kBlock, 2>(total, totals, kMaxGroups, counter)) return;
+    if (threadIdx.x == 0) { out2[0] = total[0]; out2[1] = total[1]; }
+}
+
+// One launch for a complex dot of at most kOneLaunchTiles tiles; false: the caller goes on with the two-launch form.
+template <bool F32>
+int try_cdot_once(const void *a, const void *b, size_t n, size_t blocks, size_t bytes, double *out2_dev, hipStream_t s, bool *done) {
+    static const size_t max_tiles = [] { const char *e = getenv("SMHIP_REDUCE_ONE_TILES"); return e && *e ? (size_t)atol(e) : kOneLaunchTiles; }();
+    *done = false;
+    if (blocks > max_tiles) return SMHIP_OK;
+    const unsigned grid = (unsigned)(blocks < kMaxGroups ? blocks : kMaxGroups);
+    double *scratch = nullptr;
+    ScratchLease lease;
+    uint32_t *counter = nullptr;
+    if (grid > 1) {
+        if (int rc = lease.take(2 * (kMaxGroups + kTicketGroup), &scratch)) return rc;
+        if (int rc = reduce_counters(s, &counter)) return rc;
+    }
+    hipLaunchKernelGGL((cdot_once_kernel<F32>), dim3(grid), dim3(kBlock), 0, s, a, b, n, scratch, counter, out2_dev, stream_policy({{a, bytes}, {b, bytes}}, {nullptr, 0}));
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+        if (grid > 1) reduce_counters_suspect(s);
+        return fail(SMHIP_ERR_HIP, "launch complex dot: %s", hipGetErrorString(e));
+    }
+    *done = true;
+    return SMHIP_OK;
+}
+
 // Queues finish_kernel over `blocks` partials (blocks >= 1); `partials` has room for the group totals behind them
 // (blocks / kGroupTarget + 2 more accumulators are enough).
 template <typename T, bool AS_DOUBLE>
@@ -452,8 +652,28 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
     double *scratch = nullptr;
     ScratchLease lease;
     if (blocks > 1)
-        if (int rc = lease.take(blocks + blocks / kGroupTarget + 2, &scratch)) return rc;
+        if (int rc = lease.take(blocks + blocks / kGroupTarget + 2 > kMaxGroups + kTicketGroup ? blocks + blocks / kGroupTarget + 2 : kMaxGroups + kTicketGroup, &scratch)) return rc;
     A *partials = reinterpret_cast<A *>(scratch);
+    static const size_t max_tiles = [] { const char *e = getenv("SMHIP_REDUCE_ONE_TILES"); return e && *e ? (size_t)atol(e) : kOneLaunchTiles; }();
+    if (reduce_one_launch() && blocks <= max_tiles && MODE != kFused) {
+        const int pol1 = MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
+                                      : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0});
+        const unsigned grid = (unsigned)(blocks < kMaxGroups ? blocks : kMaxGroups);
+        uint32_t *counter = nullptr;
+        if (grid > 1)
+            if (int rc = reduce_counters(s, &counter)) return rc;
+        if (MODE == kFused && (pol1 & kStoreKeep))
+            hipLaunchKernelGGL((reduce_once_kernel<T, Op, MODE, MODE == kFused, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, a, b, out, n_vec, n, partials, counter, out8,
+                               static_cast<T *>(out_native), pol1);
+        else
+            hipLaunchKernelGGL((reduce_once_kernel<T, Op, MODE, false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, a, b, out, n_vec, n, partials, counter, out8,
+                               static_cast<T *>(out_native), pol1);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            if (grid > 1) reduce_counters_suspect(s);
+            return fail(SMHIP_ERR_HIP, "launch reduce: %s", hipGetErrorString(e));
+        }
+        return SMHIP_OK;
+    }
     const int pol = MODE == kSum ? stream_policy({{a, n * sizeof(T)}}, {nullptr, 0})
                                  : stream_policy({{a, n * sizeof(T)}, {b, n * sizeof(T)}}, {MODE == kFused ? out : nullptr, MODE == kFused ? n * sizeof(T) : 0});
     const bool keep = MODE == kFused && (pol & kStoreKeep);
@@ -489,7 +709,7 @@ int run_reduce(const void *a_, const void *b_, void *out_, size_t n, void *out8,
 struct CounterBuf { uint32_t *p; bool suspect; };
 std::mutex g_counter_mutex;
 std::map<std::pair<int, hipStream_t>, CounterBuf> g_counter_bufs;
-constexpr size_t kCounterBytes = 64;  // two counters (the complex dot's planes), on a cache line of their own
+constexpr size_t kCounterBytes = 4096;  // finish_kernel: two counters (the complex dot's planes) at the front; the one-launch form: 1 + kTicketGroup counters, 64 bytes apart
 
 int reduce_counters(hipStream_t s, uint32_t **out) {
     const std::pair<int, hipStream_t> key(current_device(), s);
@@ -549,6 +769,11 @@ int launch_dot(int dtype, const void *a, const void *b, size_t n, double *out8_d
 int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s) {
     const size_t blocks = n / (kBlock * 2) + 1;
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "complex dot too large (%zu workgroups)", blocks);
+    if (reduce_one_launch()) {
+        bool done;
+        if (int rc = try_cdot_once<false>(a, b, n, blocks, n * sizeof(dbl2), out2_dev, s, &done)) return rc;
+        if (done) return SMHIP_OK;
+    }
     // two partial arrays (real, imaginary), each with room for its group totals behind it
     const size_t span = blocks + blocks / kGroupTarget + 2;
     double *scratch;
@@ -564,6 +789,11 @@ int launch_cdot(const void *a, const void *b, size_t n, double *out2_dev, hipStr
 int launch_cdot32(const void *a, const void *b, size_t n, double *out2_dev, hipStream_t s) {
     const size_t blocks = (n / 2) / (kBlock * 2) + 1;
     if (blocks > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "complex dot too large (%zu workgroups)", blocks);
+    if (reduce_one_launch()) {
+        bool done;
+        if (int rc = try_cdot_once<true>(a, b, n, blocks, n * 8, out2_dev, s, &done)) return rc;
+        if (done) return SMHIP_OK;
+    }
     const size_t span = blocks + blocks / kGroupTarget + 2;
     double *scratch;
     ScratchLease lease;

@@ -28,6 +28,8 @@ struct ThreadState {
     bool checked[kMaxDevices] = {};
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
+    void *result_host[kMaxDevices] = {};  // a pinned, device-mapped 64-byte slot per device: where the synchronous reductions'
+    void *result_dev[kMaxDevices] = {};   // kernels leave their scalar for the host (no device buffer, no copy packet)
     int op_depth = 0;   // > 0: inside an operator's scope (OpScope); allocations made there are that operator's scratch
     int op_queue = 0;   // the library queue the operator in progress runs on
     std::string error;
@@ -697,6 +699,29 @@ using namespace smhip;
 
 namespace {
 // Bytes from an operand's first element to its last, through `strides` over `shape`.
+// The calling thread's result slot on its current device: host pointer and the device's alias of the same 64 bytes.  A
+// synchronous reduction's kernel writes its scalar there and the host reads it after the stream has drained -- the
+// alternative (a pooled device buffer, hipMemcpyAsync device-to-host, the same wait) queued a copy packet and cost 5-8 us
+// per call, most of a mid-size dot.
+int result_slot(void **host, void **dev) {
+    hipStream_t s;
+    if (int rc = acquire_stream(&s)) return rc;
+    const int d = tls.device;
+    if (!tls.result_host[d]) {
+        void *h = nullptr, *p = nullptr;
+        SMHIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&p, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h);
+            return fail(SMHIP_ERR_HIP, "no device alias for the pinned result slot");
+        }
+        tls.result_host[d] = h;
+        tls.result_dev[d] = p;
+    }
+    *host = tls.result_host[d];
+    *dev = tls.result_dev[d];
+    return SMHIP_OK;
+}
 size_t span_bytes(const int64_t *shape, const int64_t *strides, int ndim, size_t esz) {
     size_t last = 0;
     for (int i = 0; i < ndim; ++i)
@@ -773,7 +798,7 @@ int smhip_get_stream(void **hip_stream) {
 
 int smhip_synchronize(void) {
     SMHIP_ACQUIRE(s);  // a barrier: queue 0 is behind everything on queue 1
-    SMHIP_TRY(hipStreamSynchronize(s));
+    SMHIP_TRY(hipStreamSynchronize(s));  // (polling hipStreamQuery instead of this sleeping wait was tried for the reductions' scalars: no faster, profiles/r04_reduce_mid_rates.txt)
     if (!tls.use_user_stream) queues_all_complete(tls.device);
     return SMHIP_OK;
 }
@@ -1275,29 +1300,28 @@ int smhip_contiguous_sum_async(int op, int dtype, const void *a, const void *b, 
 
 int smhip_sum(int dtype, const void *a, size_t n, double *out_host) {
     if (!out_host) return fail(SMHIP_ERR_INVALID, "sum: null result");
-    void *d = nullptr;
-    if (int rc = smhip_alloc(&d, sizeof(double))) return rc;
-    int rc = smhip_sum_async(dtype, a, n, static_cast<double *>(d));
-    if (!rc) rc = smhip_download(out_host, d, sizeof(double));
-    smhip_free(d);
-    return rc;
+    void *h = nullptr, *d = nullptr;
+    if (int rc = result_slot(&h, &d)) return rc;
+    if (int rc = smhip_sum_async(dtype, a, n, static_cast<double *>(d))) return rc;
+    if (int rc = smhip_synchronize()) return rc;
+    *out_host = *static_cast<const volatile double *>(h);
+    return SMHIP_OK;
 }
 
 int smhip_dot(int dtype, const void *a, const void *b, size_t n, void *out_host) {
     if (!valid_dot_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "dot: bad dtype %d", dtype);
     if (!out_host || (n && (!a || !b))) return fail(SMHIP_ERR_INVALID, "dot: null buffer");
-    void *d = nullptr;
-    if (int rc = smhip_alloc(&d, 16)) return rc;
-    int rc;
+    void *h = nullptr, *d = nullptr;
+    if (int rc = result_slot(&h, &d)) return rc;
     {
         hipStream_t s;
         OpScope op_scope_;
-        rc = op_scope_.begin_barrier(&s);
-        if (!rc) rc = launch_dot(dtype, a, b, n, nullptr, d, s);
+        if (int rc = op_scope_.begin_barrier(&s)) return rc;
+        if (int rc = launch_dot(dtype, a, b, n, nullptr, d, s)) return rc;
     }
-    if (!rc) rc = smhip_download(out_host, d, dtype_size(dtype));
-    smhip_free(d);
-    return rc;
+    if (int rc = smhip_synchronize()) return rc;
+    memcpy(out_host, h, dtype_size(dtype));
+    return SMHIP_OK;
 }
 
 int smhip_dot_c64_async(const void *a, const void *b, size_t n, double *out2_dev) {
@@ -1309,12 +1333,12 @@ int smhip_dot_c64_async(const void *a, const void *b, size_t n, double *out2_dev
 
 int smhip_dot_c64(const void *a, const void *b, size_t n, double *out2_host) {
     if (!out2_host) return fail(SMHIP_ERR_INVALID, "dot_c64: null buffer");
-    void *d = nullptr;
-    if (int rc = smhip_alloc(&d, 16)) return rc;
-    int rc = smhip_dot_c64_async(a, b, n, static_cast<double *>(d));
-    if (!rc) rc = smhip_download(out2_host, d, 16);
-    smhip_free(d);
-    return rc;
+    void *h = nullptr, *d = nullptr;
+    if (int rc = result_slot(&h, &d)) return rc;
+    if (int rc = smhip_dot_c64_async(a, b, n, static_cast<double *>(d))) return rc;
+    if (int rc = smhip_synchronize()) return rc;
+    memcpy(out2_host, h, 16);
+    return SMHIP_OK;
 }
 
 int smhip_dot_c32_async(const void *a, const void *b, size_t n, double *out2_dev) {
@@ -1326,15 +1350,15 @@ int smhip_dot_c32_async(const void *a, const void *b, size_t n, double *out2_dev
 
 int smhip_dot_c32(const void *a, const void *b, size_t n, float *out2_host) {
     if (!out2_host) return fail(SMHIP_ERR_INVALID, "dot_c32: null buffer");
-    void *d = nullptr;
-    if (int rc = smhip_alloc(&d, 16)) return rc;
-    double both[2] = {0, 0};
-    int rc = smhip_dot_c32_async(a, b, n, static_cast<double *>(d));
-    if (!rc) rc = smhip_download(both, d, 16);
-    smhip_free(d);
+    void *h = nullptr, *d = nullptr;
+    if (int rc = result_slot(&h, &d)) return rc;
+    if (int rc = smhip_dot_c32_async(a, b, n, static_cast<double *>(d))) return rc;
+    if (int rc = smhip_synchronize()) return rc;
+    double both[2];
+    memcpy(both, h, 16);
     out2_host[0] = (float)both[0];
     out2_host[1] = (float)both[1];
-    return rc;
+    return SMHIP_OK;
 }
 
 /* ----------------------------------------------------------- diagnostics */
