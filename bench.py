@@ -17,6 +17,8 @@ N GPUs   each GPU owns one outer-dimension shard of 2^28 elements of the N * 2^2
          process is one of the ranks.  torch.distributed (backend nccl = RCCL) provides the barrier and the
          max-over-ranks of the timings only.
          --mode single: one process, one host thread, N devices through libsmhip's device group.
+         --mode single also runs config 3 over the group ("c5"."c3_sharded": 4096 rows per GPU, the row replicated device to device
+         by smhip_copy_peer, smhip_sharded_elementwise -- the replicated-operand path and a real peer copy).
          Config 5's exchange step (fused add + sum per shard, then ONE ncclAllReduce of an fp64 scalar over xGMI, issued
          by libsmhip itself: smhip_allreduce_sum_async / smhip_sharded_contiguous_sum) is timed after the headline
          region and reported under "c5" (operands: config 5's seeds 6/7 in [0,1)).
@@ -1015,6 +1017,59 @@ def run_single(args):
           "allreduce": "smhip_sharded_contiguous_sum -> ncclGroupStart / ncclAllReduce x devices / ncclGroupEnd (RCCL), scalar read back each step",
           "ms_per_step": tc * 1e3, "value": G * n / tc / 1e9, "unit": "Gelem/s", "global_sum": total.value,
           "expected_sum_approx": float(G) * n}
+
+    # config 3 over the group: the result's outermost dimension cut into G blocks of 4096 rows (weak: 4096 x 4096 per GPU), the
+    # (1 x 4096) row -- broadcast along that dimension -- REPLICATED to every GPU device to device (smhip_copy_peer), then
+    # smhip_sharded_elementwise: G independent launches, no collective
+    del a5, b5, c5o
+    rows = cols = 4096
+    lib.set_device(0)
+    row0 = lib.uniform_f32(cols, 4, -1.0, 1.0)
+    A3, R3, O3 = [], [], []
+    for g in range(G):
+        lib.set_device(g)
+        A3.append(lib.uniform_f32(rows * cols, 3, -1.0, 1.0, first=g * rows * cols))
+        R3.append(row0 if g == 0 else lib.empty((cols,), F32))
+        O3.append(lib.empty((rows * cols,), F32))
+    lib.set_device(0)
+    for g in range(1, G):
+        lib.copy_peer(R3[g].ptr, g, row0.ptr, 0, 4 * cols)
+    lib.sharded_synchronize()
+    i64 = lambda seq: (C.c_int64 * len(seq))(*seq)
+    pa3, pr3, po3 = pt(A3), pt(R3), pt(O3)
+    sa3, sb3, sh3 = i64([cols, 1]), i64([0, 1]), i64([rows * G, cols])
+
+    def c3_step():
+        rc = lib.c.smhip_sharded_elementwise(C.c_int(sma.OP_MUL), C.c_int(sma.F32), pa3, sa3, pr3, sb3, sh3, C.c_int(2), po3)
+        if rc < 0:
+            raise sma.SmhipError(rc, lib.c.smhip_last_error().decode())
+
+    for _ in range(5):
+        c3_step()
+    lib.sharded_synchronize()
+    t3 = time.perf_counter()
+    reps3 = 100
+    for _ in range(reps3):
+        c3_step()
+    lib.sharded_synchronize()
+    t3 = (time.perf_counter() - t3) / reps3
+    # every block against the same multiply done by the single-device entry point on its own GPU (the replica must hold the row)
+    block_ok = []
+    for g in range(G):
+        lib.set_device(g)
+        want = lib.empty((rows * cols,), F32)
+        lib.c.smhip_elementwise(C.c_int(sma.OP_MUL), C.c_int(sma.F32), C.c_void_p(A3[g].ptr), sa3, C.c_void_p(R3[g].ptr), sb3, i64([rows, cols]), C.c_int(2),
+                                C.c_void_p(want.ptr))
+        d = lib.empty((rows * cols,), F32)
+        lib.contiguous(sma.OP_SUB, O3[g], want, out=d)
+        block_ok.append(lib.sum(d) == 0.0 and lib.dot(d, d) == 0.0)
+        del want, d
+    lib.set_device(0)
+    c3_bytes = 4 * (2 * rows * cols + cols)
+    c5["c3_sharded"] = {"workload": f"({rows * G} x {cols}) * (1 x {cols}) float32 over {G} GPU(s): blocks of {rows} rows, the row replicated by smhip_copy_peer",
+                        "entry": "smhip_sharded_elementwise (no collective)", "ms_per_step": t3 * 1e3, "value": G * rows * cols / t3 / 1e9, "unit": "Gelem/s",
+                        "per_gpu_frac_of_8TBps": c3_bytes / t3 / 1e9 / HBM_PEAK_GBS, "peer_copies": G - 1, "blocks_match_single_device_result": all(block_ok),
+                        "note": "host clock over 100 steps of G launches each (replayed operands: cache-fed, like configs.c3.replay)"}
 
     info = [lib.group_info(g) for g in range(G)]
     extra = {"rccl": {"nranks": info[0][0], "version": lib.rccl_version(), "communicators": [{"rank": r, "device": d, "nranks": nr} for nr, r, d in info],
