@@ -575,7 +575,8 @@ struct TileParams {
     int64_t a_r[SMHIP_MAX_NDIM - 2], b_r[SMHIP_MAX_NDIM - 2], o_r[SMHIP_MAX_NDIM - 2];
     uint32_t tiles_p, tiles_q;
     uint32_t nt;                // streamed reads carry the non-temporal hint (the launch reads more than the Infinity Cache holds)
-    uint32_t order;             // walk of the patches: 1 diagonal, 0 row-major (q fastest, p unshifted)
+    uint32_t order;             // walk of the patches: 1 diagonal, 0 row-major (q fastest, p unshifted), 2 row-major in eight runs, one per XCD
+    uint32_t total;             // order 2: patches in all (the grid is rounded up to a multiple of eight)
     uint32_t in_place;          // the output overlaps an operand: no patch may compute an element twice (see the pull-back below)
 };
 
@@ -602,9 +603,20 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     __shared__ T tile[kTileP * PITCH];
     const int mode_a = VEC ? MA : p.mode_a, mode_b = VEC ? MB : p.mode_b;
     const bool both = mode_a == 1 && mode_b == 1;
+    uint32_t bid = blockIdx.x;
+    if (p.order == 2) {
+        // Rows that do not start on 128-byte lines: the patches on either side of a seam share the lines there -- of the direct
+        // operand AND of the output, whose halves then leave as two partial writes.  Workgroups are dealt to the eight XCDs in
+        // turn, so neighbouring patches of the row-major walk land on DIFFERENT L2s, each of which fetches (and writes back) its
+        // own copy of the shared line: at 12287 x 12287 the launch fetches 1.18 x the bytes of 12288 x 12288 and 5.9 % of its write
+        // requests are partial (profiles/r04_pmc_tile_odd.txt).  Here XCD x walks the x-th eighth of the patch sequence, so
+        // that neighbours along q -- and along p, 48 patches further on -- meet in ONE L2, back to back.
+        const uint32_t per = gridDim.x >> 3;
+        bid = (bid & 7u) * per + (bid >> 3);
+        if (bid >= p.total) return;
+    }
     OpCtx<Op> ctx;
     ctx.init();
-    uint32_t bid = blockIdx.x;
     // Consecutive workgroups walk q (walking p instead was 15-25 % slower with one turned operand, r01, and 35 % slower
     // with two, r02: 139 -> 188 us) -- along a DIAGONAL: workgroup (tp, tq) takes patch ((tp + tq) mod tiles_p, tq), so
     // the workgroups in flight together read different column offsets of the turned operand(s) as well as different rows,

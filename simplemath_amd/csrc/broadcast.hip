@@ -310,10 +310,18 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                 // output rows that do not start on 128-byte lines (an inner extent like 8190): neighbouring patches share the
                 // lines at their seams, and the row-major walk runs them back to back (8190 x 8190: 61 -> 77 %, cold 48 -> 61 %)
                 const bool ragged_rows = ((size_t)inner * (size_t)esz) % 128 != 0;
-                t.order = forced_order >= 0 ? (forced_order != 0) : (qb == kTileQBytesWide || ragged_rows) ? 0 : 1;  // SMHIP_TILE_ORDER: for tools/tile_variants.sh
+                // (order 2 -- the row-major walk in eight runs, one per XCD, so that the patches on either side of a seam meet in one
+                // L2 -- was measured for ragged rows and NOT adopted: 8191^2 75.7 -> 77.7 %, but 12287^2 60.3 -> 56.3 % and 16383^2
+                // 60 -> 57.6 %; SMHIP_TILE_ORDER=2 selects it; profiles/r04_pmc_tile_odd.txt)
+                t.order = forced_order >= 0 ? (uint32_t)forced_order : (qb == kTileQBytesWide || ragged_rows) ? 0 : 1;  // SMHIP_TILE_ORDER: for tools/tile_variants.sh
                 L->ma = L->vec ? t.mode_a : 0;
                 L->mb = L->vec ? t.mode_b : 0;
                 L->grid = (unsigned)blocks;
+                if (t.order == 2) {  // eight runs of the row-major walk, one per XCD (bcast_kernels.hip.h: tile_body)
+                    t.total = (uint32_t)blocks;
+                    L->grid = (unsigned)((blocks + 7) / 8 * 8);
+                    if (blocks + 8 >= 0x7fffffffull) { t.order = 0; L->grid = (unsigned)blocks; }
+                }
                 return SMHIP_OK;
             }
         }
