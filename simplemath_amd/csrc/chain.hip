@@ -327,18 +327,21 @@ int run_segment(const Problem &pb, const Segment &sg, void *out_, hipStream_t s)
             case kDense:
                 for (int k = 0; k < nd; ++k)
                     if (A.dense[k] == lf->ptr) return k;  // the same array twice (a * a): one stream
+                if (nd >= kMaxDense) return -1;
                 A.dense[nd] = static_cast<const T *>(lf->ptr);
                 reads.push_back({lf->ptr, pb.n * sizeof(T)});
                 return nd++;
             case kRow:
                 for (int k = 0; k < nr; ++k)
                     if (same_leaf(rows[k], lf)) return kSlotRow + k;
+                if (nr >= kMaxRow) return -1;
                 rows[nr] = lf;
                 A.row[nr] = static_cast<const T *>(lf->ptr);
                 return kSlotRow + nr++;
             case kSplat:
                 for (int k = 0; k < ns; ++k)
                     if (same_leaf(spls[k], lf)) return kSlotSplat + k;
+                if (ns >= kMaxSplat) return -1;
                 spls[ns] = lf;
                 A.spl[ns] = static_cast<const T *>(lf->ptr);
                 return kSlotSplat + ns++;
@@ -349,10 +352,14 @@ int run_segment(const Problem &pb, const Segment &sg, void *out_, hipStream_t s)
                 return -1;
         }
     };
-    A.head = (uint32_t)slot_of(sg.leaves[0], -1);
+    const int head_slot = slot_of(sg.leaves[0], -1);
+    if (head_slot < 0) return fail(SMHIP_ERR_INVALID, "chain: segment head has no operand slot");
+    A.head = (uint32_t)head_slot;
     A.n_stages = (uint32_t)sg.ops.size();
     for (size_t k = 0; k < sg.ops.size(); ++k) {
-        A.stage[k] = (uint32_t)sg.ops[k] | (uint32_t)slot_of(sg.leaves[k + 1], (int)k) << 8 | (uint32_t)(sg.swaps[k] ? 1 : 0) << 16;
+        const int slot = slot_of(sg.leaves[k + 1], (int)k);
+        if (slot < 0) return fail(SMHIP_ERR_INVALID, "chain: a segment with more operands than its kernel variant takes (stage %zu)", k);  // the planner's bug, never the GPU's problem
+        A.stage[k] = (uint32_t)sg.ops[k] | (uint32_t)slot << 8 | (uint32_t)(sg.swaps[k] ? 1 : 0) << 16;
     }
     T *out = static_cast<T *>(out_);
     const size_t n_vec = pb.n / W;
@@ -624,6 +631,16 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
             const Leaf *cur;
             if (int rc = emit(nullptr, &cur)) return rc;
             start(cur);
+            if (!fits(x)) {
+                // the head itself holds the slot this operand needs (two different rows, two different columns: `row1 + row2`
+                // at the very start of a chain, where there is nothing to flush): this one operator runs alone
+                const Leaf *res;
+                const Leaf *lx = swapped[k] ? original_of(x) : original_of(cur), *ly = swapped[k] ? original_of(cur) : original_of(x);
+                if (int rc = eager(ops[k], lx, ly, last ? out : nullptr, &res)) return rc;
+                if (last) return SMHIP_OK;
+                start(res);
+                continue;
+            }
         }
         sg.leaves.push_back(x);
         sg.ops.push_back(ops[k]);

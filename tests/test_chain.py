@@ -123,6 +123,21 @@ def test_chain_cut_by_views(smhip, oracle, dt):
     _run(smhip, oracle, (wide, wide[:, 3:3 + n]), [(sma.OP_MUL, row), (sma.OP_ADD, A)], "a column block of a wider array as head")
 
 
+def test_chain_two_rows_or_two_columns_at_the_start(smhip, oracle):
+    """Found by tests/fuzz_chain.py (seed 3, case 37: a GPU memory access fault): a chain whose head and first operand are two
+    DIFFERENT rows (or columns) -- more small operands of one kind than a kernel variant takes, with nothing before them to
+    flush.  That operator runs alone; the chain continues."""
+    rng = np.random.default_rng(16)
+    for dt in (np.float32, np.int64):
+        A = _rand(rng, (257, 32), dt)
+        r1, r2, r3 = (_rand(rng, (1, 32), dt) for _ in range(3))
+        c1, c2 = _rand(rng, (257, 1), dt), _rand(rng, (257, 1), dt)
+        _run(smhip, oracle, r1, [(sma.OP_ADD, r2), (sma.OP_MUL, A), (sma.OP_SUB, r3)], "row + row first")
+        _run(smhip, oracle, c1, [(sma.OP_SUB, c2), (sma.OP_MUL, A), (sma.OP_ADD, c1, True)], "column - column first")
+        _run(smhip, oracle, r1, [(sma.OP_DIV, r2, True), (sma.OP_ADD, r3), (sma.OP_MUL, c1), (sma.OP_SUB, c2)], "rows then columns, no dense operand")
+        _run(smhip, oracle, A, [(sma.OP_MUL, r1), (sma.OP_ADD, r2), (sma.OP_SUB, c1), (sma.OP_DIV, c2), (sma.OP_ADD, r3)], "alternating small operands")
+
+
 def test_chain_long_and_repeated_operands(smhip, oracle):
     """More stages and more distinct operands than one kernel variant takes (4 dense, 1 row, 1 column): cut and continued."""
     rng = np.random.default_rng(14)
@@ -230,3 +245,15 @@ def test_fused_expr_with_broadcast_operands(smhip, oracle, dt):
     # equal dense shapes fall through to the flat kernel
     got = smhip.fused_expr_bcast("a0 * a1 - a0", dA, dB).numpy()
     util.assert_same_bits(got, oracle.binary(orc.SUB, oracle.binary(orc.MUL, A, B), A), "dense")
+
+
+def test_fuzz_chain_smoke(smhip):
+    """A short run of tests/fuzz_chain.py: random chains of 1-12 stages over random operand forms (dense, row, column,
+    periodic, one element, scalar, transposed / stepped / pitched views) and element types, bit for bit against the oracle's
+    operator-by-operator evaluation."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_chain.py"), "150", "17"], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "ok:" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
