@@ -87,6 +87,7 @@ struct FusionStats {
     unsigned long long chains = 0;        // smhip_chain calls: expressions of two or more operators evaluated as one call
     unsigned long long fused_stages = 0;  // operators inside them
     unsigned long long single_ops = 0;    // deferred operators that ended up alone and ran as the plain operator
+    unsigned long long direct_assignments = 0;  // `x = <expression>` evaluated straight into x (no temporary, no copy)
 };
 inline thread_local FusionStats tls_fusion_stats;
 // The end of a full-expression, seen from the destructor of one of its temporaries.
@@ -324,6 +325,23 @@ public:
         if (_shape != other._shape) throw std::runtime_error("Shape mismatch in assignment");
         if (hip::transport_of<T>::id >= 0 && _shape.size() + (hip::transport_of<T>::lanes > 1 ? 1 : 0) <= MAX_NDIM) {
             if (totalSize == 0) return *this;
+            if constexpr (hip::dtype_of<T>::id >= 0) {
+                // `x = (a + b) * c;` -- the right-hand side is this thread's unevaluated temporary: evaluate it INTO x instead of
+                // into a temporary that is then copied (12 instead of 20 bytes per element for `x = a + b`).  x must be a dense
+                // block, and every operand that shares x's storage must be exactly x (same elements, same order: then each
+                // element is read before it is written, by the same lane); anything else takes the copy below.
+                if (detail::Chain<T> *c = other.continuable(); c && is_dense() && c->may_write_into(data.storage().get(), data.offset(), _shape)) {
+                    detail::Storage<T> &mine = *data.storage();
+                    if (mine.device == c->device || !mine.dev) {
+                        mine.device = c->device;
+                        mine.pending = std::move(other.data.storage()->pending);
+                        c->retarget(&mine, _shape, data.offset(), data.offset() != 0 || totalSize != mine.count);
+                        ++detail::tls_fusion_stats.direct_assignments;
+                        mine.ensure();  // runs the chain now: an assignment is evaluated where it stands
+                        return *this;
+                    }
+                }
+            }
             hip::DeviceGuard on(common_device(*this, other));
             std::unique_ptr<SMArray> holder;
             const SMArray *src = &other;
@@ -895,6 +913,8 @@ struct Chain final : PendingBase {
         }
     };
     Storage<T> *out;
+    std::size_t out_offset = 0;  // the result's first element in `out` (assignment into a dense block of an existing array)
+    bool out_partial = false;    // ... which is then only part of that storage: its other elements stay what they are
     int out_ndim = 0;
     std::size_t out_shape[MAX_NDIM] = {};
     int device;
@@ -907,10 +927,27 @@ struct Chain final : PendingBase {
         set(leaves[n_leaves++], head);
     }
     bool full() const { return n_leaves == kMaxLeaves; }
-    void retarget(Storage<T> *o, const std::vector<std::size_t> &sh) {
+    void retarget(Storage<T> *o, const std::vector<std::size_t> &sh, std::size_t offset = 0, bool partial = false) {
         out = o;
+        out_offset = offset;
+        out_partial = partial;
         out_ndim = static_cast<int>(sh.size());
         for (int i = 0; i < out_ndim; ++i) out_shape[i] = sh[i];
+    }
+    // May the chain's result be written straight into the dense block (st, offset, shape)?  Yes if no operand lives in that
+    // storage, or every operand that does IS that block (same offset, same shape, dense): an in-place elementwise update.
+    bool may_write_into(const Storage<T> *st, std::size_t offset, const std::vector<std::size_t> &sh) const {
+        if (static_cast<int>(sh.size()) != out_ndim) return false;
+        for (int i = 0; i < out_ndim; ++i)
+            if (sh[i] != out_shape[i]) return false;
+        for (int k = 0; k < n_leaves; ++k) {
+            const Leaf &lf = leaves[k];
+            if (lf.is_scalar || lf.st.get() != st) continue;
+            if (lf.offset != offset || lf.ndim != out_ndim || !lf.dense()) return false;
+            for (int i = 0; i < out_ndim; ++i)
+                if (lf.shape[i] != out_shape[i]) return false;
+        }
+        return true;
     }
     void push(int op, bool swap, const SMArray<T> &operand) {
         ops[n_leaves - 1] = op;
@@ -942,7 +979,7 @@ struct Chain final : PendingBase {
                 strides[k * nd + shift + i] = (lf.shape[i] == 1 && out_shape[shift + i] != 1) ? 0 : static_cast<std::int64_t>(lf.strides[i]);
             ptrs[k] = lf.st->dev_ro() + lf.offset;
         }
-        T *dst = out->dev_wo();
+        T *dst = (out_partial ? out->dev_rw() : out->dev_wo()) + out_offset;
         if (n == 2) {  // one operator after all: the plain operator's entry points, exactly as before chains existed
             ++tls_fusion_stats.single_ops;
             const Leaf &x = leaves[0], &y = leaves[1];

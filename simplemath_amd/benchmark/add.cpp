@@ -78,6 +78,15 @@ int main() {
             std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s = %.1f %% of 8 TB/s (12 B/elem, %s)", n / rf.ns_per_iter, 12.0 * n / rf.ns_per_iter,
                           12.0 * n / rf.ns_per_iter / 80.0, after.fused_stages - before.fused_stages == 3 * (after.chains - before.chains) ? "1 launch" : "NOT fused");
             print(rf, extra);
+            // ... and ASSIGNED to an existing array: the expression is evaluated straight into C (no temporary, no copy)
+            sm::SMArray<float> Cdst = sm::zeros<float>(rows, cols);
+            auto ra = run("chain_assign_check/" + std::to_string(rows) + "x4096", [&] {
+                Cdst = (A * row + B) * 0.5f;
+                ClobberMemory();
+            }, sync, 200);
+            std::snprintf(extra, sizeof extra, "%.1f Gelem/s  %.0f GB/s = %.1f %% of 8 TB/s (12 B/elem; with a temporary and a copy: 20)", n / ra.ns_per_iter,
+                          12.0 * n / ra.ns_per_iter, 12.0 * n / ra.ns_per_iter / 80.0);
+            print(ra, extra);
         }
     }
     {

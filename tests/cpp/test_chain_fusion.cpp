@@ -199,6 +199,27 @@ static void ordering() {
     CHECK(x(0, 0) == 5.0f && x(7, 15) == 5.0f);
     x(SLICE(0, 2), SLICE_ALL) = (x(SLICE(0, 2), SLICE_ALL) * 2.0f + y(SLICE(0, 2), SLICE_ALL)) * 2.0f;  // 22 in rows 0-1
     CHECK(x(0, 0) == 22.0f && x(1, 15) == 22.0f && x(2, 0) == 5.0f);
+    {   // `x = <expression>` is evaluated straight into x: no temporary, no copy -- also in place (x among the operands, as itself)
+        const auto before = sm::fusion_stats().direct_assignments;
+        auto z = sm::zeros<float>(8, 16);
+        z = (x + y) * 2.0f;                                  // rows 0-1: 46, the others 12
+        CHECK(sm::fusion_stats().direct_assignments == before + 1);
+        CHECK(z(0, 0) == 46.0f && z(5, 3) == 12.0f);
+        z = z * 0.5f + z;                                    // in place, z twice
+        CHECK(sm::fusion_stats().direct_assignments == before + 2);
+        CHECK(z(0, 0) == 69.0f && z(5, 3) == 18.0f);
+        z(SLICE(4, 6), SLICE_ALL) = z(SLICE(4, 6), SLICE_ALL) - y(SLICE(4, 6), SLICE_ALL);   // a dense block inside z
+        CHECK(sm::fusion_stats().direct_assignments == before + 3);
+        CHECK(z(4, 0) == 17.0f && z(5, 15) == 17.0f && z(3, 0) == 18.0f && z(6, 0) == 18.0f);
+        // NOT in place: the right-hand side reads z through another view of the same storage (a broadcast row of z, z transposed)
+        auto q = sm::ones<float>(16, 16);
+        q.data[1] = 3.0f;                                    // q(0, 1) = 3
+        q = q + q(0, SLICE_ALL);                             // row 0 of q added to every row: must use the OLD row 0 throughout
+        CHECK(q(0, 1) == 6.0f && q(5, 1) == 4.0f && q(5, 0) == 2.0f);
+        q = q.transpose() * 2.0f + q;
+        CHECK(q(1, 0) == 2.0f * 6.0f + 2.0f && q(0, 1) == 2.0f * 2.0f + 6.0f && q(5, 1) == 2.0f * 2.0f + 4.0f && q(1, 5) == 2.0f * 4.0f + 2.0f);  // q.T(i, j) = q(j, i), all from the OLD q
+        CHECK(sm::fusion_stats().direct_assignments == before + 3);
+    }
     // a temporary's VIEW is somebody else looking at it: computed, not continued
     auto tv = (x + y).transpose() * 2.0f;
     CHECK(tv.shape() == std::vector<std::size_t>({16, 8}) && tv(0, 0) == 46.0f && tv(0, 2) == 12.0f);
