@@ -186,6 +186,7 @@ def cpu_baseline(wl, log2n):
 
     o = orc.Oracle()
     ref = orc.Reference() if orc.Reference.available() else None
+    o.set_threads(cores)  # (libgomp's own default is the machine's logical CPUs, whatever the cgroup grants: not what any leg below runs with)
     res = {"unit": "Gelem/s", "threads_visible": o.num_threads(), "usable_cores": cores, "core_accounting": core_info}
 
     def med(fn, reps):

@@ -295,16 +295,18 @@ __global__ __launch_bounds__(kBlock) void finish_kernel(const typename AccOf<T>:
     if (threadIdx.x == 0) {
         __hip_atomic_store(&fin.level2[blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // The ticket stays RELAXED.  ADVICE r02 asked for an agent-scope ACQUIRE here; measured, its invalidate costs every
-        // reduction 1.2 us (504.6 -> 505.8 us per fused add+sum step, tools/sweep_fused2.hip), 17 % of this kernel.  What the
-        // acquire would guarantee is already enforced by construction: the level2[] reads below are agent-scope atomic loads
-        // (performed past the per-XCD caches, never served from a stale line), they sit behind the workgroup barrier that
-        // publishes `last` -- no compiler moves a load across s_barrier, and `last` itself is the RETURNED value of this
-        // atomic, so the barrier is not reached before the ticket has been answered by the memory side.
+        // The ticket itself stays RELAXED: an acquire on EVERY workgroup's ticket cost each reduction 1.2 us (504.6 -> 505.8 us
+        // per fused add+sum step, tools/sweep_fused2.hip).  The acquire sits behind `if (!last) return;` below instead: only the
+        // workgroup that goes on to read the others' totals needs it.
         last = __hip_atomic_fetch_add(fin.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last) return;
+    // The LAST workgroup only: an agent-scope acquire behind its ticket, so that its reads of the other workgroups' totals are
+    // ordered by the memory model and not just by how gfx950 performs agent-scope atomics.  One
+    // invalidate per reduction -- on every workgroup's ticket it cost 1.2 us; here it is inside the noise of the step
+    // (profiles/r04_add_sum_kernel_stats.csv against r03's: finish_kernel 4.5 us before and after).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     acc = A(0);
     {
         constexpr uint32_t kShare2 = kMaxGroups / kBlock;  // the group totals: again every load in flight before the first use
