@@ -309,10 +309,26 @@ int launch_variant(int nd, int nr, int ns, const ChainArgs<T> &A, T *out, size_t
     return launch_variant_u<T, 1>(nd, nr, ns, A, out, n_vec, tail, pol, block, s);
 }
 
+// A few items in place: planning a chain allocates nothing (a chain call on a 4 MB array is host-bound: every 100 ns of
+// planning is 3 % of it).
+template <typename X, int CAP>
+struct Few {
+    X item[CAP];
+    int count = 0;
+    void push_back(const X &x) { item[count++] = x; }
+    void clear() { count = 0; }
+    bool empty() const { return count == 0; }
+    size_t size() const { return (size_t)count; }
+    X &operator[](size_t i) { return item[i]; }
+    const X &operator[](size_t i) const { return item[i]; }
+    X *data() { return item; }
+    const X *begin() const { return item; }
+    const X *end() const { return item + count; }
+};
 // One fused segment: r = leaves[0]; r = r op[k] leaves[k + 1] ... -> out (dense, pb.n elements).
 struct Segment {
-    std::vector<const Leaf *> leaves;  // leaves[0] = head
-    std::vector<int> ops, swaps;
+    Few<const Leaf *, kMaxStages + 1> leaves;  // leaves[0] = head
+    Few<int, kMaxStages> ops, swaps;
 };
 
 template <typename T>
@@ -321,7 +337,7 @@ int run_segment(const Problem &pb, const Segment &sg, void *out_, hipStream_t s)
     ChainArgs<T> A{};
     int nd = 0, nr = 0, ns = 0;
     const Leaf *rows[kMaxRow] = {}, *spls[kMaxSplat] = {};
-    std::vector<Span> reads;
+    Few<Span, kMaxDense> reads;
     auto slot_of = [&](const Leaf *lf, int stage) -> int {
         switch (lf->kind) {
             case kDense:
@@ -411,9 +427,11 @@ int run_segment_dtype(const Problem &pb, const Segment &sg, void *out, hipStream
 // Pooled temporaries of one smhip_chain call; handed back when the call returns (the pool orders their reuse after the
 // launches queued here).
 struct Temps {
-    std::vector<void *> all;
+    static constexpr int kCap = 4 * SMHIP_CHAIN_MAX_OPERANDS + 8;  // per operand at most a written-out period, two temporaries of a cut and a scalar slot
+    Few<void *, kCap> all;
     ~Temps() { for (void *p : all) smhip_free(p); }
     int take(size_t bytes, void **p) {
+        if (all.count == kCap) return fail(SMHIP_ERR_UNSUPPORTED, "chain: too many temporaries");
         if (int rc = smhip_alloc(p, bytes ? bytes : 1)) return rc;
         all.push_back(*p);
         return SMHIP_OK;
@@ -510,7 +528,7 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
     make_problem(dtype, shape, ndim, &pb);
     if (pb.n == 0) return SMHIP_OK;
     Temps temps;
-    std::vector<Leaf> leaves((size_t)n_operands);
+    Leaf leaves[SMHIP_CHAIN_MAX_OPERANDS];
     for (int k = 0; k < n_operands; ++k) {
         Leaf &lf = leaves[k];
         if (!operands[k]) {
@@ -528,8 +546,8 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
     int n_temp = 0;
     Segment sg;
     int nd = 0, nr = 0, ns = 0;
-    std::vector<const void *> dense_seen;
-    std::vector<const Leaf *> row_seen, spl_seen;
+    Few<const void *, kMaxDense + 1> dense_seen;
+    Few<const Leaf *, kMaxRow + 1> row_seen, spl_seen;
     auto reset_counts = [&] { nd = nr = ns = 0; dense_seen.clear(); row_seen.clear(); spl_seen.clear(); };
     auto fits = [&](const Leaf *lf) {  // would this leaf still find a slot?
         switch (lf->kind) {
@@ -602,13 +620,13 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
     };
     const int n_stages = n_operands - 1;
     // leaves whose period was written out keep their ORIGINAL pointer / strides for operators that run alone
-    std::vector<Leaf> originals(leaves.size());
+    Leaf originals[SMHIP_CHAIN_MAX_OPERANDS];
     for (int k = 0; k < n_operands; ++k) {
         originals[k] = leaves[k];
         if (operands[k]) { originals[k].ptr = operands[k]; originals[k].strides = strides + (size_t)k * ndim; }
     }
     auto original_of = [&](const Leaf *lf) -> const Leaf * {
-        if (lf >= leaves.data() && lf < leaves.data() + leaves.size()) return &originals[lf - leaves.data()];
+        if (lf >= leaves && lf < leaves + n_operands) return &originals[lf - leaves];
         return lf;
     };
     start(head);
