@@ -605,8 +605,11 @@ _lib = None
 
 
 def load(path: str = LIB_PATH) -> Smhip:
-    """The loaded library (cached).  Raises if libsmhip.so has not been built."""
+    """The loaded library (cached).  Raises if libsmhip.so has not been built.  SMHIP_LIBRARY=<path> substitutes an
+    experimental build (tools/build_variant.sh) for the default one."""
     global _lib
+    if path == LIB_PATH and os.environ.get("SMHIP_LIBRARY"):
+        path = os.environ["SMHIP_LIBRARY"]
     if _lib is None or _lib.path != path:
         _lib = Smhip(path)
     return _lib

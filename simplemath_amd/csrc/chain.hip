@@ -26,7 +26,8 @@
 // Kernel.  The Ops and the operand of each stage are RUN-TIME, wave-uniform codes in the argument block (a scalar branch per
 // stage); what is compiled per variant is the load structure -- how many dense streams, rows and splats -- so that every
 // load of a lane is issued before the first use, in one basic block, like the contiguous kernels.  One vector per lane,
-// no loop over the data; 19 variants per element type instead of 4^k Op combinations times the operand forms.
+// no loop over the data; 44 variants per element type (0-4 dense streams, 0-2 rows, 0-2 splats -- `(x - mean) / std` with
+// per-row or per-channel statistics is two splats) instead of 4^k Op combinations times the operand forms.
 // Roofline: HBM; algorithmic bytes = sizeof(T) * (dense leaves + 1) per element + the small operands once.
 #include <stdlib.h>
 #include <string.h>
@@ -42,7 +43,7 @@ namespace {
 
 using namespace dev;
 
-constexpr int kMaxDense = 4, kMaxRow = 1, kMaxSplat = 1, kMaxStages = 8;
+constexpr int kMaxDense = 4, kMaxRow = 2, kMaxSplat = 2, kMaxStages = 8;
 constexpr int kSlotRow = kMaxDense, kSlotSplat = kMaxDense + kMaxRow, kSlotScalar = kMaxDense + kMaxRow + kMaxSplat;
 
 template <typename T>
@@ -135,17 +136,20 @@ __device__ __forceinline__ typename VecTraits<T>::full_t chain_eval(const ChainA
                                                                     const typename VecTraits<T>::full_t (&r)[NR > 0 ? NR : 1],
                                                                     const typename VecTraits<T>::full_t (&s)[NS > 0 ? NS : 1]) {
     typedef typename VecTraits<T>::full_t F;
+    // Which operand a stage takes is wave-uniform, so it is a scalar BRANCH to one register copy, not a chain of selects over
+    // every operand the variant holds: at 1 KiB per wave the instruction stream is a visible part of the kernel (four
+    // v_cndmask per held operand and stage; the empty asm keeps the compiler from turning the branches back into selects).
     auto pick = [&](uint32_t slot, T sc) {
         F x = splat_of<T>(sc);
 #pragma unroll
         for (int k = 0; k < ND; ++k)
-            if (slot == (uint32_t)k) x = d[k];
+            if (slot == (uint32_t)k) { x = d[k]; asm volatile("" : "+v"(x)); }
 #pragma unroll
         for (int k = 0; k < NR; ++k)
-            if (slot == (uint32_t)(kSlotRow + k)) x = r[k];
+            if (slot == (uint32_t)(kSlotRow + k)) { x = r[k]; asm volatile("" : "+v"(x)); }
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            if (slot == (uint32_t)(kSlotSplat + k)) x = s[k];
+            if (slot == (uint32_t)(kSlotSplat + k)) { x = s[k]; asm volatile("" : "+v"(x)); }
         return x;
     };
     F acc = pick(A.head, T{});
@@ -281,15 +285,19 @@ int launch_variant_u(int nd, int nr, int ns, const ChainArgs<T> &A, T *out, size
     if (tiles > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "chain: array too large for one launch");
     const dim3 grid((unsigned)tiles), blk(block);
 #define SMHIP_CHAIN_CASE(ND, NR, NS) \
-    case (ND) * 4 + (NR) * 2 + (NS): hipLaunchKernelGGL((chain_kernel<T, ND, NR, NS, U>), grid, blk, 0, s, A, out, n_vec, tail, pol); break;
-    switch (nd * 4 + nr * 2 + ns) {
-        SMHIP_CHAIN_CASE(0, 0, 1) SMHIP_CHAIN_CASE(0, 1, 0) SMHIP_CHAIN_CASE(0, 1, 1)
-        SMHIP_CHAIN_CASE(1, 0, 0) SMHIP_CHAIN_CASE(1, 0, 1) SMHIP_CHAIN_CASE(1, 1, 0) SMHIP_CHAIN_CASE(1, 1, 1)
-        SMHIP_CHAIN_CASE(2, 0, 0) SMHIP_CHAIN_CASE(2, 0, 1) SMHIP_CHAIN_CASE(2, 1, 0) SMHIP_CHAIN_CASE(2, 1, 1)
-        SMHIP_CHAIN_CASE(3, 0, 0) SMHIP_CHAIN_CASE(3, 0, 1) SMHIP_CHAIN_CASE(3, 1, 0) SMHIP_CHAIN_CASE(3, 1, 1)
-        SMHIP_CHAIN_CASE(4, 0, 0) SMHIP_CHAIN_CASE(4, 0, 1) SMHIP_CHAIN_CASE(4, 1, 0) SMHIP_CHAIN_CASE(4, 1, 1)
+    case (ND) * 9 + (NR) * 3 + (NS): hipLaunchKernelGGL((chain_kernel<T, ND, NR, NS, U>), grid, blk, 0, s, A, out, n_vec, tail, pol); break;
+#define SMHIP_CHAIN_SMALL(ND) \
+    SMHIP_CHAIN_CASE(ND, 0, 1) SMHIP_CHAIN_CASE(ND, 0, 2) SMHIP_CHAIN_CASE(ND, 1, 0) SMHIP_CHAIN_CASE(ND, 1, 1) SMHIP_CHAIN_CASE(ND, 1, 2) \
+    SMHIP_CHAIN_CASE(ND, 2, 0) SMHIP_CHAIN_CASE(ND, 2, 1) SMHIP_CHAIN_CASE(ND, 2, 2)
+    switch (nd * 9 + nr * 3 + ns) {
+        SMHIP_CHAIN_SMALL(0)
+        SMHIP_CHAIN_CASE(1, 0, 0) SMHIP_CHAIN_SMALL(1)
+        SMHIP_CHAIN_CASE(2, 0, 0) SMHIP_CHAIN_SMALL(2)
+        SMHIP_CHAIN_CASE(3, 0, 0) SMHIP_CHAIN_SMALL(3)
+        SMHIP_CHAIN_CASE(4, 0, 0) SMHIP_CHAIN_SMALL(4)
         default: return fail(SMHIP_ERR_INVALID, "chain: no kernel for %d dense / %d row / %d splat operands", nd, nr, ns);
     }
+#undef SMHIP_CHAIN_SMALL
 #undef SMHIP_CHAIN_CASE
     SMHIP_LAUNCH_CHECK("chain");
     return SMHIP_OK;

@@ -51,6 +51,13 @@ for rows, cols in SIZES:
     def eager2(A, B, O):
         lib.binary(sma.OP_SUB, A, col, out=t1); lib.binary(sma.OP_DIV, t1, row, out=O)
     report("(A - col) / row", 8, lambda A, B, O: lib.chain_call(A, (sma.OP_SUB, col), (sma.OP_DIV, row), out=O), eager2)
+    col2 = arr2(lib.uniform_f32(rows, 7, 0.5, 1.5), rows, 1)
+    def eager_norm(A, B, O):
+        lib.binary(sma.OP_SUB, A, col, out=t1); lib.binary(sma.OP_DIV, t1, col2, out=O)
+    report("(A - mean_col) / std_col", 8, lambda A, B, O: lib.chain_call(A, (sma.OP_SUB, col), (sma.OP_DIV, col2), out=O), eager_norm)
+    def eager_mul(A, B, O):
+        lib.binary(sma.OP_SUB, A, col, out=t1); lib.binary(sma.OP_MUL, t1, row, out=O)
+    report("(A - col) * row", 8, lambda A, B, O: lib.chain_call(A, (sma.OP_SUB, col), (sma.OP_MUL, row), out=O), eager_mul)
     def eager2b(A, B, O):
         lib.binary(sma.OP_ADD, A, B, out=t1); lib.array_scalar(sma.OP_MUL, t1, half, out=O)
     report("(A + B) * 0.5", 12, lambda A, B, O: lib.chain_call(A, (sma.OP_ADD, B), (sma.OP_MUL, half), out=O), eager2b)
