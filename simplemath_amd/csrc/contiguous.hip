@@ -337,6 +337,10 @@ template <int KIND> struct HeavyTile<double, KIND> { static constexpr int value 
 // exceeds 1 GiB -- and, found later, even the headline's 1 GiB operands gain 1 % from going out as TWO launches
 // (internal.h: piece_for has the rule and its numbers).
 
+// Half-integer exponents whose double-double product chain (sm_pow64.h: pow_halfint_n) is slower than the one-exponent exp(s log a)
+inline bool m2_is_slow_chain(double s) {
+    return s == -7.5 || s == -6.5 || s == -5.5 || s == -4.5 || s == -3.5 || s == 7.5;
+}
 // Launches the heavy form of `Op` (KIND 0: a op b, 1: a op s, 2: s op a).
 template <typename T, typename Op, int KIND>
 void launch_heavy(const T *pa, const T *pb, T value, T *po, size_t n_vec, int tail, hipStream_t s);
@@ -375,7 +379,9 @@ void launch_heavy_piece(const T *pa, const T *pb, T value, T *po, size_t n_vec, 
         return;
     }
 #endif
-    constexpr int U = HeavyTile<T, KIND>::value;
+    // the lightest table form is served best by two vectors per lane (same box, tools/pow64_rate.py with -DSMHIP_HEAVY_F64_TILE_SCALAR=2 / 3 / 4:
+    // LEVEL 2 78.0-78.3 / 77.2-77.7 / 76.5-77.0 %; LEVEL 1 75.1-76.7 / 77.7-78.3 / 77.1-77.5 %; profiles/r04_pow64_rate.txt)
+    constexpr int U = std::is_same<Op, PowScalar64<2>>::value ? 2 : HeavyTile<T, KIND>::value;
     const size_t tiles = n_vec / ((size_t)kTileBlock * U) + 1;  // the last workgroup: partial tile + scalar tail (maybe empty)
     if (nt & kStoreKeep) hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, true>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
     else hipLaunchKernelGGL((flat_tile_kernel<T, Op, KIND, U, false>), dim3((unsigned)tiles), dim3(kTileBlock), 0, s, pa, pb, value, po, n_vec, tail, nt, FastDiv(1));
@@ -531,7 +537,10 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
         if constexpr (std::is_same<T, double>::value) {
             int m2;
             static const int max_m2 = [] { const char *e = getenv("SMHIP_POW_HALFINT_MAX"); return e && *e ? atoi(e) : 16; }();  // tools/pow64_halfint.py
-            if (smpow64::halfint_exponent(value, &m2) && (m2 < 0 ? -m2 : m2) <= max_m2 && m2 != -15) {  // -7.5: the one chain slower than exp(s log a) (213.6 against 197.6 us)
+            // the chains slower than exp(s log a) with a known exponent (pow_core_u below: 171-172 us): -7.5 213.6 us, -6.5 191.5, -5.5 188.0,
+            // -4.5 174.9, -3.5 175.1, 7.5 175.5-181 (profiles/r03_pow64_halfint.txt, r04_pow64_rate.txt)
+            const bool slow_chain = m2_is_slow_chain(value);
+            if (!slow_chain && smpow64::halfint_exponent(value, &m2) && (m2 < 0 ? -m2 : m2) <= max_m2) {
                 // sm_pow64.h: pow_halfint_n.  Through the one-shot tile form like the general pow (three vectors per lane; with
                 // one vector per lane the chain's latency adds to the load's: 189.7 us, no faster than exp(s log a)), one kernel
                 // per exponent (with a run-time exponent the chain is a loop with branches: 174-218 us).  N = 2^26, random
@@ -541,16 +550,29 @@ int run_scalar(const void *a, T value, size_t n, void *out, hipStream_t s) {
                 const double *none = nullptr;
                 switch (m2) {
 #define SMHIP_HALFINT_CASE(M) case M: launch_heavy<double, PowHalfInt64<M>, 1>(pa, none, value, po, n_vec, tail, s); break;
-                    SMHIP_HALFINT_CASE(-16) SMHIP_HALFINT_CASE(-14) SMHIP_HALFINT_CASE(-13) SMHIP_HALFINT_CASE(-12) SMHIP_HALFINT_CASE(-11)
-                    SMHIP_HALFINT_CASE(-10) SMHIP_HALFINT_CASE(-9) SMHIP_HALFINT_CASE(-8) SMHIP_HALFINT_CASE(-7) SMHIP_HALFINT_CASE(-6) SMHIP_HALFINT_CASE(-5)
+                    SMHIP_HALFINT_CASE(-16) SMHIP_HALFINT_CASE(-14) SMHIP_HALFINT_CASE(-12) 
+                    SMHIP_HALFINT_CASE(-10) SMHIP_HALFINT_CASE(-8) SMHIP_HALFINT_CASE(-6) SMHIP_HALFINT_CASE(-5)
                     SMHIP_HALFINT_CASE(-4) SMHIP_HALFINT_CASE(-3) SMHIP_HALFINT_CASE(-2) SMHIP_HALFINT_CASE(-1) SMHIP_HALFINT_CASE(1) SMHIP_HALFINT_CASE(2)
                     SMHIP_HALFINT_CASE(3) SMHIP_HALFINT_CASE(4) SMHIP_HALFINT_CASE(5) SMHIP_HALFINT_CASE(6) SMHIP_HALFINT_CASE(7) SMHIP_HALFINT_CASE(8)
                     SMHIP_HALFINT_CASE(9) SMHIP_HALFINT_CASE(10) SMHIP_HALFINT_CASE(11) SMHIP_HALFINT_CASE(12) SMHIP_HALFINT_CASE(13) SMHIP_HALFINT_CASE(14)
-                    SMHIP_HALFINT_CASE(15) SMHIP_HALFINT_CASE(16)
+                    SMHIP_HALFINT_CASE(16)
 #undef SMHIP_HALFINT_CASE
                     default: return fail(SMHIP_ERR_INVALID, "half-integer exponent out of range");
                 }
                 SMHIP_LAUNCH_CHECK("array_scalar pow (half-integer exponent)");
+                return SMHIP_OK;
+            }
+            // any other exponent up to 1024 in magnitude: the general arithmetic minus what only an UNKNOWN exponent needs
+            // (sm_pow64.h: pow_core_u).  N = 2^26, random bases (tools/pow64_rate.py, profiles/r04_pow64_rate.txt).
+            static const int max_level = [] { const char *e = getenv("SMHIP_POW_SCALAR_LEVEL"); return e && *e ? atoi(e) : 2; }();
+            int level = smpow64::scalar_level(value);
+            if (level > max_level) level = max_level;
+            if (level > 0) {
+                if (n_vec / ((size_t)kTileBlock * 2) + 1 > 0x7fffffffu) return fail(SMHIP_ERR_UNSUPPORTED, "array too large for one launch");
+                const double *none = nullptr;
+                if (level == 2) launch_heavy<double, PowScalar64<2>, 1>(pa, none, value, po, n_vec, tail, s);
+                else launch_heavy<double, PowScalar64<1>, 1>(pa, none, value, po, n_vec, tail, s);
+                SMHIP_LAUNCH_CHECK("array_scalar pow (one exponent)");
                 return SMHIP_OK;
             }
         }

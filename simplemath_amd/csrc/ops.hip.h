@@ -336,6 +336,44 @@ template <> struct OpCtx<PowBanked> {
     }
 };
 
+// sm::pow(a, s) on doubles with ONE exponent of moderate magnitude (sm_pow64.h: pow_core_u; LEVEL 1: |s| <= 1024, 2: |s| <= 16):
+// the general arithmetic minus what only an unknown exponent needs.  Launched by contiguous.hip's array-scalar form.  The tables
+// sit in LDS as five plain arrays (5 KiB; sm_pow64.h: TabSoA).
+template <int LEVEL> struct PowScalar64 {
+    static __device__ __forceinline__ double apply(double a, double b) { return smpow64::pow_scalar(a, b, LEVEL, smpow64::kLogTab, smpow64::kExpTab); }
+};
+template <typename Op> struct ScalarLevelOf { static constexpr int value = 0; };
+template <int LEVEL> struct ScalarLevelOf<PowScalar64<LEVEL>> { static constexpr int value = LEVEL; };
+template <int LEVEL> struct OpCtx<PowScalar64<LEVEL>> {
+    static constexpr int kDoubles = smpow64::kSoADoubles;
+    smpow64::TabSoA tab;
+    template <int BLOCK> struct Stage { double v[(kDoubles + BLOCK - 1) / BLOCK]; };
+    static __device__ __forceinline__ double source(int f) { return smpow64::table_value(f / smpow64::kN, f % smpow64::kN); }
+    __device__ __forceinline__ void init() {
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+        for (int f = threadIdx.x; f < kDoubles; f += blockDim.x) lds_tab[f] = source(f);
+        __syncthreads();
+        tab.base = lds_tab;
+    }
+    template <int BLOCK> __device__ __forceinline__ void fetch(Stage<BLOCK> &st) const {
+#pragma unroll
+        for (int k = 0; k < (kDoubles + BLOCK - 1) / BLOCK; ++k) {
+            const int f = threadIdx.x + k * BLOCK < kDoubles ? threadIdx.x + k * BLOCK : kDoubles - 1;  // unconditional loads
+            st.v[k] = source(f);
+        }
+    }
+    template <int BLOCK> __device__ __forceinline__ void commit(const Stage<BLOCK> &st) {
+        __shared__ __attribute__((aligned(16))) double lds_tab[kDoubles];
+#pragma unroll
+        for (int k = 0; k < (kDoubles + BLOCK - 1) / BLOCK; ++k) {
+            const int f = threadIdx.x + k * BLOCK;
+            if (f < kDoubles) lds_tab[f] = st.v[k];
+        }
+        __syncthreads();
+        tab.base = lds_tab;
+    }
+};
+
 // sm::pow(a, s) on doubles with s a multiple of one half, |s| <= 8: a double-double product chain instead of exp(s log a)
 // (sm_pow64.h: pow_halfint_n) -- no table, and with the exponent a template parameter no branch either.  M2 = 2 s.  Only
 // launched by contiguous.hip's array-scalar form (run_scalar), through the one-shot tile kernel.
@@ -363,6 +401,8 @@ __device__ __forceinline__ void apply_n(const OpCtx<Op> &ctx, const T (&a)[W], c
         smpow64::pow_n<W, smpow64::TabBanked>(a, b, r, ctx.tab);
     } else if constexpr (HalfIntOf<Op>::value != 0) {
         smpow64::pow_halfint_n<W, HalfIntOf<Op>::value>(a, HalfIntOf<Op>::value, r);
+    } else if constexpr (ScalarLevelOf<Op>::value != 0) {
+        smpow64::pow_scalar_n<ScalarLevelOf<Op>::value, W>(a, b[0], r, ctx.tab);  // one exponent for the launch (apply_vec_scalar)
     } else {
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = Op::apply(a[i], b[i]);

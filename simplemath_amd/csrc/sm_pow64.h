@@ -22,6 +22,7 @@
 
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 
 #include "sm_pow.h"  // SM_POW_FN, SM_POW_FMA, SM_POW_RINT, sat_i32, any_lane, f64_bits / bits_f64
 
@@ -522,6 +523,145 @@ SM_POW_FN void pow_n(const double (&x)[W], const double (&y)[W], double (&out)[W
     pow_n<W, TabAoS>(x, y, out, TabAoS{logtab, exptab});
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE exponent of moderate magnitude for a whole array (sm::pow(a, 2.7): array_scalar_op, calculate.h:137-169, with
+// PowOp<double>::apply, pow.h:8-10).  The evaluation above is built for ANY pair (x, y): |y ln x| may overflow, y may be
+// 2^60, and every error term of ln x is carried because it is multiplied by an unknown y.  The general form is bound by its
+// vector instructions (profiles/r02_pow64_rate.txt: the VALU busy 79 % of the kernel at ~75 instructions per element), so
+// knowing the exponent on the host buys time directly:
+//   LEVEL 1, |y| <= 1024:  E = y ln x stays below 2^20, so nothing overflows and nothing needs clamping (4 instructions);
+//            ln x need not be renormalised before the product (y * hi, then y * lo joins the low part: 3); rounding E N / ln 2
+//            to an integer is one fma against 1.5 * 2^52 whose low word IS the integer (glibc's exp idiom: 2 instead of
+//            mul + rndne + cvt); the residual of r * (-r/2), < 2^-69, times 1024 is 2^-59: dropped (1).
+//   LEVEL 2, |y| <= 16:  what ln x must carry shrinks with y.  r = fma(z, invc, -1) in ONE rounding (the bit it can lose,
+//            <= 2^-61.6, times 16 is 0.04 ULP of the result) instead of the exact product and its three-term
+//            renormalisation (5); r - r^2/2 summed first and added to k ln 2 + log c with ONE error-free step instead of
+//            two (2).  37 fp64 instructions instead of 55.
+// Bases that are not positive normal numbers go through pow_general like everywhere else.  The kernels read the tables as five
+// plain arrays (TabSoA).  Host check: tests/cpp/pow64_host_check.cpp
+// (each level over its range of exponents against glibc's pow, <= 1 ULP).
+struct TabSoA {  // five arrays of kN doubles in LDS: invc | logc | logctail | T | tail
+    // Entry i of every array starts in bank pair i mod 16, so the sixteen lanes of one LDS pass meet sixteen different starting
+    // positions (the generated {invc, logc, logctail} triples: the same sixteen; triples padded to 32 bytes for one b128 read: FOUR --
+    // 70 % of the LDS-active cycles were bank conflicts, profiles/r04_pow64_rate.txt).  The interval's BYTE offset is a shift and a
+    // mask of the high word; the compiler pairs the reads 1 KiB apart into ds_read2st64_b64.
+    const double *base;
+    SM_POW_MEMFN double invc(int i) const { return base[i]; }
+    SM_POW_MEMFN double logc(int i) const { return base[kN + i]; }
+    SM_POW_MEMFN double logctail(int i) const { return base[2 * kN + i]; }
+    SM_POW_MEMFN double th(int j) const { return base[3 * kN + j]; }
+    SM_POW_MEMFN double trel(int j) const { return base[4 * kN + j]; }
+    SM_POW_MEMFN const double *log_entry(uint32_t tmp) const {  // the interval encoded in tmp's bits 13..19
+        return reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((tmp >> (20 - 7 - 3)) & ((uint32_t)(kN - 1) << 3)));
+    }
+};
+constexpr int kSoADoubles = 5 * kN;  // value `a` of entry i at a * kN + i (table_value)
+// 0: the general evaluation; 1: |y| <= 1024; 2: |y| <= 16 (y finite and of normal magnitude in both)
+inline int scalar_level(double y) {
+    const uint64_t ay = f64_bits(y) & 0x7fffffffffffffffULL;
+    if (ay < 0x0010000000000000ULL || ay > 0x4090000000000000ULL) return 0;  // zero / subnormal, or beyond 1024 (infinities, NaNs)
+    return ay <= 0x4030000000000000ULL ? 2 : 1;
+}
+template <int LEVEL, typename TAB>
+SM_POW_FN double pow_core_u(double ax, double y, const TAB &tab) {
+    static_assert(LEVEL == 1 || LEVEL == 2, "see scalar_level");
+    const uint32_t hi = (uint32_t)(f64_bits(ax) >> 32), lw = (uint32_t)f64_bits(ax);
+    const uint32_t tmp = hi - (uint32_t)(kOff >> 32);
+    const int i = (int)((tmp >> (20 - 7)) & (kN - 1));
+    const int k = (int32_t)tmp >> 20;
+    const double z = smpow::make_f64(hi - (tmp & 0xfff00000u), lw);
+    double invc, logc, logctail;
+    if constexpr (std::is_same<TAB, TabSoA>::value) {
+        const double *e = tab.log_entry(tmp);
+        invc = e[0]; logc = e[kN]; logctail = e[2 * kN];
+    } else {
+        invc = tab.invc(i); logc = tab.logc(i); logctail = tab.logctail(i);
+    }
+    const double kd = (double)k;
+    const double Ln2hi = 0x1.62e42f8000000p-1, Ln2lo = 0x1.be8e7bcd5e4f2p-27;
+    const double t1 = SM_POW_FMA(kd, Ln2hi, logc);  // exact
+    const double lo1 = SM_POW_FMA(kd, Ln2lo, logctail);
+    double r, lhi, low;
+    if constexpr (LEVEL == 2) {
+        r = SM_POW_FMA(z, invc, -1.0);
+        const double ar2 = r * (-0.5 * r);
+        const double s = r + ar2;
+        lhi = t1 + s;
+        low = lo1 + ((t1 - lhi) + s);
+    } else {
+        const double ph = z * invc, pl = SM_POW_FMA(z, invc, -ph);
+        const double rm = ph - 1.0;
+        r = rm + pl;
+        const double rlo = (rm - r) + pl;
+        const double t2 = t1 + r;
+        const double lo2 = (t1 - t2) + r;
+        const double ar2 = r * (-0.5 * r);
+        lhi = t2 + ar2;
+        const double lo4 = (t2 - lhi) + ar2;
+        low = ((lo1 + lo2) + lo4) + rlo;
+    }
+    const double ar = -0.5 * r;
+    double p = fma4_c(ar, 0x1.2492492492492p+1);               // 16/7   (the polynomial of pow_core_t)
+    p = fma_c(p, ar, 0x1.5555555555555p+0);                    //  4/3
+    p = fma_c(p, ar, 0x1.999999999999ap-1);                    //  4/5
+    p = SM_POW_FMA(p, ar, 0.5);
+    p = fma_c(p, ar, 0x1.5555555555555p-2);                    //  1/3
+    const double r3 = (r * r) * r;
+    const double lo = SM_POW_FMA(p, r3, low);                  // ln(ax) = lhi + lo, lo up to 2^-23: not renormalised
+
+    const double ehi = y * lhi;
+    const double elo = SM_POW_FMA(y, lo, SM_POW_FMA(y, lhi, -ehi));  // |y lo| <= 2^-13
+    const double InvLn2N = 0x1.71547652b82fep+7, Ln2hiN = 0x1.62e42f8000000p-8, Ln2loN = 0x1.be8e7bcd5e4f2p-34;
+    const double Shift = 0x1.8p52;
+    const double ks = SM_POW_FMA(ehi, InvLn2N, Shift);        // |ehi InvLn2N| < 2^28: the integer sits in the low word
+    const int ki = (int32_t)(uint32_t)f64_bits(ks);
+    const double kd2 = ks - Shift;
+    double rr = SM_POW_FMA(-kd2, Ln2hiN, ehi);
+    rr = SM_POW_FMA(-kd2, Ln2loN, rr);
+    rr += elo;
+    const int j = ki & (kN - 1), e = ki >> 7;
+    const double th = tab.th(j), trel = tab.trel(j);
+    const double r2 = rr * rr;
+    double u = (rr + 5.0) * 0x1.1111111111111p-7;
+    u = fma_c(u, rr, 0x1.5555555555555p-3);
+    u = SM_POW_FMA(u, rr, 0.5);
+    const double q = SM_POW_FMA(u, r2, trel + rr);
+    return SM_POW_LDEXP(SM_POW_FMA(th, q, th), e);             // e up to +-2^13: v_ldexp_f64 saturates to 0 / inf
+}
+// W bases held in registers, one exponent for which scalar_level(y) == LEVEL
+template <int LEVEL, int W, typename TAB>
+SM_POW_FN void pow_scalar_n(const double (&x)[W], double y, double (&out)[W], const TAB &tab) {
+    uint32_t worst = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const uint32_t o = (uint32_t)(f64_bits(x[k]) >> 32) - kMinNormalHi;
+        worst = o > worst ? o : worst;
+    }
+    if (!smpow::any_lane(worst >= kOrdinarySpan)) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) out[k] = pow_core_u<LEVEL>(x[k], y, tab);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        double xs = x[k], ys = y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(xs), "+v"(ys));
+#endif
+        out[k] = pow_general(xs, ys, tab);
+    }
+}
+// by run-time exponent (host check; a kernel's scalar tail)
+SM_POW_FN double pow_scalar(double x, double y, int level, const double *logtab, const double *exptab) {
+    const TabAoS tab{logtab, exptab};
+    const double xs[1] = {x};
+    double r[1];
+    if (level == 2) pow_scalar_n<2, 1>(xs, y, r, tab);
+    else if (level == 1) pow_scalar_n<1, 1>(xs, y, r, tab);
+    else r[0] = pow(x, y, logtab, exptab);
+    return r[0];
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Scalar exponents that are a multiple of one half, |y| <= 8 (sm::pow(a, 2.5), a cube, an inverse square root ...):

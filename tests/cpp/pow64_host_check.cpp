@@ -51,5 +51,47 @@ int main() {
         if (!ok) { ++bad; printf("lattice x=%a y=%a got=%a want=%a\n", x, y, got, want); }
     }
     printf("lattice_mismatches %d\n", bad);
+
+    // One exponent of moderate magnitude for the whole array (smpow64::pow_scalar, LEVEL 2: |y| <= 16, LEVEL 1: |y| <= 1024): against
+    // glibc, and the TRUE error in ULP against long double powl (64-bit significand) where the result is a normal number.
+    const double ys1[] = {2.7, 0.3333, 7.5, 8.5, 16.0, -16.0, 1e-3, 0.1, 15.99, -13.37, 3.141592653589793, 1.0 / 3, -0.001, 1e-300, 2.2250738585072014e-308,
+                          1.0000000000000002, 0.9999999999999999, 10.25, -7.77, 37.75, 100.0, -100.0, 700.0, -700.0, 1024.0, -1000.5, 123.456, 16.000000000000004,
+                          511.3, -64.1, 17.0};
+    int64_t sworst = 0; uint64_t scount = 0; double strue = 0, swx = 0, swy = 0; int levels[3] = {0, 0, 0}, sbad = 0;
+    for (double y : ys1) {
+        const int level = smpow64::scalar_level(y);
+        ++levels[level];
+        for (uint64_t i = 0; i < 120000; ++i) {
+            uint64_t h = mix(i * 0x9E3779B97F4A7C15ULL + (uint64_t)(int64_t)(y * 1000));
+            double x;
+            switch (i % 5) {
+                case 0: { uint64_t u = h & 0x7fffffffffffffffULL; memcpy(&x, &u, 8); break; }
+                case 1: x = 0.01 + (double)(h >> 11) * 0x1.0p-53 * 99.99; break;
+                case 2: x = 1.0 + ((double)(h >> 11) * 0x1.0p-53 - 0.5) * ((h & 1) ? 1e-3 : 0.05); break;
+                case 3: { uint64_t u = h & 0x000fffffffffffffULL; memcpy(&x, &u, 8); break; }
+                default: x = std::exp2((double)((int64_t)(h % 2000) - 1000) / 10.0) * (1.0 + (double)(h >> 40) * 0x1p-24); break;
+            }
+            if (!(x == x) || std::isinf(x)) continue;
+            const double got = smpow64::pow_scalar(x, y, level, smpow64::kLogTab, smpow64::kExpTab), want = std::pow(x, y);
+            int64_t d = ord(got) - ord(want); if (d < 0) d = -d;
+            if (d > sworst) { sworst = d; swx = x; swy = y; }
+            if (std::isfinite(want) && want > 1e-290) {
+                const long double t = powl((long double)x, (long double)y);
+                const double u = std::nextafter(want, INFINITY) - want;
+                const double err = (double)fabsl(((long double)got - t) / u);
+                if (err > strue) strue = err;
+            }
+            ++scount;
+        }
+        for (double x : sp) {  // the lattice's bases with this exponent
+            const double got = smpow64::pow_scalar(x, y, level, smpow64::kLogTab, smpow64::kExpTab), want = std::pow(x, y);
+            int64_t d = ord(got) - ord(want); if (d < 0) d = -d;
+            const bool ok = (got != got && want != want) || (ord(got) == ord(want) && std::signbit(got) == std::signbit(want)) ||
+                            (d <= 1 && std::isfinite(want) && want != 0.0);
+            if (!ok) { ++sbad; printf("scalar lattice x=%a y=%a got=%a want=%a\n", x, y, got, want); }
+        }
+    }
+    printf("scalar_max_ulp %lld over %llu (x=%a y=%a) true_err %.3f levels %d %d %d lattice_mismatches_scalar %d\n", (long long)sworst,
+           (unsigned long long)scount, swx, swy, strue, levels[0], levels[1], levels[2], sbad);
     return 0;
 }

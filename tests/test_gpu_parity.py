@@ -263,6 +263,29 @@ def test_pow_f64_half_integer_exponents(smhip, oracle):
         assert same_kind.mean() > 0.999, y
 
 
+def test_pow_f64_one_exponent(smhip, oracle):
+    """sm::pow(a, s) on doubles with one exponent up to 1024 in magnitude that is not a half-integer: sm_pow64.h's pow_core_u
+    (level 2 up to 16, level 1 up to 1024; beyond that the general form).  Against libm's pow (PowOp<double>::apply, pow.h:8-10):
+    <= 1 ULP, NaNs in the same places, same signs -- mixed-sign values, subnormals, powers that overflow / underflow, specials,
+    odd tails and a size that spans several workgroups."""
+    a = np.concatenate([gen.gen(np.float64, 6001, 121, "mixed"), gen.gen(np.float64, 70001, 122, "positive"),
+                        np.exp2(np.linspace(-1074, 1023, 4003)), -np.exp2(np.linspace(-300, 300, 1001)),
+                        1.0 + np.linspace(-0.05, 0.05, 3001),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 4.0, 5e-324, -5e-324, 1e-310, 1.7976931348623157e308,
+                                  -1.7976931348623157e308, 2.2250738585072014e-308], dtype=np.float64)])
+    da = smhip.to_device(a)
+    for y in (2.7, 1.0 / 3, 0.3333, 8.5, -13.37, 15.99, 16.0, -16.0, 1e-3, 1e-300, 16.000000000000004, 37.75, 100.25, -700.3, 1024.0, -1024.0,
+              1024.0000000000002, 5000.1, 17.0, 33.0):
+        got = smhip.array_scalar(sma.OP_POW, da, np.float64(y)).numpy()
+        with np.errstate(all="ignore"):
+            want = oracle.array_scalar(orc.POW, a, np.float64(y))
+        assert np.array_equal(np.isnan(got), np.isnan(want)), y
+        ok = ~np.isnan(want)
+        d = orc.ulp_diff_f64(got[ok], want[ok])
+        assert d.max() <= 1, (y, a[ok][np.argmax(d)])
+        assert np.array_equal(np.signbit(got[ok]), np.signbit(want[ok])), y
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64", "i32", "i64"])
 def test_array_scalar_vs_oracle(smhip, oracle, dt):
     for op in ("add", "sub", "mul", "div"):

@@ -26,6 +26,14 @@ def test_pow64_algorithm_on_host():
     assert m and int(m.group(2)) > 3_500_000
     assert int(m.group(1)) <= 1, out
     assert "lattice_mismatches 0" in out, out
+    # one exponent of moderate magnitude for a whole array (pow_core_u: the arithmetic trimmed to what a KNOWN exponent needs):
+    # <= 1 ULP from glibc, and its true error (against long double powl) stays below 0.65 ULP
+    m = re.search(r"scalar_max_ulp (\d+) over (\d+) .* true_err ([0-9.]+) levels (\d+) (\d+) (\d+) lattice_mismatches_scalar (\d+)", out)
+    assert m and int(m.group(2)) > 3_500_000, out
+    assert int(m.group(1)) <= 1, out
+    assert float(m.group(3)) < 0.65, out
+    assert int(m.group(4)) == 0 and int(m.group(5)) >= 10 and int(m.group(6)) >= 15, out
+    assert int(m.group(7)) == 0, out
 
 
 def test_pow64_half_integer_exponents_on_host():

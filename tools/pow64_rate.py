@@ -25,7 +25,7 @@ for name, src in (("random bases", a), ("all bases 1.5", ones)):
     t = timeit(lib.c.smhip_contiguous, (C.c_int(4), C.c_int(1), C.c_void_p(src.ptr), C.c_void_p(b.ptr), C.c_void_p(out.ptr), C.c_size_t(n)))
     print("f64 pow(a, b)    %-14s 2^26: %6.1f us  %5.1f%%" % (name, t, 24.0 * n / t * 1e-3 / 80), flush=True)
 # other scalar exponents: multiples of one half up to 8 take the double-double product chain, everything else the general form
-for y in (2.7, 1.5, 3.0, -2.5, 7.5, -8.0, 8.5, 0.3333333333333333):
+for y in (2.7, 1.5, 3.0, -2.5, 7.5, -8.0, 8.5, 0.3333333333333333, -13.37, 37.75, -1000.5, 5000.0):  # SMHIP_POW_SCALAR_LEVEL=0: the general form for all
     sy = C.c_double(y)
     t = timeit(lib.c.smhip_array_scalar, (C.c_int(4), C.c_int(1), C.c_void_p(a.ptr), C.byref(sy), C.c_size_t(n), C.c_void_p(out.ptr)))
     print("f64 pow(a, %-6.4g) random bases  2^26: %6.1f us  %5.1f%%" % (y, t, 16.0 * n / t * 1e-3 / 80), flush=True)
