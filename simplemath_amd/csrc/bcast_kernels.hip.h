@@ -615,6 +615,22 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
         bid = (bid & 7u) * per + (bid >> 3);
         if (bid >= p.total) return;
     }
+    uint32_t tq3 = 0, tp3 = 0;
+    if (p.order == 3) {
+        // Blocks of BP x BQ patches, dealt to the XCDs in turn: the patches on either side of a seam -- along q (the output's and the
+        // direct operand's shared lines) and along p (the turned operand's) -- run back to back on ONE XCD, and the eight XCDs work
+        // on neighbouring blocks.  p.total packs BP | BQ << 8; the grid is 8 * BP * BQ * ceil(blocks / 8).
+        const uint32_t BP = p.total & 0xffu, BQ = (p.total >> 8) & 0xffu, per = BP * BQ;
+        const uint32_t x = bid & 7u, local = bid >> 3;
+        const uint32_t blk = (local / per) * 8u + x, in = local % per;
+        const uint32_t blocks_q = (p.tiles_q + BQ - 1) / BQ;
+        tq3 = (blk % blocks_q) * BQ + in % BQ;
+        tp3 = (blk / blocks_q) * BP + in / BQ;  // over tiles_p x slices
+        uint32_t rows = p.tiles_p;
+        for (int k = 0; k < p.n_rest; ++k) rows *= p.rest[k].d;
+        if (tq3 >= p.tiles_q || tp3 >= rows) return;
+        bid = tp3 * p.tiles_q + tq3;  // the row-major index the code below takes apart
+    }
     OpCtx<Op> ctx;
     ctx.init();
     // Consecutive workgroups walk q (walking p instead was 15-25 % slower with one turned operand, r01, and 35 % slower
@@ -845,3 +861,160 @@ __device__ __forceinline__ void tile_body(const T *__restrict__ a, const T *__re
     }
 }
 
+#ifndef SMHIP_TILE_SHIFT_FORM
+#define SMHIP_TILE_SHIFT_FORM 0
+#endif
+#if SMHIP_TILE_SHIFT_FORM
+// ------------------------------------------------------------------ tile kernel, output rows off the 128-byte lines
+// An inner extent like 12287 puts every output row at its own phase against the 128-byte lines.  tile_body's patches cut every
+// row at the same COLUMNS, so each patch row starts and ends inside a line it shares with the neighbouring patch: the output
+// leaves as two partial writes per seam and row, the direct operand's seam lines are fetched twice.  Where that costs
+// (tools/tile_align_probe.py -> profiles/r04_tile_align_probe.txt, out = A.T + B, f32, 12288^2 with one base pointer moved off
+// the lines: everything aligned 298 us; out off 337; A, the turned side, off 330; B off 309; all three 377 = the 370 us of
+// 12287^2), the output is the largest term -- and the one a different cut can remove: here row i of patch tq covers the columns
+// [tq TQ - m_i, (tq + 1) TQ - m_i) with m_i = the row's phase, (address of out[i][0]) mod 128 bytes in elements -- a parallelogram
+// in index space whose every row is a whole number of lines of the output (and of the direct operand when it shares the
+// output's pitch and phase).  The turned operand is staged for TQ + G columns (G = one line of elements: the union of the rows'
+// windows), phase 2 reads row i of the LDS tile at its own shift.  One more patch column than tile_body needs at most; the
+// windows that hang over a row's ends (first and last patch column) move those vectors element by element.  Loads are issued
+// unconditionally (addresses clamped into the row), so every load of a lane still goes out ahead of the first use.
+// MEASURED AND NOT ADOPTED (profiles/r04_tile_align_probe.txt): at 12287^2 the aligned output wins what the 12.5 % of extra turned
+// loads and the extra patch column lose (370 -> 378 us; on rows that ARE on the lines the form costs 7.7 %: 300 -> 323 us) -- the
+// kernel is bound by the number of 128-byte line requests, not by DRAM bytes, and this form trades one kind for another.  Built
+// with -DSMHIP_TILE_SHIFT_FORM=1 and selected with SMHIP_TILE_SHIFT=1 (2: also for rows on the lines).
+// The host guarantees: np >= 4 * kTileP and the output overlaps no operand (row-edge patches are pulled back inside and
+// recompute their neighbour's values), the direct operand is dense or constant along q.
+constexpr int kTileShiftBytes = 128;
+template <typename T, typename Op, int MA, int MB, int QB>
+__device__ __forceinline__ void tile_shift_body(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, TileParams p) {
+    constexpr int W = VecTraits<T>::width;
+    constexpr int TQ = tile_q<T, QB>();
+    constexpr int G = kTileShiftBytes / (int)sizeof(T);
+    constexpr int TC = TQ + G;  // columns staged
+    constexpr int VP = kTileP / W, VQ = TQ / W;
+    constexpr bool SKEW = sizeof(T) == 4;
+    constexpr int PITCH = (SKEW ? TC + TC / 32 + 1 : TC + 1) | 1;  // tile_body's layout, the pitch kept odd
+    auto at = [](uint32_t i, uint32_t j) -> uint32_t { return SKEW ? i * PITCH + j + (j >> 5) + ((i >> 5) << 1) : i * PITCH + j; };
+    typedef typename VecTraits<T>::vec_t V;
+    constexpr bool kBoth = MA == 1 && MB == 1;
+    constexpr int S1 = TC * VP / 256, S2 = kTileP * VQ / 256;
+    static_assert((TC * VP) % 256 == 0 && (kTileP * VQ) % 256 == 0, "whole slots");
+    __shared__ T tile[kTileP * PITCH];
+    OpCtx<Op> ctx;
+    ctx.init();
+    uint32_t bid = blockIdx.x;
+    const uint32_t tq = bid % p.tiles_q; bid /= p.tiles_q;
+    const uint32_t tp = bid % p.tiles_p; bid /= p.tiles_p;
+    int64_t offA = 0, offB = 0, offO = 0;
+    for (int k = 0; k < p.n_rest; ++k) {
+        uint32_t qd, idx;
+        p.rest[k].divmod(bid, qd, idx);
+        bid = qd;
+        offA += (int64_t)idx * p.a_r[k];
+        offB += (int64_t)idx * p.b_r[k];
+        offO += (int64_t)idx * p.o_r[k];
+    }
+    uint32_t i0 = tp * kTileP;
+    if (i0 + kTileP > p.np) i0 = p.np - kTileP;
+    const int32_t j0 = (int32_t)(tq * TQ), nq = (int32_t)p.nq;
+    const T *a0 = a + offA + (int64_t)i0 * p.a_p;  // column 0 of the patch's rows
+    const T *b0 = b + offB + (int64_t)i0 * p.b_p;
+    T *o0 = out + offO + (int64_t)i0 * p.o_p;
+    // the rows' phases against the lines: row il starts m(il) elements past one
+    const uint32_t m0 = (uint32_t)((reinterpret_cast<uintptr_t>(o0) / sizeof(T)) & (G - 1)), opm = (uint32_t)p.o_p & (G - 1);
+    const int64_t direct_q = MA == 1 ? p.b_q : p.a_q;
+    const bool dsplat = !kBoth && direct_q == 0;
+    const T *d0 = MA == 1 ? b0 : a0;
+    const int64_t d_p = MA == 1 ? p.b_p : p.a_p;
+    V va[S1], vb[kBoth ? S1 : 1], vd[kBoth ? 1 : S2];
+    auto issue = [&](auto nt_tag) {
+        constexpr bool NT = decltype(nt_tag)::value;
+#pragma unroll
+        for (int s = 0; s < S1; ++s) {
+            const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
+            int32_t j = j0 - G + (int32_t)jl;
+            j = j < 0 ? 0 : (j >= nq ? nq - 1 : j);
+            if constexpr (kBoth) {
+                va[s] = load_stream_as(T, reinterpret_cast<const V *>(a0 + ig * W + (int64_t)j * p.a_q), NT);
+                vb[s] = load_stream_as(T, reinterpret_cast<const V *>(b0 + ig * W + (int64_t)j * p.b_q), NT);
+            } else if constexpr (MA == 1) {
+                va[s] = load_stream_as(T, reinterpret_cast<const V *>(a0 + ig * W + (int64_t)j * p.a_q), NT);
+            } else {
+                va[s] = load_stream_as(T, reinterpret_cast<const V *>(b0 + ig * W + (int64_t)j * p.b_q), NT);
+            }
+        }
+        if constexpr (!kBoth) {
+#pragma unroll
+            for (int s = 0; s < S2; ++s) {
+                const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
+                if (dsplat) {
+                    const T one = d0[(int64_t)il * d_p];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) vd[s][k] = one;
+                } else {
+                    int32_t j = j0 + (int32_t)(jg * W) - (int32_t)((m0 + il * opm) & (G - 1));
+                    j = j < 0 ? 0 : (j > nq - W ? nq - W : j);
+                    vd[s] = load_stream_as(T, reinterpret_cast<const V *>(d0 + (int64_t)il * d_p + j), NT);
+                }
+            }
+        }
+    };
+    if (p.nt & kLoadNt) issue(BoolTag<true>{});
+    else issue(BoolTag<false>{});
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, jl = v / VP, ig = v % VP;
+        T x[W];
+        if constexpr (kBoth) {
+            T xa[W], xb[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) { xa[k] = va[s][k]; xb[k] = vb[s][k]; }
+            apply_n<Op, T, W>(ctx, xa, xb, x);
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) x[k] = va[s][k];
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) tile[at(ig * W + k, jl)] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+        const uint32_t v = threadIdx.x + 256 * s, il = v / VQ, jg = v % VQ;
+        const int32_t jr = (int32_t)(jg * W) - (int32_t)((m0 + il * opm) & (G - 1));  // against j0; the tile's column 0 is j0 - G
+        const int32_t j = j0 + jr;
+        T xt[W], xr[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) xt[k] = tile[at(il, (uint32_t)(jr + G + k))];
+        T *orow = o0 + (int64_t)il * p.o_p;
+        if ((uint32_t)j <= (uint32_t)(nq - W)) {  // the whole vector inside the row (j < 0 compares as huge)
+            if constexpr (kBoth) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) xr[k] = xt[k];
+            } else {
+                T xd[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) xd[k] = vd[s][k];
+                if constexpr (MA == 1) apply_n<Op, T, W>(ctx, xt, xd, xr);
+                else apply_n<Op, T, W>(ctx, xd, xt, xr);
+            }
+            V val;
+#pragma unroll
+            for (int k = 0; k < W; ++k) val[k] = xr[k];
+            store_stream_if(T, reinterpret_cast<V *>(orow + j), val, p.nt);
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                if ((uint32_t)(j + k) < (uint32_t)nq) {
+                    if constexpr (kBoth) {
+                        orow[j + k] = xt[k];
+                    } else {
+                        const T xd = dsplat ? vd[s][0] : d0[(int64_t)il * d_p + (j + k)];
+                        orow[j + k] = MA == 1 ? Op::apply(xt[k], xd) : Op::apply(xd, xt[k]);
+                    }
+                }
+            }
+        }
+    }
+}
+#endif  // SMHIP_TILE_SHIFT_FORM

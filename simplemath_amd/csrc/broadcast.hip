@@ -81,6 +81,12 @@ template <typename T, typename Op, bool VEC, int MA, int MB, int QB>
 __global__ __launch_bounds__(256) void tile_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, TileParams p) {
     tile_body<T, Op, VEC, MA, MB, QB>(a, b, out, p);
 }
+#if SMHIP_TILE_SHIFT_FORM
+template <typename T, typename Op, int MA, int MB, int QB>
+__global__ __launch_bounds__(256) void tile_shift_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, TileParams p) {
+    tile_shift_body<T, Op, MA, MB, QB>(a, b, out, p);
+}
+#endif
 
 // ---------------------------------------------------------------------------- choosing a kernel
 // plan_launch() turns a normalised problem into a Launch: which body, which compile-time variant of it, the grid and the
@@ -317,6 +323,14 @@ int plan_launch(const Plan &pl, int esz, bool heavy, Launch *L) {
                 L->ma = L->vec ? t.mode_a : 0;
                 L->mb = L->vec ? t.mode_b : 0;
                 L->grid = (unsigned)blocks;
+                if (t.order == 3) {  // blocks of BP x BQ patches dealt to the XCDs in turn (SMHIP_TILE_BLOCK = BP * 16 + BQ in hex digits: 24 = 2 x 4)
+                    static const int blk = [] { const char *e = getenv("SMHIP_TILE_BLOCK"); return e && *e ? (int)strtol(e, nullptr, 16) : 0x24; }();
+                    const uint32_t BP = (uint32_t)(blk >> 4) & 15u ? (uint32_t)(blk >> 4) & 15u : 1u, BQ = (uint32_t)blk & 15u ? (uint32_t)blk & 15u : 1u;
+                    const size_t rows = slices * t.tiles_p, nblocks = ((rows + BP - 1) / BP) * ((t.tiles_q + BQ - 1) / BQ);
+                    const size_t g = (nblocks + 7) / 8 * 8 * BP * BQ;
+                    if (g < 0x7fffffffull) { t.total = BP | (BQ << 8); L->grid = (unsigned)g; }
+                    else t.order = 0;
+                }
                 if (t.order == 2) {  // eight runs of the row-major walk, one per XCD (bcast_kernels.hip.h: tile_body)
                     t.total = (uint32_t)blocks;
                     L->grid = (unsigned)((blocks + 7) / 8 * 8);
@@ -449,6 +463,32 @@ int launch_aot(const Launch &L, const void *a_, const void *b_, void *out_, hipS
         case Launch::kTile:
             if (!L.vec) return fail(SMHIP_ERR_INVALID, "tile kernel: the plan always asks for the 16-byte form");  // (the one-element-per-slot form is no longer built: the 16-byte form takes every extent)
             else {
+#if SMHIP_TILE_SHIFT_FORM
+                // Output rows off the 128-byte lines, past the Infinity Cache: patches whose rows are cut at LINES, not columns
+                // (bcast_kernels.hip.h: tile_shift_body) -- measured and not adopted, see there; built only with -DSMHIP_TILE_SHIFT_FORM=1.
+                {
+                    const TileParams &t = L.p.tile;
+                    static const int shift_mode = [] { const char *e = getenv("SMHIP_TILE_SHIFT"); return e && *e ? atoi(e) : 0; }();  // 0: off (default), 1: rows off the lines, 2: also for rows ON the lines (the form's own cost)
+                    const bool shift_on = shift_mode != 0;
+                    constexpr uint32_t TQ = kTileQBytesWide / sizeof(T), G = kTileShiftBytes / sizeof(T);
+                    const bool both = L.ma == 1 && L.mb == 1;
+                    const int64_t direct_q = L.ma == 1 ? t.b_q : t.a_q;
+                    if (shift_on && L.qb == kTileQBytesWide && t.order == 0 && !t.in_place && t.np >= 4u * kTileP && t.nq >= 2u * TQ &&
+                        (((size_t)t.nq * sizeof(T)) % kTileShiftBytes != 0 || shift_mode == 2) && (both || direct_q == 1 || direct_q == 0)) {
+                        TileParams ts = t;
+                        ts.tiles_q = (t.nq + G - 1 + TQ - 1) / TQ;
+                        const size_t blocks = (size_t)L.grid / ((size_t)t.tiles_p * t.tiles_q) * ts.tiles_p * ts.tiles_q;
+                        if (blocks < 0x7fffffffull) {
+                            const dim3 sgrid((unsigned)blocks);
+                            if (both) hipLaunchKernelGGL((tile_shift_kernel<T, Op, 1, 1, kTileQBytesWide>), sgrid, block, 0, s, a, b, out, ts);
+                            else if (L.ma == 1) hipLaunchKernelGGL((tile_shift_kernel<T, Op, 1, 0, kTileQBytesWide>), sgrid, block, 0, s, a, b, out, ts);
+                            else hipLaunchKernelGGL((tile_shift_kernel<T, Op, 0, 1, kTileQBytesWide>), sgrid, block, 0, s, a, b, out, ts);
+                            SMHIP_LAUNCH_CHECK("tile_shift_kernel");
+                            return SMHIP_OK;
+                        }
+                    }
+                }
+#endif
                 auto go = [&](auto qb_tag) {
                     constexpr int QB = decltype(qb_tag)::value;
                     if (L.ma == 1 && L.mb == 1) hipLaunchKernelGGL((tile_kernel<T, Op, true, 1, 1, QB>), grid, block, 0, s, a, b, out, L.p.tile);

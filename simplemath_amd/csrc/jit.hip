@@ -246,6 +246,7 @@ typedef __INT32_TYPE__ int32_t;
 typedef __INT64_TYPE__ int64_t;
 typedef __UINT64_TYPE__ uint64_t;
 typedef __SIZE_TYPE__ size_t;
+typedef __UINTPTR_TYPE__ uintptr_t;
 #define SMHIP_MAX_NDIM 6
 template <typename T> struct VecTraits;
 #define SMHIP_VEC(T, N) template <> struct VecTraits<T> { typedef T full_t __attribute__((ext_vector_type(N))); \

@@ -99,6 +99,60 @@ for dt, bar in ((np.float32, 1), (np.float64, 1)):
                 print("MISMATCH pow", np.dtype(dt), dims, int(d.max()))
                 sys.exit(1)
             cases += 1
+# output rows off the 128-byte lines (inner extents like 1031): with the wide patch (SMHIP_TILE_QB=1024, or unforced past the
+# Infinity Cache) these take tile_shift_body -- patch rows cut at the output's LINES, each row at its own shift.  One and two
+# turned operands, either side, non-commutative Ops, slices of a third axis, operand views at offset bases, a constant direct
+# operand (column), every element type; extents around the patch sizes so that the first / last windows hang over the rows' ends.
+for t, dims in enumerate(((300, 1031), (257, 517), (1000, 773), (3, 260, 1029), (512, 2049), (640, 1283), (259, 514), (2, 300, 643), (1030, 1030))):
+    dtn = ("f32", "f64", "i32")[t % 3]
+    dt = DT[dtn]
+    P, Q = dims[-2], dims[-1]
+    lead = list(dims[:-2])
+    a = gen.gen(dt, int(np.prod(dims)), 1200 + t, "uniform").reshape(lead + [Q, P])   # stored (.., Q, P), used turned
+    b = gen.gen(dt, int(np.prod(dims)), 1300 + t, "uniform").reshape(lead + [P, Q])
+    wide = gen.gen(dt, int(np.prod(lead + [P, Q + 9])), 1400 + t, "uniform").reshape(lead + [P, Q + 9])
+    da, db, dwide = smhip.to_device(a), smhip.to_device(b), smhip.to_device(wide)
+    turn = lambda x: np.swapaxes(x, -1, -2)
+    at, bview = turn(a), wide[..., 5:5 + Q]   # a direct operand at an offset base with a pitch of its own
+    for opn, f in (("sub", np.subtract), ("add", np.add)):
+        for (x, dx, y, dy) in ((at, da.view_like(at, a), b, db), (b, db, at, da.view_like(at, a)), (at, da.view_like(at, a), bview, dwide.view_like(bview, wide))):
+            got = smhip.binary(sma.OPS[opn], dx, dy).numpy()
+            if not np.array_equal(got, f(x, y)):
+                bad = np.argwhere(got != f(x, y))
+                print("MISMATCH rows off the lines", dtn, opn, dims, len(bad), bad[:4].tolist()); sys.exit(1)
+            cases += 1
+    # both turned
+    bt_store = np.ascontiguousarray(turn(b))
+    dbt = smhip.to_device(bt_store)
+    got = smhip.binary(sma.OPS["sub"], da.view_like(at, a), dbt.view_like(turn(bt_store), bt_store)).numpy()
+    if not np.array_equal(got, at - b):
+        print("MISMATCH rows off the lines, both turned", dtn, dims); sys.exit(1)
+    # a turned operand against one value per row, and the plain transposed copy
+    if not lead:
+        col = gen.gen(dt, P, 1500 + t, "uniform").reshape(P, 1)
+        dcol = smhip.to_device(col)
+        got = smhip.binary(sma.OPS["sub"], dcol, da.view_like(at, a)).numpy()
+        if not np.array_equal(got, col - at):
+            print("MISMATCH rows off the lines, column - turned", dtn, dims); sys.exit(1)
+        dst = smhip.empty((P, Q), dt)
+        smhip.assign(dst, da.view_like(at, a))
+        if not np.array_equal(dst.numpy(), at):
+            print("MISMATCH rows off the lines, dst = src.T", dtn, dims); sys.exit(1)
+        cases += 2
+    cases += 1
+if len(sys.argv) > 1 and sys.argv[1] == "big":
+    # 8191 x 8703 f32 = 272 MiB per array, rows off the lines: unforced, the wide patch with shifted rows
+    P, Q = 8191, 8703
+    a = gen.gen(np.float32, P * Q, 3, "uniform").reshape(Q, P)
+    b = gen.gen(np.float32, P * Q, 4, "uniform").reshape(P, Q)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    got = smhip.binary(sma.OPS["sub"], da.view_like(a.T, a), db).numpy()
+    if not np.array_equal(got, a.T - b):
+        print("MISMATCH big, rows off the lines")
+        sys.exit(1)
+    del a, b, da, db, got
+    smhip.pool_trim()
+    cases += 1
 if len(sys.argv) > 1 and sys.argv[1] == "big":
     # 8704 x 8192 f32 = 272 MiB per array: past the Infinity Cache, so the unforced library takes the wide patch
     P, Q = 8704, 8192
