@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round 4's evidence in two GPU-box visits (each under gpurun's 20-minute cap):
+# Round 4's evidence in three GPU-box visits (each under gpurun's 20-minute cap):
 #   SMHIP_COMMIT=<sha> bash tools/gpu_round4.sh <tag> a    parity tests, smoke, the bench line (N = 1 with configs incl. "chain"; --mode single with the
-#                                                           sharded config-3 leg; per workload, replayed and cold) with rocprofv3 kernel stats of the
-#                                                           same commands, PMC traffic, the C++ benchmarks and fusion test, the small-array breakdown
+#                                                           sharded config-3 leg; per workload, replayed and cold)
+#   SMHIP_COMMIT=<sha> bash tools/gpu_round4.sh <tag> c    rocprofv3 kernel stats of the same bench commands, PMC traffic, the C++ benchmarks and fusion
+#                                                           test, the small-array breakdown, f64 pow rates
 #   SMHIP_COMMIT=<sha> bash tools/gpu_round4.sh <tag> b    rate tables: chains, cold operands on one / two queues, mid-size reductions, the r03 matrices,
 #                                                           fuzzers (chains, views, policy)
 # tools/collect_round4.sh copies the judged summaries into profiles/r04_*.
@@ -29,6 +30,8 @@ if [ "$part" = a ]; then
   for wl in bcast_mul pow add_sum chain; do
     timeout -k 10 200 python bench.py --workload $wl --setting cold --no-cpu-baseline > $out/bench_${wl}_cold.json 2> $out/bench_${wl}_cold.err; echo "bench $wl cold rc=$?"
   done
+  echo "part a done"
+elif [ "$part" = c ]; then
   prof add --steps 200 --warmup 20 --no-cpu-baseline --configs none
   for wl in bcast_mul pow add_sum transpose_add chain; do prof $wl --workload $wl --steps 200 --warmup 3 --no-cpu-baseline --configs none; done
   for wl in bcast_mul pow add_sum chain; do prof ${wl}_cold --workload $wl --setting cold --steps 200 --warmup 20 --no-cpu-baseline --configs none; done
@@ -44,7 +47,8 @@ from oracle import oracle as orc
 r = orc.Reference()
 print('the reference on this host (oracle/ref_shim.cpp: ref_bench_tiny), ns per iteration: simple_check %.0f  BM_SMArrayPow_1D %.0f  BM_SMArrayPow_2D %.0f' % tuple(r.bench_tiny(k, 300000) for k in range(3)))" >> $out/small_breakdown.txt 2>&1
   tail -4 $out/small_breakdown.txt
-  echo "part a done"
+  timeout -k 10 200 python tools/pow64_rate.py > $out/pow64_rate.txt 2>&1; tail -14 $out/pow64_rate.txt
+  echo "part c done"
 else
   timeout -k 10 300 python tools/chain_fused_rates.py > $out/chain_fused_rates.txt 2>&1; cat $out/chain_fused_rates.txt
   for q in 2 1; do echo "SMHIP_QUEUES=$q"; SMHIP_QUEUES=$q timeout -k 10 300 python tools/cold_rates.py --sizes 8,16,32,64,128,256; done > $out/cold_rates_queues.txt 2>&1; echo "cold rates rc=$?"
