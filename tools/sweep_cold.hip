@@ -125,6 +125,7 @@ template <int MODE> void add_mode(std::vector<Variant> &v) {
 int main(int argc, char **argv) {
     const bool same = argc > 1 && !strcmp(argv[1], "same");
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const bool streams_only = argc > 1 && !strcmp(argv[1], "streams");  // only the last section: the rotate sequence over 1 ... 4 streams
     const size_t slab_bytes = (size_t)6 << 30;
     float *slab;
     CK(hipMalloc(&slab, slab_bytes));
@@ -158,6 +159,7 @@ int main(int argc, char **argv) {
         return ms[2];
     };
 
+    if (!streams_only) {
     // ---- dispatch alone: empty kernels with the grids the shapes above use
     printf("# empty-kernel dispatch (back to back on one stream), us per launch and waves per us\n");
     for (size_t mib : {16, 64, 128}) {
@@ -208,11 +210,16 @@ int main(int argc, char **argv) {
         }
     }
 
-    // ---- the rotate sequence dealt over two streams: launches on different streams are independent, so one's ramp can
-    // cover the other's drain.  (Diagnosis only: a library stream is in order.)
-    printf("\n# two streams alternating, rotate, library-like shapes: us per launch (wall over both streams)\n");
+    }  // !streams_only
+    // ---- the rotate sequence dealt over 1 ... 4 streams: launches on different streams are independent, so one's ramp can
+    // cover the other's drain -- and the hardware runs them side by side.  (r03: two streams, diagnosis only; r04: the library
+    // does this on two queues; would three or four buy more?)
+    hipStream_t ss[4] = {s0, s1, nullptr, nullptr};
+    CK(hipStreamCreate(&ss[2]));
+    CK(hipStreamCreate(&ss[3]));
+    printf("\n# 1 ... 4 streams in turn, rotate, library-like shapes: us per launch (wall over all streams)\n");
     for (int mode = 0; mode < 3; ++mode) {
-        for (size_t mib : {16, 64, 128}) {
+        for (size_t mib : {16, 32, 64, 128}) {
             const size_t n = (mib << 20) / 4, n_vec = n / 4;
             const int arrays = mode == 1 ? 3 : 2;
             const double bytes = (double)arrays * n * 4 + (mode == 2 ? 16384 : 0);
@@ -223,33 +230,38 @@ int main(int argc, char **argv) {
                 if (v.mode != mode) continue;
                 if (v.name.find("ld=nt") == std::string::npos || v.name.find("st=nt ") == std::string::npos) continue;
                 if (v.name.find("tile    wg256  U1") == std::string::npos && v.name.find("tile    wg256  U2") == std::string::npos) continue;
-                int seq = 0;
-                auto body = [&](hipStream_t st_) {
-                    const int i = seq++;
-                    float *base = slab + (size_t)(i % K) * set_floats;
-                    v.launch(base, mode == 1 ? base + n : row, base + (size_t)(arrays - 1) * n, n_vec, st_);
-                };
-                for (int i = 0; i < 24; ++i) body(i & 1 ? s1 : s0);
-                CK(hipDeviceSynchronize());
-                std::vector<float> us;
-                for (int r = 0; r < 5; ++r) {
-                    hipEvent_t j;
-                    CK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
-                    CK(hipEventRecord(e0, s0));
-                    CK(hipStreamWaitEvent(s1, e0, 0));
-                    for (int i = 0; i < 80; ++i) body(i & 1 ? s1 : s0);
-                    CK(hipEventRecord(j, s1));
-                    CK(hipStreamWaitEvent(s0, j, 0));
-                    CK(hipEventRecord(e1, s0));
-                    CK(hipEventSynchronize(e1));
-                    float ms;
-                    CK(hipEventElapsedTime(&ms, e0, e1));
-                    us.push_back(ms * 1e3f / 80);
-                    CK(hipEventDestroy(j));
+                for (int ns = streams_only ? 1 : 2; ns <= (streams_only ? 4 : 2); ++ns) {
+                    int seq = 0;
+                    auto body = [&](hipStream_t st_) {
+                        const int i = seq++;
+                        float *base = slab + (size_t)(i % K) * set_floats;
+                        v.launch(base, mode == 1 ? base + n : row, base + (size_t)(arrays - 1) * n, n_vec, st_);
+                    };
+                    for (int i = 0; i < 24; ++i) body(ss[i % ns]);
+                    CK(hipDeviceSynchronize());
+                    std::vector<float> us;
+                    for (int r = 0; r < 5; ++r) {
+                        hipEvent_t j[4];
+                        CK(hipEventRecord(e0, s0));
+                        for (int q = 1; q < ns; ++q) CK(hipStreamWaitEvent(ss[q], e0, 0));
+                        for (int i = 0; i < 96; ++i) body(ss[i % ns]);
+                        for (int q = 1; q < ns; ++q) {
+                            CK(hipEventCreateWithFlags(&j[q], hipEventDisableTiming));
+                            CK(hipEventRecord(j[q], ss[q]));
+                            CK(hipStreamWaitEvent(s0, j[q], 0));
+                        }
+                        CK(hipEventRecord(e1, s0));
+                        CK(hipEventSynchronize(e1));
+                        float ms;
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        us.push_back(ms * 1e3f / 96);
+                        for (int q = 1; q < ns; ++q) CK(hipEventDestroy(j[q]));
+                    }
+                    std::sort(us.begin(), us.end());
+                    printf("%dstreams %4zu MiB m%d %-44s %8.2f us %6.1f %%\n", ns, mib, mode, v.name.c_str(), us[2], bytes / (us[2] * 1e-6) / 8e12 * 100);
                 }
-                std::sort(us.begin(), us.end());
-                printf("2streams %4zu MiB m%d %-44s %8.2f us %6.1f %%\n", mib, mode, v.name.c_str(), us[2], bytes / (us[2] * 1e-6) / 8e12 * 100);
             }
+            fflush(stdout);
         }
     }
     return 0;
