@@ -14,6 +14,10 @@
 int main() {
     using namespace minibench;
     auto sync = [] { sm::synchronize(); };
+    {
+        sm::SMArray<float> w = {1, 2, 3, 4};
+        warm_device([&] { auto r = w + w; DoNotOptimize(r); }, sync);
+    }
     header();
 
     print(run("simple_check", [] {  // benchmark/add.cpp:4-19: build a 5x5 array and add it to itself

@@ -43,6 +43,19 @@ inline Result run(const std::string &name, const std::function<void()> &body, co
     return {name, total / iters * 1e9, iters};
 }
 
+// The first benchmark of a process otherwise pays for the device leaving its idle state: the launch path of a GPU that has
+// been idle is ~0.4 us per launch slower for the first second or so (BM_SMArrayPow_1D as the first benchmark 3.24 us, the same
+// body after others 2.84 us -- profiles/r04_small_array_breakdown.txt).  Google Benchmark's own iteration search runs a body for
+// about that long before the run it reports; this does it once per process.
+inline void warm_device(const std::function<void()> &body, const std::function<void()> &sync, double seconds = 1.0) {
+    using clock = std::chrono::steady_clock;
+    auto t0 = clock::now();
+    do {
+        for (int i = 0; i < 256; ++i) body();
+    } while (std::chrono::duration<double>(clock::now() - t0).count() < seconds);
+    sync();
+}
+
 inline void header() {
     std::printf("%-34s %15s %12s\n", "Benchmark", "Time", "Iterations");
     std::printf("%s\n", std::string(63, '-').c_str());

@@ -10,6 +10,10 @@
 int main() {
     using namespace minibench;
     auto sync = [] { sm::synchronize(); };
+    {
+        sm::SMArray<int> w = {1, 2, 3, 4};
+        warm_device([&] { auto r = sm::pow(w, 2); DoNotOptimize(r); }, sync);
+    }
     header();
     {
         sm::SMArray<int> arr1d = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10};  // benchmark/pow.cpp:5-14
