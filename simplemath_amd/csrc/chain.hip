@@ -57,7 +57,7 @@ struct ChainArgs {
     FastDiv spl_c[kMaxSplat];    // values before the operand repeats
     uint32_t spl_r0[kMaxSplat];  // this launch's first element (vector) within its run of R
     uint32_t spl_q0[kMaxSplat];  // ... and the run's number, mod C
-    uint32_t spl_elem[kMaxSplat];  // 1: R is not a whole number of vectors -- one index per element
+    uint32_t spl_elem[kMaxSplat];  // 1: R is not a whole number of vectors -- one index per element; 2: one element per WAVE (R a whole number of waves' worth)
     uint32_t n_stages, head;     // head: the slot r starts from
     uint32_t stage[kMaxStages];  // op | slot << 8 | swapped << 16: whole words, so that the stages are scalar loads at fixed offsets
     T scalar[kMaxStages];
@@ -113,7 +113,11 @@ __device__ __forceinline__ void chain_small_loads(const ChainArgs<T> &A, uint32_
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        if (A.spl_elem[k]) {
+        if (A.spl_elem[k] == 2) {  // wave-uniform (run_segment): no vector instruction until the splat itself
+            uint32_t q, m;
+            A.spl_c[k].divmod(A.spl_q0[k] + A.spl_r[k].div(A.spl_r0[k] + (uint32_t)__builtin_amdgcn_readfirstlane((int)(v & ~63u))), q, m);
+            s[k] = splat_of<T>(A.spl[k][__builtin_amdgcn_readfirstlane((int)m)]);
+        } else if (A.spl_elem[k]) {
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 uint32_t q, m;
@@ -415,6 +419,10 @@ int run_segment(const Problem &pb, const Segment &sg, void *out_, hipStream_t s)
             A.spl_c[k] = FastDiv((uint32_t)spls[k]->C);
             A.spl_r0[k] = (uint32_t)(at % r);
             A.spl_q0[k] = (uint32_t)((at / r) % spls[k]->C);
+            // a wave's 64 vectors are consecutive and start at a multiple of 64: with R a whole number of those, and the piece
+            // starting on one, every lane of a wave wants the SAME element -- the index is scalar arithmetic and one scalar load
+            static const bool uniform_ok = [] { const char *e = getenv("SMHIP_CHAIN_UNIFORM_SPLAT"); return !(e && *e && atoi(e) == 0); }();
+            if (!elem && uniform_ok && r % 64 == 0 && A.spl_r0[k] % 64 == 0) A.spl_elem[k] = 2;
         }
         if (int rc = launch_variant<T>(nd, nr, ns, A, out + v0 * W, nv, last ? tail : 0, pol, s)) return rc;
         if (last) break;

@@ -86,6 +86,22 @@ def test_chain_row_column_scalar(smhip, oracle, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_chain_per_row_and_per_channel_values(smhip, oracle, dt):
+    """(A - mean) / std with one value per row, and per channel of an NCHW batch: rows / planes that are a whole number of
+    waves' worth of vectors take the wave-uniform index (one scalar load per wave), the others the per-lane one -- both against
+    the oracle, with a plane count that makes the channel index wrap."""
+    rng = np.random.default_rng(12)
+    for shape, small in [((96, 512), (96, 1)), ((33, 1280), (33, 1)), ((40, 260), (40, 1)),
+                         ((5, 7, 16, 16), (1, 7, 1, 1)), ((3, 4, 32, 24), (1, 4, 1, 1)), ((2, 3, 10, 26), (1, 3, 1, 1)), ((6, 2, 64, 8), (6, 2, 1, 1))]:
+        A = _rand(rng, shape, dt)
+        mean, std = _rand(rng, small, dt), _rand(rng, small, dt)
+        std[std == 0] = 1
+        tag = f"{np.dtype(dt).name} {shape} {small}"
+        _run(smhip, oracle, A, [(sma.OP_SUB, mean), (sma.OP_DIV, std)], tag + " (A-mean)/std")
+        _run(smhip, oracle, A, [(sma.OP_SUB, mean, True), (sma.OP_MUL, std), (sma.OP_ADD, A)], tag + " (mean-A)*std+A")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=lambda d: np.dtype(d).name)
 def test_chain_periodic_4d(smhip, oracle, dt):
     """The reference tests' broadcast pattern, (N,224,224,3) o (1,224,1,3) (tests/add.cpp:59-92), inside a chain; a
     per-channel bias (1,C,1,1); a 3-element period (rows of 3 are not whole vectors)."""
