@@ -574,6 +574,12 @@ class Smhip:
         self._ck(self.c.smhip_queue_stats(C.byref(q), C.byref(alt), C.byref(edges)))
         return q.value, alt.value, edges.value
 
+    def tiny_stats(self):
+        """(launches that carried recorded tiny operators, operators they carried) on this thread's device (csrc/tiny.hip)"""
+        launches, ops = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._ck(self.c.smhip_tiny_stats(C.byref(launches), C.byref(ops)))
+        return launches.value, ops.value
+
     def launch_pieces(self, bytes_per_operand, streams=3):
         """Kernel launches a dense streaming operator over operands of this size goes out as (streams: 3 a op b, 2 a op s / dot, 1 sum)."""
         k = C.c_int(0)

@@ -21,6 +21,13 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int acquire(hipStream_t *stream);
 // The same without touching the queues: the caller's stream, or the device's first library queue.
 int acquire_stream(hipStream_t *stream);
+// tiny.hip: operators on tiny arrays are recorded and go out several to a launch; acquire_stream() flushes them first.
+int tiny_flush_device(int dev);
+bool tiny_defer_free(int dev, void *p, size_t bytes);
+bool tiny_context(int *dev);  // runtime.hip: may the calling thread record a tiny operator now?
+int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *sa, const void *b, size_t b_host_bytes,
+                     const int64_t *sb, const int64_t *shape, int ndim, const void *scalar_host, void *out, bool *taken);
+void tiny_stats(int dev, unsigned long long *launches, unsigned long long *operators);
 // Second library queue of `dev` off (true) / on again (false); see runtime.hip "two queues per device".
 void dispatch_single_queue(int dev, bool single);
 

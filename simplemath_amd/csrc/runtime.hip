@@ -485,7 +485,20 @@ int acquire(hipStream_t *stream) {
     return SMHIP_OK;
 }
 
+namespace {
+int acquire_stream_quietly(hipStream_t *stream);
+}
 int acquire_stream(hipStream_t *stream) {
+    if (int rc = acquire_stream_quietly(stream)) return rc;
+    // whoever wants the library's stream is about to queue or observe something: the tiny operators recorded so far go first
+    // (tiny.hip).  Not from inside an operator -- its own begin() has been here already -- and not on a caller's stream.
+    if (tls.op_depth == 0 && !tls.use_user_stream) return tiny_flush_device(tls.device);
+    return SMHIP_OK;
+}
+namespace {
+// ... without that: smhip_alloc selects the device and may order a recycled block behind its previous users, but it neither
+// queues nor observes results.
+int acquire_stream_quietly(hipStream_t *stream) {
     {
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_device_count < 0) {
@@ -518,10 +531,28 @@ int acquire_stream(hipStream_t *stream) {
         *stream = tls.user_stream;
         return SMHIP_OK;
     }
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (!g_streams[tls.device]) SMHIP_TRY(hipStreamCreateWithFlags(&g_streams[tls.device], hipStreamNonBlocking));
-    *stream = g_streams[tls.device];
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!g_streams[tls.device]) SMHIP_TRY(hipStreamCreateWithFlags(&g_streams[tls.device], hipStreamNonBlocking));
+        *stream = g_streams[tls.device];
+    }
     return SMHIP_OK;
+}
+}  // namespace
+
+// Is the calling thread in a state in which a tiny operator may be recorded instead of launched: on the library's queue of a
+// device that has been checked, outside any operator?
+bool tiny_context(int *dev) {
+    const int d = tls.device;
+    if (d < 0 || tls.use_user_stream || tls.op_depth != 0 || !tls.checked[d] || !g_streams[d]) return false;
+    {   // a caller that holds the library's stream handle (smhip_get_stream) or drives the device group orders its own work by
+        // what it has seen enqueued: on such a device every operator is a launch at once, as on one queue
+        Dispatch &q = g_dispatch[d];
+        std::lock_guard<std::recursive_mutex> lock(q.m);
+        if (q.single) return false;
+    }
+    *dev = d;
+    return true;
 }
 
 size_t piece_for(size_t n_vec, int streams) {
@@ -808,7 +839,7 @@ int smhip_synchronize(void) {
 int smhip_alloc(void **dptr, size_t bytes) {
     if (!dptr) return fail(SMHIP_ERR_INVALID, "alloc: null");
     hipStream_t s;  // no operator: the queues are not touched (who uses the bytes, and on which queue, is the operators' business)
-    if (int rc = acquire_stream(&s)) return rc;
+    if (int rc = acquire_stream_quietly(&s)) return rc;
     const size_t cls = size_class(bytes);
     const int dev = tls.device;
     void *p = nullptr;
@@ -892,6 +923,16 @@ int smhip_alloc(void **dptr, size_t bytes) {
 
 int smhip_free(void *dptr) {
     if (!dptr) return SMHIP_OK;
+    {   // a recorded tiny operator may still refer to it: then the block goes back to the pool after that launch (tiny.hip)
+        int dev = -1;
+        size_t cls = 0;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            auto it = g_live.find(dptr);
+            if (it != g_live.end()) { dev = it->second.device; cls = it->second.cls; }
+        }
+        if (dev >= 0 && tiny_defer_free(dev, dptr, cls)) return SMHIP_OK;
+    }
     Block b;
     {
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -960,7 +1001,13 @@ int smhip_pool_trim(void) {
     return SMHIP_OK;
 }
 
+int smhip_tiny_stats(unsigned long long *launches, unsigned long long *operators) {
+    tiny_stats(tls.device < 0 ? 0 : tls.device, launches, operators);
+    return SMHIP_OK;
+}
+
 int smhip_pool_stats(size_t *bytes_in_use, size_t *bytes_cached) {
+    if (tls.device >= 0 && !tls.use_user_stream && tls.op_depth == 0) (void)tiny_flush_device(tls.device);  // blocks freed under a recorded tiny operator return with its launch
     std::lock_guard<std::mutex> lock(g_mutex);
     if (bytes_in_use) *bytes_in_use = g_bytes_live;
     if (bytes_cached) *bytes_cached = g_bytes_cached;
@@ -1104,6 +1151,11 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
     const size_t esz = dtype_size(dtype);
+    if (n <= 1024) {  // tiny: recorded, several operators to a launch (tiny.hip)
+        bool taken;
+        if (int rc = tiny_try_enqueue(op, dtype, a, 0, stride_a, b, 0, stride_b, shape, ndim, nullptr, out, &taken)) return rc;
+        if (taken) return SMHIP_OK;
+    }
     SMHIP_ACQUIRE_OP(s, (Span{out, (size_t)n * esz}), Span{a, span_bytes(shape, stride_a, ndim, esz)}, Span{b, span_bytes(shape, stride_b, ndim, esz)});
     return launch_broadcast(op, dtype, a, stride_a, b, stride_b, shape, ndim, out, s);
 }
@@ -1128,6 +1180,11 @@ int smhip_elementwise_inline(int op, int dtype, const void *a, size_t a_host_byt
     const int64_t esz = (int64_t)dtype_size(dtype);
     if ((a_host_bytes && (span_a + 1) * esz > (int64_t)a_host_bytes) || (b_host_bytes && (span_b + 1) * esz > (int64_t)b_host_bytes))
         return fail(SMHIP_ERR_INVALID, "elementwise_inline: the strides reach past the inline operand's bytes");
+    if (n <= 1024) {
+        bool taken;
+        if (int rc = tiny_try_enqueue(op, dtype, a, a_host_bytes, stride_a, b, b_host_bytes, stride_b, shape, ndim, nullptr, out, &taken)) return rc;
+        if (taken) return SMHIP_OK;
+    }
     SMHIP_ACQUIRE(s);
     return launch_inline(op, dtype, a, a_host_bytes, stride_a, b, b_host_bytes, stride_b, shape, ndim, out, s);
 }
@@ -1191,6 +1248,12 @@ int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out,
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "contiguous: null buffer");
     const size_t nbytes = n * dtype_size(dtype);
+    if (n <= 1024) {
+        const int64_t one = 1, shape1 = (int64_t)n;
+        bool taken;
+        if (int rc = tiny_try_enqueue(op, dtype, a, 0, &one, b, 0, &one, &shape1, 1, nullptr, out, &taken)) return rc;
+        if (taken) return SMHIP_OK;
+    }
     SMHIP_ACQUIRE_OP(s, (Span{out, nbytes}), Span{a, nbytes}, Span{b, nbytes});
     if (user_op(op)) return jit_contiguous(op, dtype, a, b, out, n, s);
     return launch_contiguous(op, dtype, a, b, out, n, s);
@@ -1201,6 +1264,12 @@ int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host,
     if (n == 0) return SMHIP_OK;
     if (!a || !value_host || !out) return fail(SMHIP_ERR_INVALID, "array_scalar: null buffer");
     const size_t nbytes = n * dtype_size(dtype);
+    if (n <= 1024) {
+        const int64_t one = 1, zero = 0, shape1 = (int64_t)n;
+        bool taken;
+        if (int rc = tiny_try_enqueue(op, dtype, a, 0, &one, nullptr, 0, &zero, &shape1, 1, value_host, out, &taken)) return rc;
+        if (taken) return SMHIP_OK;
+    }
     SMHIP_ACQUIRE_OP(s, (Span{out, nbytes}), Span{a, nbytes});
     if (user_op(op)) return jit_array_scalar(op, dtype, a, value_host, n, out, s);
     return launch_array_scalar(op, dtype, a, value_host, n, out, s);

@@ -1,0 +1,289 @@
+// tiny.hip -- operators on tiny arrays, several to a launch.
+//
+// The reference's smallest benchmarks apply ONE operator to a 5 x 5 or a 10-element array (benchmark/add.cpp:4-19,
+// benchmark/pow.cpp:5-28): 0.2-0.6 us on a CPU core.  A kernel launch costs the host ~2.5-3.5 us whatever the kernel does
+// (profiles/r04_small_array_breakdown.txt: empty kernels back to back, any-order or not), so one launch per operator can
+// never come near that -- but nothing says an operator must be a launch of its own.  The library's calls are asynchronous
+// already: the caller sees a result only through another library call (a read-back, a synchronisation, an operator that
+// consumes it, the stream handle).  So an eligible tiny operator is RECORDED -- its descriptor and, for host-built
+// operands, their bytes, appended to a per-device block -- and the block goes out as ONE launch (one workgroup per
+// operator) when
+//   * it is full (24 operators or ~3.9 KiB of descriptors),
+//   * a new tiny operator depends on a recorded one (reads or overwrites what it writes, overwrites what it reads):
+//     the operators of one launch run side by side,
+//   * ANY other library call on the device acquires the stream (operators, uploads, read-backs, synchronisation, events,
+//     the stream handle, peer copies): runtime.hip's acquire_stream() flushes first, so every observation point sees
+//     what call order promises.
+// A buffer freed while a recorded operator still refers to it (the benchmark bodies' `auto result = ...` dies at the end
+// of each iteration) is handed back to the pool only after the launch: the next result gets another block, and the
+// operators stay independent.  Eligible: + - * / of every element type and integer pow (Op::apply -- the very functions
+// the vector kernels' scalar tails use, so results are bit-identical to the one-launch path), at most 1024 results,
+// operands of any strides (views, broadcasts) or host-built (<= 256 bytes), the output overlapping no operand, the
+// library's own queue (not a caller's stream).  SMHIP_TINY_BATCH=0 turns it off.
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+#include "internal.h"
+#include "ops.hip.h"
+
+namespace smhip {
+namespace {
+
+using namespace dev;
+
+constexpr int kTinyMaxOps = 24;
+constexpr uint32_t kTinyMaxOut = 1024;
+constexpr size_t kTinyMaxInline = 256;
+constexpr int kTinySmallBytes = 960, kTinyBigBytes = 3904;  // argument blocks of 1 KiB and ~3.9 KiB (the launch writes the block it is given)
+constexpr int kTinyDevices = 64;
+
+struct TinyOp {
+    uint8_t op, dtype, ndim, flags;  // flags bit 0: b is `scalar` (array_scalar)
+    uint32_t n;
+    uint32_t shape[SMHIP_MAX_NDIM];  // innermost first
+    uint32_t sa[SMHIP_MAX_NDIM], sb[SMHIP_MAX_NDIM];
+    uint64_t a, b, out;
+    uint64_t scalar;
+    uint16_t a_inl, b_inl;  // byte offset of the operand's bytes from this descriptor's start; 0: `a` / `b` is a device pointer
+    uint32_t pad[3];
+};
+static_assert(sizeof(TinyOp) == 128, "descriptor layout");
+
+template <int BYTES> struct alignas(16) TinyArgs {
+    uint32_t n_ops;
+    uint16_t off[kTinyMaxOps];
+    uint32_t pad[3];
+    unsigned char bytes[BYTES];
+};
+static_assert(offsetof(TinyArgs<kTinySmallBytes>, bytes) == 64 && sizeof(TinyArgs<kTinySmallBytes>) == 1024, "argument block layout");
+static_assert(sizeof(TinyArgs<kTinyBigBytes>) <= 4096, "one argument block");
+
+template <typename T, typename Op>
+__device__ __forceinline__ void tiny_run(const TinyOp *d, const char *base) {
+    const T *a = d->a_inl ? reinterpret_cast<const T *>(base + d->a_inl) : reinterpret_cast<const T *>(d->a);
+    const T *b = d->b_inl ? reinterpret_cast<const T *>(base + d->b_inl) : reinterpret_cast<const T *>(d->b);
+    T *out = reinterpret_cast<T *>(d->out);
+    const bool b_scalar = d->flags & 1;
+    T sv;
+    {
+        const uint64_t bits = d->scalar;
+        __builtin_memcpy(&sv, &bits, sizeof(T));
+    }
+    const int nd = d->ndim;
+    const uint32_t n = d->n;
+    for (uint32_t e = threadIdx.x; e < n; e += 64) {
+        uint32_t rem = e, oa = 0, ob = 0;
+        for (int k = 0; k < nd; ++k) {
+            const uint32_t ext = d->shape[k];
+            const uint32_t idx = k == nd - 1 ? rem : rem % ext;
+            rem /= ext;
+            oa += idx * d->sa[k];
+            ob += idx * d->sb[k];
+        }
+        out[e] = Op::apply(a[oa], b_scalar ? sv : b[ob]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tiny_dtype(const TinyOp *d, const char *base) {
+    switch (d->op) {
+        case SMHIP_OP_ADD: tiny_run<T, AddOp<T>>(d, base); break;
+        case SMHIP_OP_SUB: tiny_run<T, SubtractOp<T>>(d, base); break;
+        case SMHIP_OP_MUL: tiny_run<T, MultiplyOp<T>>(d, base); break;
+        case SMHIP_OP_DIV: tiny_run<T, DivideOp<T>>(d, base); break;
+        default:
+            if constexpr (std::is_integral<T>::value) tiny_run<T, PowOp<T>>(d, base);
+            break;
+    }
+}
+// One workgroup of one wave per recorded operator; the descriptors are read from the argument block itself.
+template <int BYTES>
+__global__ __launch_bounds__(64) void tiny_batch_kernel(TinyArgs<BYTES> args) {
+    (void)args;  // read through the kernarg pointer: indexing the by-value copy would spill it to scratch (inline.hip)
+    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t off = reinterpret_cast<const uint16_t *>(ka + offsetof(TinyArgs<BYTES>, off))[blockIdx.x];
+    const char *base = ka + offsetof(TinyArgs<BYTES>, bytes) + off;
+    const TinyOp *d = reinterpret_cast<const TinyOp *>(base);
+    switch (d->dtype) {
+        case SMHIP_F32: tiny_dtype<float>(d, base); break;
+        case SMHIP_F64: tiny_dtype<double>(d, base); break;
+        case SMHIP_I32: tiny_dtype<int32_t>(d, base); break;
+        default: tiny_dtype<int64_t>(d, base); break;
+    }
+}
+
+struct TinyQueue {
+    std::recursive_mutex m;
+    int count = 0;
+    size_t used = 0;
+    uint16_t off[kTinyMaxOps];
+    alignas(16) unsigned char bytes[kTinyBigBytes];
+    Span reads[2 * kTinyMaxOps], writes[kTinyMaxOps];
+    int n_reads = 0;
+    std::vector<void *> deferred;  // freed while recorded operators refer to them
+    bool flushing = false;
+    unsigned long long launches = 0, operators = 0;
+};
+TinyQueue g_tiny[kTinyDevices];
+std::atomic<int> g_tiny_pending{0};
+
+bool overlap(const Span &x, const Span &y) {
+    if (!x.p || !y.p || !x.bytes || !y.bytes) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(x.p), b = reinterpret_cast<uintptr_t>(y.p);
+    return a < b + y.bytes && b < a + x.bytes;
+}
+
+// Launches what is recorded.  Caller holds q.m.
+int flush_locked(TinyQueue &q) {
+    if (q.count == 0 || q.flushing) return SMHIP_OK;
+    q.flushing = true;  // the launch below acquires the stream, whose hook comes back here
+    int rc = SMHIP_OK;
+    {
+        hipStream_t s;
+        OpScope scope;
+        rc = scope.begin_barrier(&s);
+        if (rc == SMHIP_OK) {
+            if (q.used <= (size_t)kTinySmallBytes) {
+                TinyArgs<kTinySmallBytes> args;
+                args.n_ops = (uint32_t)q.count;
+                memcpy(args.off, q.off, sizeof args.off);
+                memcpy(args.bytes, q.bytes, q.used);
+                hipLaunchKernelGGL((tiny_batch_kernel<kTinySmallBytes>), dim3((unsigned)q.count), dim3(64), 0, s, args);
+            } else {
+                TinyArgs<kTinyBigBytes> args;
+                args.n_ops = (uint32_t)q.count;
+                memcpy(args.off, q.off, sizeof args.off);
+                memcpy(args.bytes, q.bytes, q.used);
+                hipLaunchKernelGGL((tiny_batch_kernel<kTinyBigBytes>), dim3((unsigned)q.count), dim3(64), 0, s, args);
+            }
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "tiny operators (%d in one launch): %s", q.count, hipGetErrorString(e));
+        }
+    }
+    ++q.launches;
+    q.operators += (unsigned long long)q.count;
+    g_tiny_pending.fetch_sub(q.count, std::memory_order_relaxed);
+    q.count = 0;
+    q.used = 0;
+    q.n_reads = 0;
+    std::vector<void *> dead;
+    dead.swap(q.deferred);
+    q.flushing = false;
+    for (void *p : dead) (void)smhip_free(p);  // ordered behind the launch like any free on the library's stream
+    return rc;
+}
+
+bool enabled() {
+    static const bool on = [] { const char *e = getenv("SMHIP_TINY_BATCH"); return !(e && *e && atoi(e) == 0); }();
+    return on;
+}
+
+}  // namespace
+
+int tiny_flush_device(int dev) {
+    if (dev < 0 || dev >= kTinyDevices) return SMHIP_OK;
+    if (g_tiny_pending.load(std::memory_order_relaxed) == 0) return SMHIP_OK;
+    TinyQueue &q = g_tiny[dev];
+    std::lock_guard<std::recursive_mutex> lock(q.m);
+    return flush_locked(q);
+}
+
+bool tiny_defer_free(int dev, void *p, size_t bytes) {
+    if (dev < 0 || dev >= kTinyDevices || g_tiny_pending.load(std::memory_order_relaxed) == 0) return false;
+    TinyQueue &q = g_tiny[dev];
+    std::lock_guard<std::recursive_mutex> lock(q.m);
+    if (q.count == 0 || q.flushing) return false;
+    const Span blk{p, bytes};
+    bool used = false;
+    for (int i = 0; i < q.count && !used; ++i) used = overlap(blk, q.writes[i]);
+    for (int i = 0; i < q.n_reads && !used; ++i) used = overlap(blk, q.reads[i]);
+    if (!used) return false;
+    q.deferred.push_back(p);
+    return true;
+}
+
+void tiny_stats(int dev, unsigned long long *launches, unsigned long long *operators) {
+    TinyQueue &q = g_tiny[dev < 0 || dev >= kTinyDevices ? 0 : dev];
+    std::lock_guard<std::recursive_mutex> lock(q.m);
+    if (launches) *launches = q.launches;
+    if (operators) *operators = q.operators;
+}
+
+// Records `out = a op b` (b an array, or the value at scalar_host) if it is eligible; *taken says whether it was.
+int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *sa, const void *b, size_t b_host_bytes,
+                     const int64_t *sb, const int64_t *shape, int ndim, const void *scalar_host, void *out, bool *taken) {
+    *taken = false;
+    if (!enabled()) return SMHIP_OK;
+    int dev;
+    if (!tiny_context(&dev) || dev >= kTinyDevices) return SMHIP_OK;
+    const bool integral = dtype == SMHIP_I32 || dtype == SMHIP_I64;
+    if (!(op == SMHIP_OP_ADD || op == SMHIP_OP_SUB || op == SMHIP_OP_MUL || op == SMHIP_OP_DIV || (op == SMHIP_OP_POW && integral))) return SMHIP_OK;
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM || a_host_bytes > kTinyMaxInline || b_host_bytes > kTinyMaxInline) return SMHIP_OK;
+    const size_t esz = dtype_size(dtype);
+    uint64_t n = 1, span_a = 0, span_b = 0;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0) return SMHIP_OK;
+        n *= (uint64_t)shape[i];
+        if (n > kTinyMaxOut) return SMHIP_OK;
+        span_a += (uint64_t)(shape[i] - 1) * (uint64_t)sa[i];
+        if (!scalar_host) span_b += (uint64_t)(shape[i] - 1) * (uint64_t)sb[i];
+        if (span_a >= (1ull << 31) || span_b >= (1ull << 31)) return SMHIP_OK;
+    }
+    const Span w{out, (size_t)n * esz};
+    const Span ra{a_host_bytes ? nullptr : a, a_host_bytes ? 0 : (size_t)(span_a + 1) * esz};
+    const Span rb{(b_host_bytes || scalar_host) ? nullptr : b, (b_host_bytes || scalar_host) ? 0 : (size_t)(span_b + 1) * esz};
+    if (overlap(w, ra) || overlap(w, rb)) return SMHIP_OK;  // in place: the one-launch path has its own rules for that
+    const size_t need = sizeof(TinyOp) + ((a_host_bytes + 15) & ~(size_t)15) + ((b_host_bytes + 15) & ~(size_t)15);
+
+    TinyQueue &q = g_tiny[dev];
+    std::lock_guard<std::recursive_mutex> lock(q.m);
+    if (q.flushing) return SMHIP_OK;
+    bool conflict = q.count == kTinyMaxOps || q.used + need > (size_t)kTinyBigBytes;
+    for (int i = 0; i < q.count && !conflict; ++i) conflict = overlap(w, q.writes[i]) || overlap(ra, q.writes[i]) || overlap(rb, q.writes[i]);
+    for (int i = 0; i < q.n_reads && !conflict; ++i) conflict = overlap(w, q.reads[i]);
+    if (conflict) {
+        if (int rc = flush_locked(q)) return rc;
+    }
+    TinyOp d{};
+    d.op = (uint8_t)op;
+    d.dtype = (uint8_t)dtype;
+    d.ndim = (uint8_t)ndim;
+    d.flags = scalar_host ? 1 : 0;
+    d.n = (uint32_t)n;
+    for (int k = 0; k < ndim; ++k) {
+        const int src = ndim - 1 - k;
+        d.shape[k] = (uint32_t)shape[src];
+        d.sa[k] = (uint32_t)sa[src];
+        d.sb[k] = scalar_host ? 0u : (uint32_t)sb[src];
+    }
+    d.a = reinterpret_cast<uint64_t>(a);
+    d.b = reinterpret_cast<uint64_t>(b);
+    d.out = reinterpret_cast<uint64_t>(out);
+    if (scalar_host) memcpy(&d.scalar, scalar_host, esz);
+    unsigned char *at = q.bytes + q.used;
+    size_t extra = sizeof(TinyOp);
+    if (a_host_bytes) {
+        d.a_inl = (uint16_t)extra;
+        memcpy(at + extra, a, a_host_bytes);
+        extra += (a_host_bytes + 15) & ~(size_t)15;
+    }
+    if (b_host_bytes) {
+        d.b_inl = (uint16_t)extra;
+        memcpy(at + extra, b, b_host_bytes);
+        extra += (b_host_bytes + 15) & ~(size_t)15;
+    }
+    memcpy(at, &d, sizeof d);
+    q.off[q.count] = (uint16_t)q.used;
+    q.writes[q.count] = w;
+    if (ra.p) q.reads[q.n_reads++] = ra;
+    if (rb.p) q.reads[q.n_reads++] = rb;
+    q.used += extra;
+    ++q.count;
+    g_tiny_pending.fetch_add(1, std::memory_order_relaxed);
+    *taken = true;
+    return SMHIP_OK;
+}
+
+}  // namespace smhip
