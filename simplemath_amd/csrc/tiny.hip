@@ -235,7 +235,8 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
     const Span ra{a_host_bytes ? nullptr : a, a_host_bytes ? 0 : (size_t)(span_a + 1) * esz};
     const Span rb{(b_host_bytes || scalar_host) ? nullptr : b, (b_host_bytes || scalar_host) ? 0 : (size_t)(span_b + 1) * esz};
     if (overlap(w, ra) || overlap(w, rb)) return SMHIP_OK;  // in place: the one-launch path has its own rules for that
-    const size_t need = sizeof(TinyOp) + ((a_host_bytes + 15) & ~(size_t)15) + ((b_host_bytes + 15) & ~(size_t)15);
+    const bool same_inline = a_host_bytes && a == b && a_host_bytes == b_host_bytes;  // `ac + ac` on a host-built array: its bytes go in once
+    const size_t need = sizeof(TinyOp) + ((a_host_bytes + 15) & ~(size_t)15) + (same_inline ? 0 : ((b_host_bytes + 15) & ~(size_t)15));
 
     TinyQueue &q = g_tiny[dev];
     std::lock_guard<std::recursive_mutex> lock(q.m);
@@ -269,7 +270,9 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
         memcpy(at + extra, a, a_host_bytes);
         extra += (a_host_bytes + 15) & ~(size_t)15;
     }
-    if (b_host_bytes) {
+    if (same_inline) {
+        d.b_inl = d.a_inl;
+    } else if (b_host_bytes) {
         d.b_inl = (uint16_t)extra;
         memcpy(at + extra, b, b_host_bytes);
         extra += (b_host_bytes + 15) & ~(size_t)15;
