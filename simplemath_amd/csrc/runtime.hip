@@ -804,7 +804,10 @@ int smhip_set_stream(void *hip_stream) {
         hipStream_t prev = tls.use_user_stream ? tls.user_stream : g_streams[tls.device];
         hipStream_t now = next ? next : g_streams[tls.device];
         if (prev && now && prev != now) {
-            if (prev == g_streams[tls.device]) queues_join(tls.device);  // the library's first queue speaks for both
+            if (prev == g_streams[tls.device]) {
+                if (!tls.use_user_stream && tls.op_depth == 0) (void)tiny_flush_device(tls.device);  // what was recorded for the library's queue is launched there first
+                queues_join(tls.device);  // the library's first queue speaks for both
+            }
             hipEvent_t e = take_event(tls.device);
             if (e) {
                 if (hipEventRecord(e, prev) == hipSuccess) (void)hipStreamWaitEvent(now, e, 0);

@@ -9,6 +9,8 @@
 //   6. the library's TWO queues per device (runtime.hip): independent operators alternate between them, and every
 //      dependency that crosses them -- read after write, write after read, write after write, a consumer on another host
 //      thread, an operator's pooled scratch -- is an event edge.
+//   7. tiny operators recorded on the library's queue (csrc/tiny.hip) against a switch to a caller's stream, a consumer on another
+//      host thread, and frees of results nobody read.
 // The reference has nothing like this (new[]/delete[] per operator, SMArray.h:219,342-346).  Exit code 0 = all held.
 #include <hip/hip_runtime.h>
 #include <smhip.h>
@@ -248,6 +250,55 @@ int main() {
         OK(smhip_free(y));
         OK(smhip_free(z));
         OK(smhip_free(u));
+    }
+    std::printf("case 7\n");
+    {  // 7. operators on tiny arrays are RECORDED on the library's queue and launched together later (csrc/tiny.hip): a thread that
+       //    switches to its own stream must find them launched -- its stream is ordered behind the library's at the switch --
+       //    and one that consumes a recorded result on another host thread, or frees it, must see call order.
+        const size_t T = 25;
+        const float one = 1.0f, two = 2.0f;
+        void *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr;
+        OK(smhip_alloc(&a, T * sizeof(float)));
+        OK(smhip_alloc(&b, T * sizeof(float)));
+        OK(smhip_alloc(&c, T * sizeof(float)));
+        OK(smhip_alloc(&d, T * sizeof(float)));
+        OK(smhip_fill(SMHIP_F32, a, &seven, T));
+        unsigned long long l0 = 0, o0 = 0, l1 = 0, o1 = 0;
+        OK(smhip_tiny_stats(&l0, &o0));
+        OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, a, &one, T, b));   // recorded: b = 8
+        OK(smhip_array_scalar(SMHIP_OP_MUL, SMHIP_F32, a, &two, T, c));   // recorded beside it: c = 14
+        OK(smhip_set_stream(s1));                                         // the switch launches them on the library's queue, s1 waits for it
+        OK(smhip_contiguous(SMHIP_OP_ADD, SMHIP_F32, b, c, d, T));        // on s1, at once: d = 22
+        CHECK(all_equal(static_cast<float *>(d), 22.0f, T));
+        OK(smhip_set_stream(nullptr));
+        OK(smhip_tiny_stats(&l1, &o1));
+        std::printf("  tiny operators recorded %llu, launches %llu\n", o1 - o0, l1 - l0);
+        CHECK(o1 - o0 == 2 && l1 - l0 == 1);
+        // a recorded result consumed by another host thread, then freed by it while the producer records more
+        OK(smhip_array_scalar(SMHIP_OP_SUB, SMHIP_F32, a, &one, T, b));   // recorded: b = 6
+        bool ok_thread = false;
+        std::thread consumer([&] {
+            OK(smhip_set_device(0));
+            void *w = nullptr;
+            OK(smhip_alloc(&w, T * sizeof(float)));
+            OK(smhip_contiguous(SMHIP_OP_MUL, SMHIP_F32, b, b, w, T));    // reads what the other thread recorded: 36
+            ok_thread = all_equal(static_cast<float *>(w), 36.0f, T);
+            OK(smhip_free(w));
+            OK(smhip_free(b));
+        });
+        consumer.join();
+        CHECK(ok_thread);
+        for (int i = 0; i < 100; ++i) {  // results that die unread, as in the benchmark bodies: their blocks come back after the launch
+            void *r = nullptr;
+            OK(smhip_alloc(&r, T * sizeof(float)));
+            OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, a, &one, T, r));
+            OK(smhip_free(r));
+        }
+        OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, a, &two, T, c));
+        CHECK(all_equal(static_cast<float *>(c), 9.0f, T));
+        OK(smhip_free(a));
+        OK(smhip_free(c));
+        OK(smhip_free(d));
     }
     OK(smhip_synchronize());
     hipStreamDestroy(s1);
