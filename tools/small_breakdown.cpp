@@ -41,6 +41,14 @@ int main() {
         void *p, *q; smhip_alloc(&p, 40); smhip_alloc(&q, 40);
         const int three = 3;
         print(run("smhip_array_scalar pow i32 n=10", [&] { smhip_array_scalar(SMHIP_OP_POW, SMHIP_I32, p, &three, 10, q); }, sync));
+        {   // the recorded path by itself (csrc/tiny.hip): independent results, so they batch
+            void *outs[64];
+            for (auto &o : outs) smhip_alloc(&o, 40);
+            unsigned k = 0;
+            print(run("smhip_array_scalar pow i32 n=10 into 64 rotating outputs (record + 1/24 launch)", [&] { smhip_array_scalar(SMHIP_OP_POW, SMHIP_I32, p, &three, 10, outs[k++ & 63]); }, sync));
+            print(run("smhip_alloc + smhip_array_scalar + smhip_free (fresh result each time)", [&] { void *t; smhip_alloc(&t, 40); smhip_array_scalar(SMHIP_OP_POW, SMHIP_I32, p, &three, 10, t); smhip_free(t); }, sync));
+            for (auto &o : outs) smhip_free(o);
+        }
         const int one = 1;
         print(run("smhip_array_scalar add i32 n=10", [&] { smhip_array_scalar(SMHIP_OP_ADD, SMHIP_I32, p, &one, 10, q); }, sync));
         print(run("smhip_fill i32 n=10", [&] { smhip_fill(SMHIP_I32, q, &one, 10); }, sync));
