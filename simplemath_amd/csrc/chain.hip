@@ -314,7 +314,12 @@ int launch_variant(int nd, int nr, int ns, const ChainArgs<T> &A, T *out, size_t
     // workgroups of 256, one vector per lane: (A * row + B) * 0.5 at 4096 x 4096 29.9 us (84 % of peak on its 12 B/elem) against
     // 31.1 with 1024 threads and 29.6 / 32.7 with two vectors per lane; at 8192 x 8192 121.5 against 137.8 / 122.9 / 140.3 us
     // (tools/chain_fused_rates.py, profiles/r04_chain_shapes.txt)
-    const int block = forced_block ? forced_block : 256;
+    // ... and 512 where no operand is a per-row / per-channel value and the output is at most 256 MiB (same box, A/B/A/B,
+    // profiles/r04_chain_block.txt: (A * row + B) * 0.5 at 4096^2 82.3 -> 84.2 %, at 8192^2 80.0 -> 83.6, on rotating operands
+    // 77.1 -> 78.8; (A + B) * 0.5 rotating 75.9 -> 78.3 -- but splat forms on rotating operands 80 -> 75 and everything at
+    // 16384 x 8192 one to five points WORSE)
+    const bool clamp_ok = forced_block >= 64 && forced_block <= 1024 && forced_block % 64 == 0;
+    const int block = clamp_ok ? forced_block : (ns == 0 && n_vec <= ((size_t)1 << 24) ? 512 : 256);
     (void)nd;
     const int u = forced_u ? forced_u : 1;
     if (u == 2) return launch_variant_u<T, 2>(nd, nr, ns, A, out, n_vec, tail, pol, block, s);
