@@ -8,9 +8,11 @@
 // consumes it, the stream handle).  So an eligible tiny operator is RECORDED -- its descriptor and, for host-built
 // operands, their bytes, appended to a per-device block -- and the block goes out as ONE launch (one workgroup per
 // operator) when
-//   * it is full (24 operators or ~3.9 KiB of descriptors),
-//   * a new tiny operator depends on a recorded one (reads or overwrites what it writes, overwrites what it reads):
-//     the operators of one launch run side by side,
+//   * it is full (30 operators or ~3.9 KiB of descriptors),
+//   * a new tiny operator depends on recorded operators of MORE THAN ONE workgroup: independent operators run side by side,
+//     one workgroup each; an operator that depends on recorded ones (reads or overwrites what they write, overwrites what
+//     they read) is appended to THEIR workgroup's list, which runs in call order with a __syncthreads() between operators
+//     -- `c = a + b; d = c * c; e = d - a` is one launch of one workgroup; only a dependency on two lists ends the recording,
 //   * ANY other library call on the device acquires the stream (operators, uploads, read-backs, synchronisation, events,
 //     the stream handle, peer copies): runtime.hip's acquire_stream() flushes first, so every observation point sees
 //     what call order promises.
@@ -34,7 +36,7 @@ namespace {
 
 using namespace dev;
 
-constexpr int kTinyMaxOps = 24;
+constexpr int kTinyMaxOps = 30;  // per launch; every one may start a list of its own
 constexpr uint32_t kTinyMaxOut = 1024;
 constexpr size_t kTinyMaxInline = 256;
 constexpr int kTinySmallBytes = 960, kTinyBigBytes = 3904;  // argument blocks of 1 KiB and ~3.9 KiB (the launch writes the block it is given)
@@ -48,17 +50,19 @@ struct TinyOp {
     uint64_t a, b, out;
     uint64_t scalar;
     uint16_t a_inl, b_inl;  // byte offset of the operand's bytes from this descriptor's start; 0: `a` / `b` is a device pointer
-    uint32_t pad[3];
+    uint16_t next;          // 1 + the byte offset (in the block) of the next operator of this workgroup's list; 0: the last one
+    uint16_t pad16;
+    uint32_t pad[2];
 };
 static_assert(sizeof(TinyOp) == 128, "descriptor layout");
 
 template <int BYTES> struct alignas(16) TinyArgs {
-    uint32_t n_ops;
-    uint16_t off[kTinyMaxOps];
-    uint32_t pad[3];
+    uint32_t n_lists;
+    uint16_t head[kTinyMaxOps];  // byte offset of each list's first operator
     unsigned char bytes[BYTES];
 };
 static_assert(offsetof(TinyArgs<kTinySmallBytes>, bytes) == 64 && sizeof(TinyArgs<kTinySmallBytes>) == 1024, "argument block layout");
+static_assert(kTinyBigBytes + 1 < 65536 && kTinyMaxOps < 256, "offsets and list numbers fit their fields");
 static_assert(sizeof(TinyArgs<kTinyBigBytes>) <= 4096, "one argument block");
 
 template <typename T, typename Op>
@@ -98,33 +102,42 @@ __device__ __forceinline__ void tiny_dtype(const TinyOp *d, const char *base) {
             break;
     }
 }
-// One workgroup of one wave per recorded operator; the descriptors are read from the argument block itself.
+// One workgroup of one wave per LIST of recorded operators (a list: operators that depend on each other, in call order); the
+// descriptors are read from the argument block itself.  __syncthreads() between two operators of a list makes the first one's
+// stores visible to every lane of the workgroup before the second one loads (the barrier's release / acquire at workgroup scope).
 template <int BYTES>
 __global__ __launch_bounds__(64) void tiny_batch_kernel(TinyArgs<BYTES> args) {
     (void)args;  // read through the kernarg pointer: indexing the by-value copy would spill it to scratch (inline.hip)
     const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t off = reinterpret_cast<const uint16_t *>(ka + offsetof(TinyArgs<BYTES>, off))[blockIdx.x];
-    const char *base = ka + offsetof(TinyArgs<BYTES>, bytes) + off;
-    const TinyOp *d = reinterpret_cast<const TinyOp *>(base);
-    switch (d->dtype) {
-        case SMHIP_F32: tiny_dtype<float>(d, base); break;
-        case SMHIP_F64: tiny_dtype<double>(d, base); break;
-        case SMHIP_I32: tiny_dtype<int32_t>(d, base); break;
-        default: tiny_dtype<int64_t>(d, base); break;
+    uint32_t off = reinterpret_cast<const uint16_t *>(ka + offsetof(TinyArgs<BYTES>, head))[blockIdx.x];
+    for (;;) {
+        const char *base = ka + offsetof(TinyArgs<BYTES>, bytes) + off;
+        const TinyOp *d = reinterpret_cast<const TinyOp *>(base);
+        switch (d->dtype) {
+            case SMHIP_F32: tiny_dtype<float>(d, base); break;
+            case SMHIP_F64: tiny_dtype<double>(d, base); break;
+            case SMHIP_I32: tiny_dtype<int32_t>(d, base); break;
+            default: tiny_dtype<int64_t>(d, base); break;
+        }
+        const uint32_t next = d->next;  // the same for every lane
+        if (next == 0) break;
+        __syncthreads();
+        off = next - 1;
     }
 }
 
 struct TinyQueue {
     std::recursive_mutex m;
-    int count = 0;
+    int count = 0, lists = 0;
     size_t used = 0;
-    uint16_t off[kTinyMaxOps];
+    uint16_t head[kTinyMaxOps], tail[kTinyMaxOps];  // per list: byte offsets of its first and last operator
     alignas(16) unsigned char bytes[kTinyBigBytes];
     Span reads[2 * kTinyMaxOps], writes[kTinyMaxOps];
+    unsigned char read_list[2 * kTinyMaxOps], write_list[kTinyMaxOps];  // which list the span's operator belongs to
     int n_reads = 0;
     std::vector<void *> deferred;  // freed while recorded operators refer to them
     bool flushing = false;
-    unsigned long long launches = 0, operators = 0;
+    unsigned long long launches = 0, operators = 0, appended = 0;  // appended: operators that joined the list of one they depend on
 };
 TinyQueue g_tiny[kTinyDevices];
 std::atomic<int> g_tiny_pending{0};
@@ -147,16 +160,16 @@ int flush_locked(TinyQueue &q) {
         if (rc == SMHIP_OK) {
             if (q.used <= (size_t)kTinySmallBytes) {
                 TinyArgs<kTinySmallBytes> args;
-                args.n_ops = (uint32_t)q.count;
-                memcpy(args.off, q.off, sizeof args.off);
+                args.n_lists = (uint32_t)q.lists;
+                memcpy(args.head, q.head, sizeof args.head);
                 memcpy(args.bytes, q.bytes, q.used);
-                hipLaunchKernelGGL((tiny_batch_kernel<kTinySmallBytes>), dim3((unsigned)q.count), dim3(64), 0, s, args);
+                hipLaunchKernelGGL((tiny_batch_kernel<kTinySmallBytes>), dim3((unsigned)q.lists), dim3(64), 0, s, args);
             } else {
                 TinyArgs<kTinyBigBytes> args;
-                args.n_ops = (uint32_t)q.count;
-                memcpy(args.off, q.off, sizeof args.off);
+                args.n_lists = (uint32_t)q.lists;
+                memcpy(args.head, q.head, sizeof args.head);
                 memcpy(args.bytes, q.bytes, q.used);
-                hipLaunchKernelGGL((tiny_batch_kernel<kTinyBigBytes>), dim3((unsigned)q.count), dim3(64), 0, s, args);
+                hipLaunchKernelGGL((tiny_batch_kernel<kTinyBigBytes>), dim3((unsigned)q.lists), dim3(64), 0, s, args);
             }
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "tiny operators (%d in one launch): %s", q.count, hipGetErrorString(e));
@@ -166,6 +179,7 @@ int flush_locked(TinyQueue &q) {
     q.operators += (unsigned long long)q.count;
     g_tiny_pending.fetch_sub(q.count, std::memory_order_relaxed);
     q.count = 0;
+    q.lists = 0;
     q.used = 0;
     q.n_reads = 0;
     std::vector<void *> dead;
@@ -241,11 +255,21 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
     TinyQueue &q = g_tiny[dev];
     std::lock_guard<std::recursive_mutex> lock(q.m);
     if (q.flushing) return SMHIP_OK;
-    bool conflict = q.count == kTinyMaxOps || q.used + need > (size_t)kTinyBigBytes;
-    for (int i = 0; i < q.count && !conflict; ++i) conflict = overlap(w, q.writes[i]) || overlap(ra, q.writes[i]) || overlap(rb, q.writes[i]);
-    for (int i = 0; i < q.n_reads && !conflict; ++i) conflict = overlap(w, q.reads[i]);
-    if (conflict) {
+    // Which recorded operators must this one come after?  None: a list of its own.  Those of ONE list: it joins that list.
+    // Those of two lists: what is recorded goes out first.
+    int list = -1;
+    bool two = false;
+    auto after = [&](int l) {
+        if (list < 0) list = l;
+        else if (list != l) two = true;
+    };
+    for (int i = 0; i < q.count; ++i)
+        if (overlap(w, q.writes[i]) || overlap(ra, q.writes[i]) || overlap(rb, q.writes[i])) after(q.write_list[i]);  // WAW, RAW
+    for (int i = 0; i < q.n_reads; ++i)
+        if (overlap(w, q.reads[i])) after(q.read_list[i]);  // WAR
+    if (two || q.count == kTinyMaxOps || q.used + need > (size_t)kTinyBigBytes) {
         if (int rc = flush_locked(q)) return rc;
+        list = -1;
     }
     TinyOp d{};
     d.op = (uint8_t)op;
@@ -278,10 +302,19 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
         extra += (b_host_bytes + 15) & ~(size_t)15;
     }
     memcpy(at, &d, sizeof d);
-    q.off[q.count] = (uint16_t)q.used;
+    if (list < 0) {
+        list = q.lists++;
+        q.head[list] = (uint16_t)q.used;
+    } else {  // behind the last operator of the list it depends on
+        const uint16_t link = (uint16_t)(q.used + 1);
+        memcpy(q.bytes + q.tail[list] + offsetof(TinyOp, next), &link, sizeof link);
+        ++q.appended;
+    }
+    q.tail[list] = (uint16_t)q.used;
     q.writes[q.count] = w;
-    if (ra.p) q.reads[q.n_reads++] = ra;
-    if (rb.p) q.reads[q.n_reads++] = rb;
+    q.write_list[q.count] = (unsigned char)list;
+    if (ra.p) { q.reads[q.n_reads] = ra; q.read_list[q.n_reads++] = (unsigned char)list; }
+    if (rb.p) { q.reads[q.n_reads] = rb; q.read_list[q.n_reads++] = (unsigned char)list; }
     q.used += extra;
     ++q.count;
     g_tiny_pending.fetch_add(1, std::memory_order_relaxed);

@@ -66,10 +66,16 @@ def test_dependent_operators_keep_their_order(smhip, oracle):
     for dt in DT:
         a, b = _vals(dt, 30, 1).reshape(5, 6), _vals(dt, 30, 2, nonzero=True).reshape(5, 6)
         da, db = smhip.to_device(a), smhip.to_device(b)
+        l0, o0 = smhip.tiny_stats()
         c = smhip.binary(sma.OP_ADD, da, db)
         d = smhip.binary(sma.OP_MUL, c, c)
         e = smhip.binary(sma.OP_SUB, d, da)
         f = smhip.binary(sma.OP_DIV, e, db)
+        g2 = smhip.binary(sma.OP_ADD, da, da)  # unrelated: a list of its own in the same launch
+        smhip.synchronize()
+        l1, o1 = smhip.tiny_stats()
+        assert (l1 - l0, o1 - o0) == (1, 5), (l0, l1, o0, o1)  # the dependent four ran as ONE workgroup's list, in call order
+        util.assert_same_bits(g2.numpy(), oracle.binary(orc.ADD, a, a), "the unrelated one")
         hc = oracle.binary(orc.ADD, a, b)
         hd = oracle.binary(orc.MUL, hc, hc)
         he = oracle.binary(orc.SUB, hd, a)
@@ -90,6 +96,31 @@ def test_dependent_operators_keep_their_order(smhip, oracle):
         util.assert_same_bits(out.numpy(), oracle.binary(orc.MUL, a2, b), f"{np.dtype(dt).name} second write wins")
 
 
+def test_a_dependency_on_two_lists_ends_the_recording(smhip, oracle):
+    """x = a + b and y = a - b are independent (two lists); z = x * y depends on both: what is recorded goes out first, z starts
+    the next launch; w = z + x then joins z's list."""
+    a, b = _vals(np.float64, 12, 21).reshape(3, 4), _vals(np.float64, 12, 22).reshape(3, 4)
+    da, db = smhip.to_device(a), smhip.to_device(b)
+    l0, o0 = smhip.tiny_stats()
+    x = smhip.binary(sma.OP_ADD, da, db)
+    y = smhip.binary(sma.OP_SUB, da, db)
+    z = smhip.binary(sma.OP_MUL, x, y)
+    w = smhip.binary(sma.OP_ADD, z, x)
+    smhip.synchronize()
+    l1, o1 = smhip.tiny_stats()
+    assert (l1 - l0, o1 - o0) == (2, 4), (l0, l1, o0, o1)
+    hx, hy = oracle.binary(orc.ADD, a, b), oracle.binary(orc.SUB, a, b)
+    hz = oracle.binary(orc.MUL, hx, hy)
+    util.assert_same_bits(w.numpy(), oracle.binary(orc.ADD, hz, hx), "diamond")
+    # a long dependent sequence: 40 operators in a row, each reading the previous result (lists are cut at 30 operators)
+    r, h = da, a
+    for k in range(40):
+        op = (sma.OP_ADD, sma.OP_MUL, sma.OP_SUB)[k % 3]
+        r = smhip.binary(op, r, db)
+        h = oracle.binary(ORC[op], h, b)
+    util.assert_same_bits(r.numpy(), h, "40 dependent operators")
+
+
 def test_results_freed_while_recorded(smhip, oracle):
     """The benchmark bodies' pattern: `auto result = a op b` dies at the end of every iteration.  The freed block returns to the
     pool after the launch that writes it -- the next result gets another block, the operators batch, nothing leaks, and a later
@@ -106,7 +137,7 @@ def test_results_freed_while_recorded(smhip, oracle):
     util.assert_same_bits(last.numpy(), oracle.binary(orc.MUL, a, b), "after 100 dropped results")
     l1, o1 = smhip.tiny_stats()
     assert o1 - o0 == 101
-    assert l1 - l0 <= 8, (l0, l1)  # 24 to a launch
+    assert l1 - l0 <= 6, (l0, l1)  # 30 to a launch
     del last
     smhip.synchronize()
     in_use1, _ = smhip.pool_stats()
