@@ -91,10 +91,11 @@ int smhip_get_stream(void **hip_stream);
 int smhip_synchronize(void);
 
 /* -------------------------------------------------------------- memory */
-/* Operators on tiny arrays (<= 1024 results; + - * / of every element type, integer pow; operands of any strides or host-built;
+/* Operators on tiny arrays (<= 1024 results; + - * / of every element type, integer pow, smhip_fill, smhip_copy / _copy_strided,
+ * smhip_upload of <= 256 bytes; operands of any strides or host-built;
  * the library's own queue) are RECORDED by smhip_elementwise / _inline / smhip_contiguous / smhip_array_scalar and go out several
  * to a launch: independent ones side by side, dependent ones in call order on one workgroup -- the launch goes out when 30 are
- * recorded, when a new one depends on two separate lists of recorded ones, and before ANY other call on the device touches
+ * recorded, when a new one would tie two long lists of recorded ones together, and before ANY other call on the device touches
  * the stream (operators, copies, smhip_synchronize, events, smhip_get_stream): what a caller can observe is what call order
  * promises.  A buffer freed while a recorded operator refers to it returns to the pool after that launch.  Results are bit-identical
  * to the one-launch path (the same Op::apply).  SMHIP_TINY_BATCH=0 turns it off.  This reports, for the calling thread's device,

@@ -26,7 +26,7 @@ int tiny_flush_device(int dev);
 bool tiny_defer_free(int dev, void *p, size_t bytes);
 bool tiny_context(int *dev);  // runtime.hip: may the calling thread record a tiny operator now?
 int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *sa, const void *b, size_t b_host_bytes,
-                     const int64_t *sb, const int64_t *shape, int ndim, const void *scalar_host, void *out, bool *taken);
+                     const int64_t *sb, const int64_t *shape, int ndim, const void *scalar_host, void *out, bool *taken, int kind = 0);
 void tiny_stats(int dev, unsigned long long *launches, unsigned long long *operators);
 // Second library queue of `dev` off (true) / on again (false); see runtime.hip "two queues per device".
 void dispatch_single_queue(int dev, bool single);

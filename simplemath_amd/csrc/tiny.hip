@@ -9,10 +9,11 @@
 // operands, their bytes, appended to a per-device block -- and the block goes out as ONE launch (one workgroup per
 // operator) when
 //   * it is full (30 operators or ~3.9 KiB of descriptors),
-//   * a new tiny operator depends on recorded operators of MORE THAN ONE workgroup: independent operators run side by side,
-//     one workgroup each; an operator that depends on recorded ones (reads or overwrites what they write, overwrites what
-//     they read) is appended to THEIR workgroup's list, which runs in call order with a __syncthreads() between operators
-//     -- `c = a + b; d = c * c; e = d - a` is one launch of one workgroup; only a dependency on two lists ends the recording,
+//   * a new tiny operator would tie two LONG lists together: independent operators run side by side, one workgroup each; an
+//     operator that depends on recorded ones (reads or overwrites what they write, overwrites what they read) is appended to
+//     THEIR workgroup's list, which runs in call order with a __syncthreads() between operators -- `c = a + b; d = c * c;
+//     e = d - a` is one launch of one workgroup; one that depends on two lists joins them into one (they do not depend on
+//     each other, so either order is call order) up to 12 operators; beyond that what is recorded goes out first,
 //   * ANY other library call on the device acquires the stream (operators, uploads, read-backs, synchronisation, events,
 //     the stream handle, peer copies): runtime.hip's acquire_stream() flushes first, so every observation point sees
 //     what call order promises.
@@ -38,6 +39,7 @@ using namespace dev;
 
 constexpr int kTinyMaxOps = 30;  // per launch; every one may start a list of its own
 constexpr uint32_t kTinyMaxOut = 1024;
+constexpr int kTinyMaxMerged = 12;  // two lists are run as one only up to this many operators together
 constexpr size_t kTinyMaxInline = 256;
 constexpr int kTinySmallBytes = 960, kTinyBigBytes = 3904;  // argument blocks of 1 KiB and ~3.9 KiB (the launch writes the block it is given)
 constexpr int kTinyDevices = 64;
@@ -90,9 +92,36 @@ __device__ __forceinline__ void tiny_run(const TinyOp *d, const char *base) {
         out[e] = Op::apply(a[oa], b_scalar ? sv : b[ob]);
     }
 }
+constexpr int kTinyFill = 250, kTinyCopy = 251;  // descriptor op codes next to SMHIP_OP_*: out[e] = scalar; out[sum idx * sb] = a[sum idx * sa]
+template <typename T>
+__device__ __forceinline__ void tiny_move(const TinyOp *d, const char *base) {
+    const T *a = d->a_inl ? reinterpret_cast<const T *>(base + d->a_inl) : reinterpret_cast<const T *>(d->a);
+    T *out = reinterpret_cast<T *>(d->out);
+    T sv;
+    {
+        const uint64_t bits = d->scalar;
+        __builtin_memcpy(&sv, &bits, sizeof(T));
+    }
+    const bool fill = d->op == kTinyFill;
+    const int nd = d->ndim;
+    const uint32_t n = d->n;
+    for (uint32_t e = threadIdx.x; e < n; e += 64) {
+        uint32_t rem = e, oa = 0, od = 0;
+        for (int k = 0; k < nd; ++k) {
+            const uint32_t ext = d->shape[k];
+            const uint32_t idx = k == nd - 1 ? rem : rem % ext;
+            rem /= ext;
+            oa += idx * d->sa[k];
+            od += idx * d->sb[k];
+        }
+        out[od] = fill ? sv : a[oa];
+    }
+}
 template <typename T>
 __device__ __forceinline__ void tiny_dtype(const TinyOp *d, const char *base) {
     switch (d->op) {
+        case kTinyFill:
+        case kTinyCopy: tiny_move<T>(d, base); break;
         case SMHIP_OP_ADD: tiny_run<T, AddOp<T>>(d, base); break;
         case SMHIP_OP_SUB: tiny_run<T, SubtractOp<T>>(d, base); break;
         case SMHIP_OP_MUL: tiny_run<T, MultiplyOp<T>>(d, base); break;
@@ -130,14 +159,14 @@ struct TinyQueue {
     std::recursive_mutex m;
     int count = 0, lists = 0;
     size_t used = 0;
-    uint16_t head[kTinyMaxOps], tail[kTinyMaxOps];  // per list: byte offsets of its first and last operator
+    uint16_t head[kTinyMaxOps], tail[kTinyMaxOps], list_len[kTinyMaxOps];  // per list: byte offsets of its first and last operator, operators in it
     alignas(16) unsigned char bytes[kTinyBigBytes];
     Span reads[2 * kTinyMaxOps], writes[kTinyMaxOps];
     unsigned char read_list[2 * kTinyMaxOps], write_list[kTinyMaxOps];  // which list the span's operator belongs to
     int n_reads = 0;
     std::vector<void *> deferred;  // freed while recorded operators refer to them
     bool flushing = false;
-    unsigned long long launches = 0, operators = 0, appended = 0;  // appended: operators that joined the list of one they depend on
+    unsigned long long launches = 0, operators = 0, appended = 0, merged = 0;  // appended: operators that joined the list of one they depend on; merged: lists joined by one that depends on both
 };
 TinyQueue g_tiny[kTinyDevices];
 std::atomic<int> g_tiny_pending{0};
@@ -226,14 +255,18 @@ void tiny_stats(int dev, unsigned long long *launches, unsigned long long *opera
 }
 
 // Records `out = a op b` (b an array, or the value at scalar_host) if it is eligible; *taken says whether it was.
+// kind 1: a fill, out[e] = the value at scalar_host (a, b unused).  kind 2: a copy, out[sum idx * sb] = a[sum idx * sa] -- sb are
+// the DESTINATION's strides (an assignment into a view, a dense device-to-device copy, an upload whose bytes ride as `a`).
 int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, const int64_t *sa, const void *b, size_t b_host_bytes,
-                     const int64_t *sb, const int64_t *shape, int ndim, const void *scalar_host, void *out, bool *taken) {
+                     const int64_t *sb, const int64_t *shape, int ndim, const void *scalar_host, void *out, bool *taken, int kind) {
     *taken = false;
     if (!enabled()) return SMHIP_OK;
     int dev;
     if (!tiny_context(&dev) || dev >= kTinyDevices) return SMHIP_OK;
     const bool integral = dtype == SMHIP_I32 || dtype == SMHIP_I64;
-    if (!(op == SMHIP_OP_ADD || op == SMHIP_OP_SUB || op == SMHIP_OP_MUL || op == SMHIP_OP_DIV || (op == SMHIP_OP_POW && integral))) return SMHIP_OK;
+    if (kind == 1) op = kTinyFill;
+    else if (kind == 2) op = kTinyCopy;
+    else if (!(op == SMHIP_OP_ADD || op == SMHIP_OP_SUB || op == SMHIP_OP_MUL || op == SMHIP_OP_DIV || (op == SMHIP_OP_POW && integral))) return SMHIP_OK;
     if (ndim < 1 || ndim > SMHIP_MAX_NDIM || a_host_bytes > kTinyMaxInline || b_host_bytes > kTinyMaxInline) return SMHIP_OK;
     const size_t esz = dtype_size(dtype);
     uint64_t n = 1, span_a = 0, span_b = 0;
@@ -241,13 +274,13 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
         if (shape[i] <= 0) return SMHIP_OK;
         n *= (uint64_t)shape[i];
         if (n > kTinyMaxOut) return SMHIP_OK;
-        span_a += (uint64_t)(shape[i] - 1) * (uint64_t)sa[i];
+        if (kind != 1) span_a += (uint64_t)(shape[i] - 1) * (uint64_t)sa[i];
         if (!scalar_host) span_b += (uint64_t)(shape[i] - 1) * (uint64_t)sb[i];
         if (span_a >= (1ull << 31) || span_b >= (1ull << 31)) return SMHIP_OK;
     }
-    const Span w{out, (size_t)n * esz};
-    const Span ra{a_host_bytes ? nullptr : a, a_host_bytes ? 0 : (size_t)(span_a + 1) * esz};
-    const Span rb{(b_host_bytes || scalar_host) ? nullptr : b, (b_host_bytes || scalar_host) ? 0 : (size_t)(span_b + 1) * esz};
+    const Span w{out, kind == 2 ? (size_t)(span_b + 1) * esz : (size_t)n * esz};
+    const Span ra{(a_host_bytes || kind == 1) ? nullptr : a, (a_host_bytes || kind == 1) ? 0 : (size_t)(span_a + 1) * esz};
+    const Span rb{(b_host_bytes || scalar_host || kind != 0) ? nullptr : b, (b_host_bytes || scalar_host || kind != 0) ? 0 : (size_t)(span_b + 1) * esz};
     if (overlap(w, ra) || overlap(w, rb)) return SMHIP_OK;  // in place: the one-launch path has its own rules for that
     const bool same_inline = a_host_bytes && a == b && a_host_bytes == b_host_bytes;  // `ac + ac` on a host-built array: its bytes go in once
     const size_t need = sizeof(TinyOp) + ((a_host_bytes + 15) & ~(size_t)15) + (same_inline ? 0 : ((b_host_bytes + 15) & ~(size_t)15));
@@ -260,12 +293,26 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
     int list = -1;
     bool two = false;
     auto after = [&](int l) {
-        if (list < 0) list = l;
-        else if (list != l) two = true;
+        if (list < 0 || list == l) { list = l; return; }
+        // a second list: the two do not depend on each other, so one workgroup may run them one after the other -- `a` and `b`
+        // uploaded (two lists), then a + b -- unless that would make a long serial run of what could have run side by side
+        if (q.list_len[list] + q.list_len[l] > kTinyMaxMerged) { two = true; return; }
+        const int keep = list < l ? list : l, drop = list < l ? l : list;
+        const uint16_t link = (uint16_t)(q.head[drop] + 1);
+        memcpy(q.bytes + q.tail[keep] + offsetof(TinyOp, next), &link, sizeof link);
+        q.tail[keep] = q.tail[drop];
+        q.list_len[keep] = (uint16_t)(q.list_len[keep] + q.list_len[drop]);
+        const int last = q.lists - 1;  // `drop` takes the last list's number
+        for (int i = 0; i < q.count; ++i) q.write_list[i] = q.write_list[i] == drop ? (unsigned char)keep : (q.write_list[i] == last ? (unsigned char)drop : q.write_list[i]);
+        for (int i = 0; i < q.n_reads; ++i) q.read_list[i] = q.read_list[i] == drop ? (unsigned char)keep : (q.read_list[i] == last ? (unsigned char)drop : q.read_list[i]);
+        if (drop != last) { q.head[drop] = q.head[last]; q.tail[drop] = q.tail[last]; q.list_len[drop] = q.list_len[last]; }
+        --q.lists;
+        ++q.merged;
+        list = keep;
     };
-    for (int i = 0; i < q.count; ++i)
+    for (int i = 0; i < q.count && !two; ++i)
         if (overlap(w, q.writes[i]) || overlap(ra, q.writes[i]) || overlap(rb, q.writes[i])) after(q.write_list[i]);  // WAW, RAW
-    for (int i = 0; i < q.n_reads; ++i)
+    for (int i = 0; i < q.n_reads && !two; ++i)
         if (overlap(w, q.reads[i])) after(q.read_list[i]);  // WAR
     if (two || q.count == kTinyMaxOps || q.used + need > (size_t)kTinyBigBytes) {
         if (int rc = flush_locked(q)) return rc;
@@ -280,8 +327,8 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
     for (int k = 0; k < ndim; ++k) {
         const int src = ndim - 1 - k;
         d.shape[k] = (uint32_t)shape[src];
-        d.sa[k] = (uint32_t)sa[src];
-        d.sb[k] = scalar_host ? 0u : (uint32_t)sb[src];
+        d.sa[k] = kind == 1 ? 0u : (uint32_t)sa[src];
+        d.sb[k] = (scalar_host && kind != 1) ? 0u : (uint32_t)sb[src];
     }
     d.a = reinterpret_cast<uint64_t>(a);
     d.b = reinterpret_cast<uint64_t>(b);
@@ -305,12 +352,14 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
     if (list < 0) {
         list = q.lists++;
         q.head[list] = (uint16_t)q.used;
+        q.list_len[list] = 0;
     } else {  // behind the last operator of the list it depends on
         const uint16_t link = (uint16_t)(q.used + 1);
         memcpy(q.bytes + q.tail[list] + offsetof(TinyOp, next), &link, sizeof link);
         ++q.appended;
     }
     q.tail[list] = (uint16_t)q.used;
+    ++q.list_len[list];
     q.writes[q.count] = w;
     q.write_list[q.count] = (unsigned char)list;
     if (ra.p) { q.reads[q.n_reads] = ra; q.read_list[q.n_reads++] = (unsigned char)list; }

@@ -263,6 +263,7 @@ int main() {
         OK(smhip_alloc(&c, T * sizeof(float)));
         OK(smhip_alloc(&d, T * sizeof(float)));
         OK(smhip_fill(SMHIP_F32, a, &seven, T));
+        OK(smhip_synchronize());  // (the fill of such an array is recorded too)
         unsigned long long l0 = 0, o0 = 0, l1 = 0, o1 = 0;
         OK(smhip_tiny_stats(&l0, &o0));
         OK(smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, a, &one, T, b));   // recorded: b = 8

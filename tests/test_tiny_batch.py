@@ -44,6 +44,7 @@ def test_independent_operators_share_launches(smhip, oracle):
         a, b = _vals(dt, 25, 100 + k).reshape(5, 5), _vals(dt, 25, 200 + k, nonzero=True).reshape(5, 5)
         da, db = smhip.to_device(a), smhip.to_device(b)
         keep.append((da, db))
+    smhip.synchronize()  # the uploads of such arrays are recorded too: out with them first
     l1, o1 = smhip.tiny_stats()
     outs = []
     for k, (da, db) in enumerate(keep):
@@ -66,6 +67,7 @@ def test_dependent_operators_keep_their_order(smhip, oracle):
     for dt in DT:
         a, b = _vals(dt, 30, 1).reshape(5, 6), _vals(dt, 30, 2, nonzero=True).reshape(5, 6)
         da, db = smhip.to_device(a), smhip.to_device(b)
+        smhip.synchronize()
         l0, o0 = smhip.tiny_stats()
         c = smhip.binary(sma.OP_ADD, da, db)
         d = smhip.binary(sma.OP_MUL, c, c)
@@ -96,22 +98,37 @@ def test_dependent_operators_keep_their_order(smhip, oracle):
         util.assert_same_bits(out.numpy(), oracle.binary(orc.MUL, a2, b), f"{np.dtype(dt).name} second write wins")
 
 
-def test_a_dependency_on_two_lists_ends_the_recording(smhip, oracle):
-    """x = a + b and y = a - b are independent (two lists); z = x * y depends on both: what is recorded goes out first, z starts
-    the next launch; w = z + x then joins z's list."""
+def test_an_operator_that_depends_on_two_lists_joins_them(smhip, oracle):
+    """x = a + b and y = a - b are independent (two lists); z = x * y depends on both: the two lists become one (neither depends on
+    the other, so either order is call order) and z follows; w = z + x joins as well -- one launch.  Uploads of tiny arrays are
+    recorded copies: upload a, upload b, a + b is one launch, not two packets and a launch.  Two LONG lists are not joined: what
+    is recorded goes out first."""
     a, b = _vals(np.float64, 12, 21).reshape(3, 4), _vals(np.float64, 12, 22).reshape(3, 4)
-    da, db = smhip.to_device(a), smhip.to_device(b)
+    smhip.synchronize()
     l0, o0 = smhip.tiny_stats()
+    da, db = smhip.to_device(a), smhip.to_device(b)   # two recorded uploads
     x = smhip.binary(sma.OP_ADD, da, db)
     y = smhip.binary(sma.OP_SUB, da, db)
     z = smhip.binary(sma.OP_MUL, x, y)
     w = smhip.binary(sma.OP_ADD, z, x)
     smhip.synchronize()
     l1, o1 = smhip.tiny_stats()
-    assert (l1 - l0, o1 - o0) == (2, 4), (l0, l1, o0, o1)
+    assert (l1 - l0, o1 - o0) == (1, 6), (l0, l1, o0, o1)
     hx, hy = oracle.binary(orc.ADD, a, b), oracle.binary(orc.SUB, a, b)
     hz = oracle.binary(orc.MUL, hx, hy)
     util.assert_same_bits(w.numpy(), oracle.binary(orc.ADD, hz, hx), "diamond")
+    # two lists of eight dependent operators each, then one operator that needs both: 17 > 12, so two launches
+    smhip.synchronize()
+    l0, o0 = smhip.tiny_stats()
+    p, q, hp, hq = da, db, a, b
+    for k in range(8):
+        p = smhip.binary(sma.OP_ADD, p, p); hp = oracle.binary(orc.ADD, hp, hp)
+        q = smhip.binary(sma.OP_MUL, q, q); hq = oracle.binary(orc.MUL, hq, hq)
+    r = smhip.binary(sma.OP_SUB, p, q)
+    smhip.synchronize()
+    l1, o1 = smhip.tiny_stats()
+    assert (l1 - l0, o1 - o0) == (2, 17), (l0, l1, o0, o1)
+    util.assert_same_bits(r.numpy(), oracle.binary(orc.SUB, hp, hq), "two long lists")
     # a long dependent sequence: 40 operators in a row, each reading the previous result (lists are cut at 30 operators)
     r, h = da, a
     for k in range(40):

@@ -45,7 +45,7 @@ int main() {
             void *outs[64];
             for (auto &o : outs) smhip_alloc(&o, 40);
             unsigned k = 0;
-            print(run("smhip_array_scalar pow i32 n=10 into 64 rotating outputs (record + 1/24 launch)", [&] { smhip_array_scalar(SMHIP_OP_POW, SMHIP_I32, p, &three, 10, outs[k++ & 63]); }, sync));
+            print(run("smhip_array_scalar pow i32 n=10 into 64 rotating outputs (record + 1/30 launch)", [&] { smhip_array_scalar(SMHIP_OP_POW, SMHIP_I32, p, &three, 10, outs[k++ & 63]); }, sync));
             print(run("smhip_alloc + smhip_array_scalar + smhip_free (fresh result each time)", [&] { void *t; smhip_alloc(&t, 40); smhip_array_scalar(SMHIP_OP_POW, SMHIP_I32, p, &three, 10, t); smhip_free(t); }, sync));
             for (auto &o : outs) smhip_free(o);
         }
