@@ -781,6 +781,8 @@ int smhip_device_count(int *count) {
 int smhip_set_device(int device) {
     if (device < 0 || device >= kMaxDevices) return fail(SMHIP_ERR_INVALID, "set_device: %d", device);
     const int prev = tls.device;
+    // leaving a device: what this thread's calls recorded there (tiny.hip) is launched before the thread looks elsewhere
+    if (prev >= 0 && prev != device && !tls.use_user_stream && tls.op_depth == 0) (void)tiny_flush_device(prev);
     tls.device = device;
     hipStream_t s;
     if (int rc = acquire_stream(&s)) {
