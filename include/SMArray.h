@@ -724,6 +724,29 @@ private:
         return c->full() ? nullptr : c;
     }
 
+public:
+    // sm::pow(<temporary>, s) (UserFunctions.h): when the temporary is the unevaluated result of this full-expression's chain --
+    // sm::pow(a - b, 2.0f) -- the power is one more stage of that chain (s = 2 is fused into its kernel, any other exponent cuts
+    // the chain and runs pow's own evaluation on the value so far: the same bits as the operator by itself).  The chain is
+    // launched by the operators' argument temporaries at the end of the full-expression, like every chain.
+    static SMArray pow_of(const SMArray &x, bool x_temporary, T value) {
+        if constexpr (hip::on_device_v<T, PowOp<T>> && hip::is_builtin_op<PowOp<T>>::value) {
+            if (x_temporary) {
+                if (detail::Chain<T> *cx = x.continuable()) {
+                    hip::DeviceGuard on(x.device());
+                    SMArray out = device_empty(std::vector<std::size_t>(x._shape));
+                    detail::Storage<T> &ost = *out.data.storage();
+                    ost.pending = std::move(x.data.storage()->pending);
+                    cx->retarget(&ost, out._shape);
+                    cx->push(SMHIP_OP_POW, false, value);
+                    return out;
+                }
+            }
+        }
+        return x.template apply_scalar<PowOp<T>>(value);
+    }
+
+private:
     // x Op y (y == nullptr: x Op scalar), recorded rather than launched when it can be part of a one-pass chain: built-in
     // + - * / on an element type with kernels.  See "deferred operator chains" at the top of this file.
     template <typename Op>

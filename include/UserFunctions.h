@@ -37,6 +37,12 @@ template <typename T>
 SMArray<T> pow(const SMArray<T> &arr, T val) {
     return arr.template apply_scalar<PowOp<T>>(val);
 }
+// ... of a temporary: sm::pow(a - b, 2.0f) continues the expression's operator chain (SMArray::pow_of) instead of reading
+// its result back from HBM -- the squared difference is one kernel.
+template <typename T>
+SMArray<T> pow(SMArray<T> &&arr, T val) {
+    return SMArray<T>::pow_of(arr, true, val);
+}
 
 // Fusion hook: (a Op1 b) Op2 c in ONE pass over HBM (the reference makes two passes and a
 // temporary).  Dense, equal-shaped operands take the two-Op kernel; operands that broadcast against each other (a row, a

@@ -226,7 +226,9 @@ int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const voi
  * there and 12 here.  operands[k] is a device pointer to operand k's first element with strides[k * ndim .. ) its strides
  * broadcast against `shape` (0 where it broadcasts; as smhip_broadcast returns them), or NULL for a scalar whose value is
  * element k of scalars_host (n_operands elements of the element type in host memory; entries of array operands are
- * ignored).  operands[0] must be an array.  ops[k] in {ADD, SUB, MUL, DIV}.  `out` is dense row-major over `shape` and
+ * ignored).  operands[0] must be an array.  ops[k] in {ADD, SUB, MUL, DIV}, or POW with a SCALAR x[k+1] and swapped[k] == 0
+ * (sm::pow(<expression>, s), UserFunctions.h:42-48: ^2 is a stage of the one-pass kernel, any other exponent cuts the chain and runs
+ * smhip_array_scalar's evaluation on the value so far -- the same bits either way).  `out` is dense row-major over `shape` and
  * must not overlap an operand.  Each stage is the single rounded / wrapping operation the separate operator performs, so
  * the result is bit-identical to the operator chain.  An operand the one-pass kernel has no index form for (a transposed
  * or stepped view) cuts the chain: that operator runs through smhip_elementwise's kernels, the rest stays fused. */

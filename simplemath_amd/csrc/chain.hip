@@ -91,6 +91,10 @@ __device__ __forceinline__ typename VecTraits<T>::full_t chain_step(uint32_t op,
 #pragma unroll
             for (int k = 0; k < W; ++k) o[k] = MultiplyOp<T>::apply(lhs[k], rhs[k]);
             break;
+        case SMHIP_OP_POW:  // only ever r ^ 2 (launch_chain): the one multiplication sm::pow(a, 2) is (contiguous.hip: PowSquare; integer pow wraps the same way)
+#pragma unroll
+            for (int k = 0; k < W; ++k) o[k] = MultiplyOp<T>::apply(r[k], r[k]);
+            break;
         default:
 #pragma unroll
             for (int k = 0; k < W; ++k) o[k] = DivideOp<T>::apply(lhs[k], rhs[k]);
@@ -650,11 +654,48 @@ int launch_chain(int dtype, int n_operands, const void *const *operands, const i
         if (lf >= leaves && lf < leaves + n_operands) return &originals[lf - leaves];
         return lf;
     };
+    // r ^ s (sm::pow of the chain's value; s a scalar, checked by the entry point).  s = 2 is a stage like any other -- the one
+    // multiplication sm::pow(a, 2) is; s = 1 is no stage at all; any other exponent has an evaluation of its own
+    // (contiguous.hip: run_scalar -- exact forms, the half-integer chains, pow_core_u, the table kernels), so the chain is cut
+    // there and that evaluation runs on the value so far: the same bits as the operator called by itself.
+    auto pow_value = [&](const Leaf *x, double *v) {
+        switch (dtype) {
+            case SMHIP_F32: { float f; memcpy(&f, x->scalar, 4); *v = f; break; }
+            case SMHIP_F64: { double f; memcpy(&f, x->scalar, 8); *v = f; break; }
+            case SMHIP_I32: { int32_t f; memcpy(&f, x->scalar, 4); *v = (double)f; break; }
+            default: { int64_t f; memcpy(&f, x->scalar, 8); *v = (double)f; break; }
+        }
+    };
     start(head);
     for (int k = 0; k < n_stages; ++k) {
         const Leaf *x = &leaves[k + 1];
         const bool last = k == n_stages - 1;
         const Leaf *h = sg.leaves[0];
+        if (ops[k] == SMHIP_OP_POW) {
+            double e = 0;
+            pow_value(x, &e);
+            const bool head_plain = sg.ops.empty() && h->kind != kDense;  // a broadcast operand with nothing applied yet: nothing to square in place
+            if (e == 2.0 && !head_plain && (int)sg.ops.size() < kMaxStages) {
+                sg.leaves.push_back(x);
+                sg.ops.push_back(SMHIP_OP_POW);
+                sg.swaps.push_back(0);
+                continue;
+            }
+            if (e == 1.0 && !head_plain && !last) continue;
+            const Leaf *cur;
+            if (int rc = emit(nullptr, &cur)) return rc;  // the value so far, dense (a dense head as it is)
+            if (cur->kind != kDense) {  // a head that broadcasts: written out through the copy Op first
+                const Leaf *res;
+                if (int rc = eager(SMHIP_OP_LEFT, original_of(cur), original_of(cur), nullptr, &res)) return rc;
+                cur = res;
+            }
+            void *buf = last ? out : nullptr;
+            if (!buf) if (int rc = temps.take(pb.n * pb.esz, &buf)) return rc;
+            if (int rc = launch_array_scalar(SMHIP_OP_POW, dtype, cur->ptr, x->scalar, pb.n, buf, s)) return rc;
+            if (last) return SMHIP_OK;
+            start(new_temp_head(buf));
+            continue;
+        }
         const bool head_complex = sg.ops.empty() && h->kind == kComplex;
         if (x->kind == kComplex || head_complex) {
             const Leaf *cur;

@@ -1361,8 +1361,13 @@ int smhip_chain(int dtype, int n_operands, const void *const *operands, const in
         for (int i = 0; i < ndim; ++i)
             if (strides[(size_t)k * ndim + i] < 0) return fail(SMHIP_ERR_INVALID, "chain: negative stride (operand %d, dim %d)", k, i);
     }
-    for (int k = 0; k + 1 < n_operands; ++k)
-        if (ops[k] < SMHIP_OP_ADD || ops[k] > SMHIP_OP_DIV) return fail(SMHIP_ERR_UNSUPPORTED, "chain: op %d (stage %d) is not one of add, sub, mul, div", ops[k], k);
+    for (int k = 0; k + 1 < n_operands; ++k) {
+        if (ops[k] == SMHIP_OP_POW) {  // r ^ scalar only: sm::pow(<expression>, s)
+            if (operands[k + 1] || swapped[k]) return fail(SMHIP_ERR_UNSUPPORTED, "chain: pow (stage %d) takes the chain's value to a SCALAR power", k);
+            continue;
+        }
+        if (ops[k] < SMHIP_OP_ADD || ops[k] > SMHIP_OP_DIV) return fail(SMHIP_ERR_UNSUPPORTED, "chain: op %d (stage %d) is not one of add, sub, mul, div, pow", ops[k], k);
+    }
     if (n == 0) return SMHIP_OK;
     if (!out) return fail(SMHIP_ERR_INVALID, "chain: null output");
     Span reads[SMHIP_CHAIN_MAX_OPERANDS];

@@ -251,6 +251,54 @@ static void ordering() {
     CHECK(m2(1, 1) == 5.0f);
 }
 
+// sm::pow of an expression's temporary is one more stage of its chain: ^2 inside the kernel, any other exponent by cutting the chain
+// and running pow's own evaluation on the value so far -- the same bits as the operators called one by one, for every element type.
+template <typename T>
+static void powers() {
+    const std::size_t rows = 66, cols = 200;
+    const auto A = random_array<T>(rows, cols), B = random_array<T>(rows, cols);
+    const auto row = random_array<T>(1, cols);
+    {   // the squared difference: one launch
+        Delta d;
+        auto f = sm::pow(A - B, T(2));
+        CHECK(d.chains() == 1 && d.stages() == 2 && d.singles() == 0);
+        auto t1 = A - B;
+        auto t2 = sm::pow(t1, T(2));
+        CHECK(same_bits(f, t2));
+    }
+    {   // ... with more around it: ((A - row)^2 + B) * 2
+        Delta d;
+        auto f = (sm::pow(A - row, T(2)) + B) * T(2);
+        CHECK(d.chains() == 1 && d.stages() == 4);
+        auto t1 = A - row;
+        auto t2 = sm::pow(t1, T(2));
+        auto t3 = t2 + B;
+        auto t4 = t3 * T(2);
+        CHECK(same_bits(f, t4));
+    }
+    {   // another exponent cuts the chain; the values are those of the plain operators
+        const T e = std::is_integral_v<T> ? T(3) : T(2.5);
+        auto pos = A * A + T(1);  // positive bases
+        auto f = sm::pow(pos * T(2), e) - B;
+        auto t1 = pos * T(2);
+        auto t2 = sm::pow(t1, e);
+        auto t3 = t2 - B;
+        CHECK(same_bits(f, t3));
+        auto g = sm::pow(pos + row, T(1)) * T(3);  // ^1: no stage at all
+        auto u1 = pos + row;
+        auto u2 = sm::pow(u1, T(1));
+        auto u3 = u2 * T(3);
+        CHECK(same_bits(g, u3));
+    }
+    {   // a named operand is not a temporary: computed by itself, as before
+        Delta d;
+        auto f = sm::pow(A, T(2));
+        CHECK(d.chains() == 0);
+        auto g = A * A;
+        CHECK(same_bits(f, g));
+    }
+}
+
 template <typename T>
 static void hooks() {
     // sm::fused and sm::expr take operands that broadcast against each other (smhip_chain / smhip_fused_expr_bcast)
@@ -319,6 +367,10 @@ int main() {
     STEP(periodic_4d<double>());
     STEP(periodic_4d<std::int32_t>());
     STEP(periodic_4d<std::int64_t>());
+    STEP(powers<float>());
+    STEP(powers<double>());
+    STEP(powers<std::int32_t>());
+    STEP(powers<std::int64_t>());
     STEP(hooks<float>());
     STEP(hooks<double>());
     STEP(hooks<std::int32_t>());

@@ -220,6 +220,40 @@ def test_chain_config3_size(smhip, oracle):
     util.assert_same_bits(got[1000:1016], _oracle_chain(oracle, hA, [(sma.OP_MUL, hr), (sma.OP_ADD, hB), (sma.OP_MUL, np.float32(0.5))]), "slice vs oracle")
 
 
+def test_chain_pow_stages(smhip, oracle):
+    """r ^ scalar as a stage (sm::pow of an expression): ^2 fused into the kernel, other exponents by cutting the chain and running
+    pow's own evaluation -- bit-identical to the operators called one after the other on the GPU, and within pow's bar of the
+    oracle's chain (libm's pow, PowOp<T>::apply, pow.h:8-10)."""
+    rng = np.random.default_rng(21)
+    for dt in DTYPES:
+        A, B = np.abs(_rand(rng, (70, 96), dt)) + dt(1), _rand(rng, (70, 96), dt)
+        row = _rand(rng, (1, 96), dt)
+        dA, dB, drow = smhip.to_device(A), smhip.to_device(B), smhip.to_device(row)
+        e_other = dt(3) if np.dtype(dt).kind == "i" else dt(2.5)
+        for e in (dt(2), e_other, dt(1)):
+            got = smhip.chain(dA, (sma.OP_SUB, drow), (sma.OP_POW, e), (sma.OP_ADD, dB), (sma.OP_MUL, dt(2))).numpy()
+            t = smhip.binary(sma.OP_SUB, dA, drow)
+            t = smhip.array_scalar(sma.OP_POW, t, e)
+            t = smhip.binary(sma.OP_ADD, t, dB)
+            want = smhip.array_scalar(sma.OP_MUL, t, dt(2)).numpy()
+            if np.dtype(dt).kind == "f" and e == e_other:  # negative bases ^ 2.5: NaN in both
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+                ok = ~np.isnan(want)
+                util.assert_same_bits(got[ok], want[ok], f"{np.dtype(dt).name} ^ {e}")
+            else:
+                util.assert_same_bits(got, want, f"{np.dtype(dt).name} ^ {e}")
+        # the power first and last in the chain, and against the oracle (squares are exact products)
+        got = smhip.chain(dA, (sma.OP_POW, dt(2)), (sma.OP_SUB, dB)).numpy()
+        util.assert_same_bits(got, oracle.binary(orc.SUB, oracle.binary(orc.MUL, A, A), B), f"{np.dtype(dt).name} A^2 - B")
+        got = smhip.chain(dA, (sma.OP_ADD, dB), (sma.OP_POW, dt(2))).numpy()
+        s1 = oracle.binary(orc.ADD, A, B)
+        util.assert_same_bits(got, oracle.binary(orc.MUL, s1, s1), f"{np.dtype(dt).name} (A + B)^2")
+        got = smhip.chain(drow, (sma.OP_POW, dt(2)), (sma.OP_ADD, dA)).numpy()  # a broadcast head: squared after being written out
+        util.assert_same_bits(got, oracle.binary(orc.ADD, oracle.binary(orc.MUL, row, row), A), f"{np.dtype(dt).name} row^2 + A")
+    with pytest.raises(RuntimeError):
+        smhip.chain(dA, (sma.OP_POW, dB))  # an array exponent is not a chain stage
+
+
 def test_chain_errors(smhip):
     a = smhip.to_device(np.ones((4, 4), np.float32))
     b = smhip.to_device(np.ones((3, 4), np.float32))

@@ -64,5 +64,9 @@ for rows, cols in SIZES:
     def eager1(A, B, O):
         lib.array_scalar(sma.OP_MUL, A, half, out=t1); lib.array_scalar(sma.OP_ADD, t1, half, out=O)
     report("A * 0.5 + 0.5", 8, lambda A, B, O: lib.chain_call(A, (sma.OP_MUL, half), (sma.OP_ADD, half), out=O), eager1)
+    two = np.float32(2.0)
+    def eager_sq(A, B, O):
+        lib.binary(sma.OP_SUB, A, B, out=t1); lib.array_scalar(sma.OP_POW, t1, two, out=O)
+    report("pow(A - B, 2)", 12, lambda A, B, O: lib.chain_call(A, (sma.OP_SUB, B), (sma.OP_POW, two), out=O), eager_sq)
     del sets, t1, t2, row, col
     lib.pool_trim()
