@@ -11,6 +11,12 @@ int main() {
     auto c = sm::pow(b, 2.5f) / 2.0f;
     a(SLICE(0, 2), SLICE_ALL) = c(SLICE(2, 4), SLICE_ALL);
     auto d = a.apply<Hypot2<float>>(c);
+    auto row4096 = sm::ones<float>(1, 4096) * 0.5f, mean_col = sm::ones<float>(4096, 1) * 2.0f, std_col = sm::ones<float>(4096, 1) * 4.0f;
+    auto g = (a * row4096 + b) * 0.5f;
+    (void)g;
+    a = (a - mean_col) / std_col;
+    auto mse = sm::pow(a - b, 2.0f).sum();
+    (void)mse;
     auto e = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, c);
     auto f = sm::expr("(a0 + a1) * a2 - 3 * a3", a, b, c, d);
     (void)f;
