@@ -14,8 +14,9 @@ int main() {
     auto row4096 = sm::ones<float>(1, 4096) * 0.5f, mean_col = sm::ones<float>(4096, 1) * 2.0f, std_col = sm::ones<float>(4096, 1) * 4.0f;
     auto g = (a * row4096 + b) * 0.5f;
     (void)g;
-    a = (a - mean_col) / std_col;
-    auto mse = sm::pow(a - b, 2.0f).sum();
+    auto n = sm::ones<float>(4096, 4096);
+    n = (n - mean_col) / std_col;
+    auto mse = sm::pow(n - b, 2.0f).sum();
     (void)mse;
     auto e = sm::fused<AddOp<float>, MultiplyOp<float>>(a, b, c);
     auto f = sm::expr("(a0 + a1) * a2 - 3 * a3", a, b, c, d);
