@@ -11,6 +11,7 @@
 //      thread, an operator's pooled scratch -- is an event edge.
 //   7. tiny operators recorded on the library's queue (csrc/tiny.hip) against a switch to a caller's stream, a consumer on another
 //      host thread, and frees of results nobody read.
+//   8. four host threads recording tiny operators on one device at once, a fifth launching large ones.
 // The reference has nothing like this (new[]/delete[] per operator, SMArray.h:219,342-346).  Exit code 0 = all held.
 #include <hip/hip_runtime.h>
 #include <smhip.h>
@@ -300,6 +301,57 @@ int main() {
         OK(smhip_free(a));
         OK(smhip_free(c));
         OK(smhip_free(d));
+    }
+    std::printf("case 8\n");
+    {  // 8. four host threads record tiny operators on the SAME device at once -- each a running sum in its own buffers (dependent:
+       //    one list), fresh results that die unread, reads of one shared input, a read-back every few hundred operators -- while
+       //    a fifth keeps launching a large operator: the per-device block, its deferred frees and the flushes from every
+       //    thread's calls must neither lose nor reorder anything.
+        const size_t T = 40;
+        const float one = 1.0f;
+        void *shared = nullptr, *big = nullptr;
+        OK(smhip_alloc(&shared, T * sizeof(float)));
+        OK(smhip_alloc(&big, (8u << 20) * sizeof(float)));
+        OK(smhip_fill(SMHIP_F32, shared, &one, T));
+        OK(smhip_fill(SMHIP_F32, big, &zero, 8u << 20));
+        OK(smhip_synchronize());
+        std::vector<std::thread> workers;
+        std::vector<int> bad(4, 0);
+        for (int w = 0; w < 4; ++w) {
+            workers.emplace_back([&, w] {
+                if (smhip_set_device(0) != SMHIP_OK) { bad[w] = 1; return; }
+                void *acc = nullptr, *tmp = nullptr;
+                if (smhip_alloc(&acc, T * sizeof(float)) != SMHIP_OK || smhip_alloc(&tmp, T * sizeof(float)) != SMHIP_OK) { bad[w] = 1; return; }
+                const float start = (float)w;
+                if (smhip_fill(SMHIP_F32, acc, &start, T) != SMHIP_OK) bad[w] = 1;
+                float expect = start;
+                for (int i = 1; i <= 3000 && !bad[w]; ++i) {
+                    if (smhip_contiguous(SMHIP_OP_ADD, SMHIP_F32, acc, shared, tmp, T) != SMHIP_OK) bad[w] = 1;   // tmp = acc + 1
+                    if (smhip_array_scalar(SMHIP_OP_MUL, SMHIP_F32, tmp, &one, T, acc) != SMHIP_OK) bad[w] = 1;     // acc = tmp
+                    expect += 1.0f;
+                    void *r = nullptr;  // a result nobody reads
+                    if (smhip_alloc(&r, T * sizeof(float)) != SMHIP_OK || smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, shared, &one, T, r) != SMHIP_OK ||
+                        smhip_free(r) != SMHIP_OK) bad[w] = 1;
+                    if (i % 377 == 0 && !all_equal(static_cast<float *>(acc), expect, T)) bad[w] = 2;
+                }
+                if (!bad[w] && !all_equal(static_cast<float *>(acc), expect, T)) bad[w] = 3;
+                smhip_free(acc);
+                smhip_free(tmp);
+            });
+        }
+        workers.emplace_back([&] {
+            if (smhip_set_device(0) != SMHIP_OK) return;
+            for (int i = 0; i < 200; ++i) smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, big, &one, 8u << 20, big);
+        });
+        for (auto &t : workers) t.join();
+        for (int w = 0; w < 4; ++w) {
+            if (bad[w]) std::printf("  worker %d: failure kind %d\n", w, bad[w]);
+            CHECK(bad[w] == 0);
+        }
+        CHECK(all_equal(static_cast<float *>(big), 200.0f, 8u << 20));
+        CHECK(all_equal(static_cast<float *>(shared), 1.0f, T));
+        OK(smhip_free(shared));
+        OK(smhip_free(big));
     }
     OK(smhip_synchronize());
     hipStreamDestroy(s1);
