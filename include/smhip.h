@@ -91,7 +91,7 @@ int smhip_get_stream(void **hip_stream);
 int smhip_synchronize(void);
 
 /* -------------------------------------------------------------- memory */
-/* Operators on tiny arrays (<= 1024 results; + - * / of every element type, integer pow, smhip_fill, smhip_copy / _copy_strided,
+/* Operators on tiny arrays (<= 4096 results; + - * / of every element type, integer pow, smhip_fill, smhip_copy / _copy_strided,
  * smhip_upload of <= 256 bytes; operands of any strides or host-built;
  * the library's own queue) are RECORDED by smhip_elementwise / _inline / smhip_contiguous / smhip_array_scalar and go out several
  * to a launch: independent ones side by side, dependent ones in call order on one workgroup -- the launch goes out when 30 are

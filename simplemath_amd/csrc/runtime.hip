@@ -1078,7 +1078,7 @@ int smhip_download(void *dst_host, const void *src, size_t bytes) {
 int smhip_copy(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return SMHIP_OK;
     if (!dst || !src) return fail(SMHIP_ERR_INVALID, "copy: null");
-    if (bytes <= 4096 && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 4 == 0) {
+    if (bytes <= 4 * (size_t)kTinyMaxResults && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 4 == 0) {
         const int64_t one = 1, shape1 = (int64_t)(bytes / 4);
         bool taken;
         if (int rc = tiny_try_enqueue(0, SMHIP_I32, src, 0, &one, nullptr, 0, &one, &shape1, 1, nullptr, dst, &taken, 2)) return rc;
@@ -1098,7 +1098,7 @@ int smhip_fill(int dtype, void *dst, const void *value_host, size_t n) {
     if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "fill: bad dtype %d", dtype);
     if (n == 0) return SMHIP_OK;
     if (!dst || !value_host) return fail(SMHIP_ERR_INVALID, "fill: null");
-    if (n <= 1024) {  // tiny: recorded (tiny.hip)
+    if ((int64_t)n <= kTinyMaxResults) {  // tiny: recorded (tiny.hip)
         const int64_t one = 1, shape1 = (int64_t)n;
         bool taken;
         if (int rc = tiny_try_enqueue(0, dtype, nullptr, 0, &one, nullptr, 0, &one, &shape1, 1, value_host, dst, &taken, 1)) return rc;
@@ -1174,7 +1174,7 @@ int smhip_elementwise(int op, int dtype, const void *a, const int64_t *stride_a,
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "elementwise: null buffer");
     const size_t esz = dtype_size(dtype);
-    if (n <= 1024) {  // tiny: recorded, several operators to a launch (tiny.hip)
+    if ((int64_t)n <= kTinyMaxResults) {  // tiny: recorded, several operators to a launch (tiny.hip)
         bool taken;
         if (int rc = tiny_try_enqueue(op, dtype, a, 0, stride_a, b, 0, stride_b, shape, ndim, nullptr, out, &taken)) return rc;
         if (taken) return SMHIP_OK;
@@ -1203,7 +1203,7 @@ int smhip_elementwise_inline(int op, int dtype, const void *a, size_t a_host_byt
     const int64_t esz = (int64_t)dtype_size(dtype);
     if ((a_host_bytes && (span_a + 1) * esz > (int64_t)a_host_bytes) || (b_host_bytes && (span_b + 1) * esz > (int64_t)b_host_bytes))
         return fail(SMHIP_ERR_INVALID, "elementwise_inline: the strides reach past the inline operand's bytes");
-    if (n <= 1024) {
+    if ((int64_t)n <= kTinyMaxResults) {
         bool taken;
         if (int rc = tiny_try_enqueue(op, dtype, a, a_host_bytes, stride_a, b, b_host_bytes, stride_b, shape, ndim, nullptr, out, &taken)) return rc;
         if (taken) return SMHIP_OK;
@@ -1262,7 +1262,7 @@ int smhip_copy_strided(int dtype, const void *src, const int64_t *src_strides, v
     if (n == 0) return SMHIP_OK;
     if (!src || !dst) return fail(SMHIP_ERR_INVALID, "copy_strided: null buffer");
     const size_t esz = dtype_size(dtype);
-    if (n <= 1024) {
+    if ((int64_t)n <= kTinyMaxResults) {
         bool taken;
         if (int rc = tiny_try_enqueue(0, dtype, src, 0, src_strides, nullptr, 0, dst_strides, shape, ndim, nullptr, dst, &taken, 2)) return rc;
         if (taken) return SMHIP_OK;
@@ -1276,7 +1276,7 @@ int smhip_contiguous(int op, int dtype, const void *a, const void *b, void *out,
     if (n == 0) return SMHIP_OK;
     if (!a || !b || !out) return fail(SMHIP_ERR_INVALID, "contiguous: null buffer");
     const size_t nbytes = n * dtype_size(dtype);
-    if (n <= 1024) {
+    if ((int64_t)n <= kTinyMaxResults) {
         const int64_t one = 1, shape1 = (int64_t)n;
         bool taken;
         if (int rc = tiny_try_enqueue(op, dtype, a, 0, &one, b, 0, &one, &shape1, 1, nullptr, out, &taken)) return rc;
@@ -1292,7 +1292,7 @@ int smhip_array_scalar(int op, int dtype, const void *a, const void *value_host,
     if (n == 0) return SMHIP_OK;
     if (!a || !value_host || !out) return fail(SMHIP_ERR_INVALID, "array_scalar: null buffer");
     const size_t nbytes = n * dtype_size(dtype);
-    if (n <= 1024) {
+    if ((int64_t)n <= kTinyMaxResults) {
         const int64_t one = 1, zero = 0, shape1 = (int64_t)n;
         bool taken;
         if (int rc = tiny_try_enqueue(op, dtype, a, 0, &one, nullptr, 0, &zero, &shape1, 1, value_host, out, &taken)) return rc;

@@ -20,7 +20,7 @@
 // A buffer freed while a recorded operator still refers to it (the benchmark bodies' `auto result = ...` dies at the end
 // of each iteration) is handed back to the pool only after the launch: the next result gets another block, and the
 // operators stay independent.  Eligible: + - * / of every element type and integer pow (Op::apply -- the very functions
-// the vector kernels' scalar tails use, so results are bit-identical to the one-launch path), at most 1024 results,
+// the vector kernels' scalar tails use, so results are bit-identical to the one-launch path), at most 4096 results,
 // operands of any strides (views, broadcasts) or host-built (<= 256 bytes), the output overlapping no operand, the
 // library's own queue (not a caller's stream).  SMHIP_TINY_BATCH=0 turns it off.
 #include <string.h>
@@ -38,7 +38,8 @@ namespace {
 using namespace dev;
 
 constexpr int kTinyMaxOps = 30;  // per launch; every one may start a list of its own
-constexpr uint32_t kTinyMaxOut = 1024;
+constexpr uint32_t kTinyMaxOut = kTinyMaxResults;  // internal.h: 4096
+constexpr int kTinyThreads = 256, kTinyThreadsWide = 1024;  // per workgroup; the wide form when an operator of the launch has more than 1024 results (a 64 x 64 array: four passes)
 constexpr int kTinyMaxMerged = 12;  // two lists are run as one only up to this many operators together
 constexpr size_t kTinyMaxInline = 256;
 constexpr int kTinySmallBytes = 960, kTinyBigBytes = 3904;  // argument blocks of 1 KiB and ~3.9 KiB (the launch writes the block it is given)
@@ -69,9 +70,10 @@ static_assert(sizeof(TinyArgs<kTinyBigBytes>) <= 4096, "one argument block");
 
 template <typename T, typename Op>
 __device__ __forceinline__ void tiny_run(const TinyOp *d, const char *base) {
-    const T *a = d->a_inl ? reinterpret_cast<const T *>(base + d->a_inl) : reinterpret_cast<const T *>(d->a);
-    const T *b = d->b_inl ? reinterpret_cast<const T *>(base + d->b_inl) : reinterpret_cast<const T *>(d->b);
-    T *out = reinterpret_cast<T *>(d->out);
+    // the output overlaps no operand (tiny_try_enqueue): the passes' loads need not wait for each other's stores
+    const T *__restrict__ a = d->a_inl ? reinterpret_cast<const T *>(base + d->a_inl) : reinterpret_cast<const T *>(d->a);
+    const T *__restrict__ b = d->b_inl ? reinterpret_cast<const T *>(base + d->b_inl) : reinterpret_cast<const T *>(d->b);
+    T *__restrict__ out = reinterpret_cast<T *>(d->out);
     const bool b_scalar = d->flags & 1;
     T sv;
     {
@@ -80,7 +82,7 @@ __device__ __forceinline__ void tiny_run(const TinyOp *d, const char *base) {
     }
     const int nd = d->ndim;
     const uint32_t n = d->n;
-    for (uint32_t e = threadIdx.x; e < n; e += 64) {
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         uint32_t rem = e, oa = 0, ob = 0;
         for (int k = 0; k < nd; ++k) {
             const uint32_t ext = d->shape[k];
@@ -95,8 +97,8 @@ __device__ __forceinline__ void tiny_run(const TinyOp *d, const char *base) {
 constexpr int kTinyFill = 250, kTinyCopy = 251;  // descriptor op codes next to SMHIP_OP_*: out[e] = scalar; out[sum idx * sb] = a[sum idx * sa]
 template <typename T>
 __device__ __forceinline__ void tiny_move(const TinyOp *d, const char *base) {
-    const T *a = d->a_inl ? reinterpret_cast<const T *>(base + d->a_inl) : reinterpret_cast<const T *>(d->a);
-    T *out = reinterpret_cast<T *>(d->out);
+    const T *__restrict__ a = d->a_inl ? reinterpret_cast<const T *>(base + d->a_inl) : reinterpret_cast<const T *>(d->a);
+    T *__restrict__ out = reinterpret_cast<T *>(d->out);
     T sv;
     {
         const uint64_t bits = d->scalar;
@@ -105,7 +107,7 @@ __device__ __forceinline__ void tiny_move(const TinyOp *d, const char *base) {
     const bool fill = d->op == kTinyFill;
     const int nd = d->ndim;
     const uint32_t n = d->n;
-    for (uint32_t e = threadIdx.x; e < n; e += 64) {
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         uint32_t rem = e, oa = 0, od = 0;
         for (int k = 0; k < nd; ++k) {
             const uint32_t ext = d->shape[k];
@@ -131,11 +133,11 @@ __device__ __forceinline__ void tiny_dtype(const TinyOp *d, const char *base) {
             break;
     }
 }
-// One workgroup of one wave per LIST of recorded operators (a list: operators that depend on each other, in call order); the
+// One workgroup (four waves) per LIST of recorded operators (a list: operators that depend on each other, in call order); the
 // descriptors are read from the argument block itself.  __syncthreads() between two operators of a list makes the first one's
 // stores visible to every lane of the workgroup before the second one loads (the barrier's release / acquire at workgroup scope).
 template <int BYTES>
-__global__ __launch_bounds__(64) void tiny_batch_kernel(TinyArgs<BYTES> args) {
+__global__ __launch_bounds__(kTinyThreadsWide) void tiny_batch_kernel(TinyArgs<BYTES> args) {
     (void)args;  // read through the kernarg pointer: indexing the by-value copy would spill it to scratch (inline.hip)
     const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t off = reinterpret_cast<const uint16_t *>(ka + offsetof(TinyArgs<BYTES>, head))[blockIdx.x];
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(64) void tiny_batch_kernel(TinyArgs<BYTES> args) {
 struct TinyQueue {
     std::recursive_mutex m;
     int count = 0, lists = 0;
+    uint32_t widest = 0;  // the largest result count recorded
     size_t used = 0;
     uint16_t head[kTinyMaxOps], tail[kTinyMaxOps], list_len[kTinyMaxOps];  // per list: byte offsets of its first and last operator, operators in it
     alignas(16) unsigned char bytes[kTinyBigBytes];
@@ -192,13 +195,13 @@ int flush_locked(TinyQueue &q) {
                 args.n_lists = (uint32_t)q.lists;
                 memcpy(args.head, q.head, sizeof args.head);
                 memcpy(args.bytes, q.bytes, q.used);
-                hipLaunchKernelGGL((tiny_batch_kernel<kTinySmallBytes>), dim3((unsigned)q.lists), dim3(64), 0, s, args);
+                hipLaunchKernelGGL((tiny_batch_kernel<kTinySmallBytes>), dim3((unsigned)q.lists), dim3(q.widest > 1024 ? kTinyThreadsWide : kTinyThreads), 0, s, args);
             } else {
                 TinyArgs<kTinyBigBytes> args;
                 args.n_lists = (uint32_t)q.lists;
                 memcpy(args.head, q.head, sizeof args.head);
                 memcpy(args.bytes, q.bytes, q.used);
-                hipLaunchKernelGGL((tiny_batch_kernel<kTinyBigBytes>), dim3((unsigned)q.lists), dim3(64), 0, s, args);
+                hipLaunchKernelGGL((tiny_batch_kernel<kTinyBigBytes>), dim3((unsigned)q.lists), dim3(q.widest > 1024 ? kTinyThreadsWide : kTinyThreads), 0, s, args);
             }
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) rc = fail(SMHIP_ERR_HIP, "tiny operators (%d in one launch): %s", q.count, hipGetErrorString(e));
@@ -209,6 +212,7 @@ int flush_locked(TinyQueue &q) {
     g_tiny_pending.fetch_sub(q.count, std::memory_order_relaxed);
     q.count = 0;
     q.lists = 0;
+    q.widest = 0;
     q.used = 0;
     q.n_reads = 0;
     std::vector<void *> dead;
@@ -365,6 +369,7 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
     if (ra.p) { q.reads[q.n_reads] = ra; q.read_list[q.n_reads++] = (unsigned char)list; }
     if (rb.p) { q.reads[q.n_reads] = rb; q.read_list[q.n_reads++] = (unsigned char)list; }
     q.used += extra;
+    if ((uint32_t)n > q.widest) q.widest = (uint32_t)n;
     ++q.count;
     g_tiny_pending.fetch_add(1, std::memory_order_relaxed);
     *taken = true;

@@ -209,7 +209,7 @@ def test_every_form_against_the_oracle(smhip, oracle):
 
 
 def test_switch_off_and_large_arrays_unaffected(smhip):
-    """SMHIP_TINY_BATCH=0 records nothing; arrays above 1024 results are launched as before."""
+    """SMHIP_TINY_BATCH=0 records nothing; arrays above 4096 results are launched as before."""
     code = ("import numpy as np, simplemath_amd as sma\n"
             "lib = sma.load()\n"
             "a = lib.to_device(np.arange(25, dtype=np.float32)); b = lib.to_device(np.ones(25, dtype=np.float32))\n"
@@ -225,7 +225,7 @@ def test_switch_off_and_large_arrays_unaffected(smhip):
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300, env=env2)
     assert r.returncode == 0 and "tiny (0, 0)" in r.stdout, r.stdout + r.stderr
     l0, o0 = smhip.tiny_stats()
-    a = smhip.to_device(np.arange(4096, dtype=np.float32))
+    a = smhip.to_device(np.arange(8192, dtype=np.float32))
     r = smhip.contiguous(sma.OP_ADD, a, a)
-    assert np.array_equal(r.numpy(), np.arange(4096, dtype=np.float32) * 2)
+    assert np.array_equal(r.numpy(), np.arange(8192, dtype=np.float32) * 2)
     assert smhip.tiny_stats() == (l0, o0)
