@@ -23,6 +23,7 @@ int acquire(hipStream_t *stream);
 int acquire_stream(hipStream_t *stream);
 // tiny.hip: operators on tiny arrays are recorded and go out several to a launch; acquire_stream() flushes them first.
 constexpr int64_t kTinyMaxResults = 4096;  // operators with at most this many results may be recorded
+bool tiny_any_recorded();
 int tiny_flush_device(int dev);
 bool tiny_defer_free(int dev, void *p, size_t bytes);
 bool tiny_context(int *dev);  // runtime.hip: may the calling thread record a tiny operator now?

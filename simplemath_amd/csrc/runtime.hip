@@ -928,7 +928,9 @@ int smhip_alloc(void **dptr, size_t bytes) {
 
 int smhip_free(void *dptr) {
     if (!dptr) return SMHIP_OK;
-    {   // a recorded tiny operator may still refer to it: then the block goes back to the pool after that launch (tiny.hip)
+    if (tls.op_depth == 0 && tiny_any_recorded()) {  // a recorded tiny operator may still refer to it: then the block goes back to the pool after that launch (tiny.hip)
+        // (not from inside an operator: what an operator frees is its own scratch, which no caller ever saw -- and its scope
+        // holds the dispatcher, which a flush in progress on another thread is waiting for)
         int dev = -1;
         size_t cls = 0;
         {

@@ -229,6 +229,8 @@ bool enabled() {
 
 }  // namespace
 
+bool tiny_any_recorded() { return g_tiny_pending.load(std::memory_order_relaxed) != 0; }
+
 int tiny_flush_device(int dev) {
     if (dev < 0 || dev >= kTinyDevices) return SMHIP_OK;
     if (g_tiny_pending.load(std::memory_order_relaxed) == 0) return SMHIP_OK;

@@ -341,7 +341,13 @@ int main() {
         }
         workers.emplace_back([&] {
             if (smhip_set_device(0) != SMHIP_OK) return;
-            for (int i = 0; i < 200; ++i) smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, big, &one, 8u << 20, big);
+            double total = 0;
+            for (int i = 0; i < 200; ++i) {
+                smhip_array_scalar(SMHIP_OP_ADD, SMHIP_F32, big, &one, 8u << 20, big);
+                // a reduction allocates and frees its partial sums INSIDE its operator scope, dispatcher held: a flush of recorded
+                // operators on another thread waits for that scope, so the frees in it must not wait for the flush
+                if (smhip_sum(SMHIP_F32, big, 8u << 20, &total) != SMHIP_OK || total != (double)(i + 1) * (double)(8u << 20)) { std::printf("  sum %d: %g\n", i, total); break; }
+            }
         });
         for (auto &t : workers) t.join();
         for (int w = 0; w < 4; ++w) {
