@@ -42,7 +42,7 @@ constexpr uint32_t kTinyMaxOut = kTinyMaxResults;  // internal.h: 4096
 constexpr int kTinyThreads = 256, kTinyThreadsWide = 1024;  // per workgroup; the wide form when an operator of the launch has more than 1024 results (a 64 x 64 array: four passes)
 constexpr int kTinyMaxMerged = 12;  // two lists are run as one only up to this many operators together
 constexpr size_t kTinyMaxInline = 256;
-constexpr int kTinySmallBytes = 960, kTinyBigBytes = 3904;  // argument blocks of 1 KiB and ~3.9 KiB (the launch writes the block it is given)
+constexpr int kTinySmallBytes = 1008, kTinyBigBytes = 3904;  // argument blocks of 1 KiB and ~3.9 KiB (the launch writes the block it is given)
 constexpr int kTinyDevices = 64;
 
 struct TinyOp {
@@ -59,12 +59,16 @@ struct TinyOp {
 };
 static_assert(sizeof(TinyOp) == 128, "descriptor layout");
 
+// The argument block as launched: the FIRST operator of list g sits at bytes + g * sizeof(TinyOp), so a workgroup finds its
+// work without reading an offset table first -- the argument block is host memory, every dependent read of it a trip over the
+// fabric (~1.3 us, inline.hip), and one operator waited for at once pays for each of them.  The other operators and the
+// host-built operands' bytes follow; `next`, `a_inl`, `b_inl` are laid out for this order by flush_locked().
 template <int BYTES> struct alignas(16) TinyArgs {
     uint32_t n_lists;
-    uint16_t head[kTinyMaxOps];  // byte offset of each list's first operator
+    uint32_t pad[3];
     unsigned char bytes[BYTES];
 };
-static_assert(offsetof(TinyArgs<kTinySmallBytes>, bytes) == 64 && sizeof(TinyArgs<kTinySmallBytes>) == 1024, "argument block layout");
+static_assert(offsetof(TinyArgs<kTinySmallBytes>, bytes) == 16 && sizeof(TinyArgs<kTinySmallBytes>) == kTinySmallBytes + 16, "argument block layout");
 static_assert(kTinyBigBytes + 1 < 65536 && kTinyMaxOps < 256, "offsets and list numbers fit their fields");
 static_assert(sizeof(TinyArgs<kTinyBigBytes>) <= 4096, "one argument block");
 
@@ -140,7 +144,7 @@ template <int BYTES>
 __global__ __launch_bounds__(kTinyThreadsWide) void tiny_batch_kernel(TinyArgs<BYTES> args) {
     (void)args;  // read through the kernarg pointer: indexing the by-value copy would spill it to scratch (inline.hip)
     const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t off = reinterpret_cast<const uint16_t *>(ka + offsetof(TinyArgs<BYTES>, head))[blockIdx.x];
+    uint32_t off = blockIdx.x * (uint32_t)sizeof(TinyOp);
     for (;;) {
         const char *base = ka + offsetof(TinyArgs<BYTES>, bytes) + off;
         const TinyOp *d = reinterpret_cast<const TinyOp *>(base);
@@ -163,6 +167,7 @@ struct TinyQueue {
     uint32_t widest = 0;  // the largest result count recorded
     size_t used = 0;
     uint16_t head[kTinyMaxOps], tail[kTinyMaxOps], list_len[kTinyMaxOps];  // per list: byte offsets of its first and last operator, operators in it
+    uint16_t op_off[kTinyMaxOps], op_len[kTinyMaxOps];  // per operator, in recording order: where its descriptor starts, descriptor + operand bytes
     alignas(16) unsigned char bytes[kTinyBigBytes];
     Span reads[2 * kTinyMaxOps], writes[kTinyMaxOps];
     unsigned char read_list[2 * kTinyMaxOps], write_list[kTinyMaxOps];  // which list the span's operator belongs to
@@ -180,6 +185,36 @@ bool overlap(const Span &x, const Span &y) {
     return a < b + y.bytes && b < a + x.bytes;
 }
 
+// The recorded block in launch order: list heads first, one descriptor slot each, then everything else (TinyArgs).
+template <int BYTES>
+void lay_out(const TinyQueue &q, TinyArgs<BYTES> &args) {
+    args.n_lists = (uint32_t)q.lists;
+    const int n = q.count;
+    auto index_of = [&](uint32_t off) { for (int i = 0; i < n; ++i) if (q.op_off[i] == off) return i; return -1; };
+    uint16_t at[kTinyMaxOps], payload[kTinyMaxOps];  // new descriptor offsets; where a head's operand bytes go
+    bool is_head[kTinyMaxOps] = {};
+    for (int l = 0; l < q.lists; ++l) {
+        const int i = index_of(q.head[l]);
+        at[i] = (uint16_t)(l * sizeof(TinyOp));
+        is_head[i] = true;
+    }
+    size_t tail = (size_t)q.lists * sizeof(TinyOp);
+    for (int i = 0; i < n; ++i) {
+        if (is_head[i]) { payload[i] = (uint16_t)tail; tail += q.op_len[i] - sizeof(TinyOp); }
+        else { at[i] = (uint16_t)tail; payload[i] = (uint16_t)(tail + sizeof(TinyOp)); tail += q.op_len[i]; }
+    }
+    for (int i = 0; i < n; ++i) {
+        TinyOp d;
+        memcpy(&d, q.bytes + q.op_off[i], sizeof d);
+        if (d.next) d.next = (uint16_t)(at[index_of(d.next - 1u)] + 1);
+        const int shift = (int)payload[i] - (int)at[i] - (int)sizeof(TinyOp);  // how far the operand bytes moved against the descriptor
+        if (d.a_inl) d.a_inl = (uint16_t)(d.a_inl + shift);
+        if (d.b_inl) d.b_inl = (uint16_t)(d.b_inl + shift);
+        memcpy(args.bytes + at[i], &d, sizeof d);
+        if (q.op_len[i] > sizeof(TinyOp)) memcpy(args.bytes + payload[i], q.bytes + q.op_off[i] + sizeof(TinyOp), q.op_len[i] - sizeof(TinyOp));
+    }
+}
+
 // Launches what is recorded.  Caller holds q.m.
 int flush_locked(TinyQueue &q) {
     if (q.count == 0 || q.flushing) return SMHIP_OK;
@@ -192,15 +227,11 @@ int flush_locked(TinyQueue &q) {
         if (rc == SMHIP_OK) {
             if (q.used <= (size_t)kTinySmallBytes) {
                 TinyArgs<kTinySmallBytes> args;
-                args.n_lists = (uint32_t)q.lists;
-                memcpy(args.head, q.head, sizeof args.head);
-                memcpy(args.bytes, q.bytes, q.used);
+                lay_out(q, args);
                 hipLaunchKernelGGL((tiny_batch_kernel<kTinySmallBytes>), dim3((unsigned)q.lists), dim3(q.widest > 1024 ? kTinyThreadsWide : kTinyThreads), 0, s, args);
             } else {
                 TinyArgs<kTinyBigBytes> args;
-                args.n_lists = (uint32_t)q.lists;
-                memcpy(args.head, q.head, sizeof args.head);
-                memcpy(args.bytes, q.bytes, q.used);
+                lay_out(q, args);
                 hipLaunchKernelGGL((tiny_batch_kernel<kTinyBigBytes>), dim3((unsigned)q.lists), dim3(q.widest > 1024 ? kTinyThreadsWide : kTinyThreads), 0, s, args);
             }
             const hipError_t e = hipGetLastError();
@@ -365,6 +396,8 @@ int tiny_try_enqueue(int op, int dtype, const void *a, size_t a_host_bytes, cons
         ++q.appended;
     }
     q.tail[list] = (uint16_t)q.used;
+    q.op_off[q.count] = (uint16_t)q.used;
+    q.op_len[q.count] = (uint16_t)extra;
     ++q.list_len[list];
     q.writes[q.count] = w;
     q.write_list[q.count] = (unsigned char)list;
