@@ -48,6 +48,9 @@ r = orc.Reference()
 print('the reference on this host (oracle/ref_shim.cpp: ref_bench_tiny), ns per iteration: simple_check %.0f  BM_SMArrayPow_1D %.0f  BM_SMArrayPow_2D %.0f' % tuple(r.bench_tiny(k, 300000) for k in range(3)))" >> $out/small_breakdown.txt 2>&1
   tail -4 $out/small_breakdown.txt
   timeout -k 10 200 python tools/pow64_rate.py > $out/pow64_rate.txt 2>&1; tail -14 $out/pow64_rate.txt
+  (echo "# SMHIP_TINY_BATCH=0 (one launch per operator)"; SMHIP_TINY_BATCH=0 timeout 200 python tools/tiny_latency.py; echo "# recorded (default)"; timeout 200 python tools/tiny_latency.py; \
+   echo "# SMHIP_TINY_BATCH=0 again"; SMHIP_TINY_BATCH=0 timeout 200 python tools/tiny_latency.py) > $out/tiny_latency.txt 2>&1
+  timeout -k 10 200 simplemath_amd/bin/pool_streams > $out/pool_streams.txt 2>&1; tail -1 $out/pool_streams.txt
   echo "part c done"
 else
   timeout -k 10 300 python tools/chain_fused_rates.py > $out/chain_fused_rates.txt 2>&1; cat $out/chain_fused_rates.txt
