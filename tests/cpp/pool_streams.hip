@@ -275,7 +275,10 @@ int main() {
         OK(smhip_set_stream(nullptr));
         OK(smhip_tiny_stats(&l1, &o1));
         std::printf("  tiny operators recorded %llu, launches %llu\n", o1 - o0, l1 - l0);
-        CHECK(o1 - o0 == 2 && l1 - l0 == 1);
+        {
+            const char *e = getenv("SMHIP_TINY_BATCH");
+            if (!(e && *e && atoi(e) == 0)) CHECK(o1 - o0 == 2 && l1 - l0 == 1);  // (switched off: nothing is recorded, everything else must hold all the same)
+        }
         // a recorded result consumed by another host thread, then freed by it while the producer records more
         OK(smhip_array_scalar(SMHIP_OP_SUB, SMHIP_F32, a, &one, T, b));   // recorded: b = 6
         bool ok_thread = false;
