@@ -113,7 +113,10 @@ __global__ __launch_bounds__(BLOCK) void devscalar_vec_kernel(const T *__restric
 // copy of the same bytes (tools/sweep_pow2.hip, profiles/r02_sweep_pow2.txt); one vector per lane is 97-99 us -- the
 // second load in flight is what covers the arithmetic.  Full tiles are guard-free (per-vector guards make the compiler
 // wait for each load in turn); the last, partial tile and the n % W scalar tail belong to the last workgroup.
-constexpr int kTileBlock = 256;
+#ifndef SMHIP_FLAT_TILE_THREADS
+#define SMHIP_FLAT_TILE_THREADS 256
+#endif
+constexpr int kTileBlock = SMHIP_FLAT_TILE_THREADS;  // (512: tools/build_variant.sh; measured for config 3's cold leg on two queues)
 // KEEP_STORES: the write side's policy (ops.hip.h: store_stream_if) as a template parameter -- as a run-time branch in
 // front of each store it cut the arithmetic of the tile's vectors apart (config 4: 73.2 -> 79.0 us).
 // KIND 0: a op b, 1: a op s, 2: s op a (the heavy Ops only); 3 / 4: a dense (rows x cols) against ONE ROW / ONE COLUMN of

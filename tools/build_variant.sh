@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/bin/obj_$name; mkdir -p $out
-for f in runtime contiguous broadcast reduce fill fused chain jit sharded inline; do
+for f in runtime contiguous broadcast reduce fill fused chain tiny jit sharded inline; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -I$root/include -I$root/simplemath_amd/csrc "$@" -c $root/simplemath_amd/csrc/$f.hip -o $out/$f.o &
 done
 wait
