@@ -88,6 +88,7 @@ struct FusionStats {
     unsigned long long fused_stages = 0;  // operators inside them
     unsigned long long single_ops = 0;    // deferred operators that ended up alone and ran as the plain operator
     unsigned long long direct_assignments = 0;  // `x = <expression>` evaluated straight into x (no temporary, no copy)
+    unsigned long long summed_chains = 0;       // `(<expression>).sum()` taken in the chain's own pass, the value never written
 };
 inline thread_local FusionStats tls_fusion_stats;
 // The end of a full-expression, seen from the destructor of one of its temporaries.
@@ -683,7 +684,15 @@ public:
         }
     }
     // Sum of all elements, accumulated in fp64 on the device.
-    double sum() const {
+    // ... of a TEMPORARY: sm::pow(a - b, 2.0f).sum().  The unevaluated result of this expression's chain, which nobody can look
+    // at afterwards, is not computed at all: its sum is taken in the chain's own pass (smhip_chain_sum).  (Only the rvalue form:
+    // a named array -- a by-value parameter bound to such a temporary -- may be read again after its sum.)
+    double sum() && {
+        static_assert(hip::dtype_of<T>::id >= 0, "sum(): element type has no kernels");
+        if (detail::Chain<T> *c = pending_temporary()) return c->run_sum();
+        return static_cast<const SMArray &>(*this).sum();
+    }
+    double sum() const & {
         static_assert(hip::dtype_of<T>::id >= 0, "sum(): element type has no kernels");
         hip::DeviceGuard on(device());
         std::unique_ptr<SMArray> holder;
@@ -718,10 +727,14 @@ private:
     // Is this array the unevaluated result of the chain pending on this thread, with nobody else holding its storage?  Only
     // then may an operator that consumes it (as a temporary) continue the chain instead of reading the result.
     detail::Chain<T> *continuable() const {
+        detail::Chain<T> *c = pending_temporary();
+        return (c && !c->full()) ? c : nullptr;
+    }
+    // ... the chain itself, room for another stage or not (a reduction of its value takes no stage)
+    detail::Chain<T> *pending_temporary() const {
         const auto &st = data.storage();
         if (!st || !st->pending || detail::tls_pending != st->pending.get() || isView || data.offset() != 0 || st.use_count() != 1) return nullptr;
-        auto *c = static_cast<detail::Chain<T> *>(st->pending.get());
-        return c->full() ? nullptr : c;
+        return static_cast<detail::Chain<T> *>(st->pending.get());
     }
 
 public:
@@ -1020,6 +1033,34 @@ struct Chain final : PendingBase {
         ++tls_fusion_stats.chains;
         tls_fusion_stats.fused_stages += static_cast<unsigned long long>(n - 1);
         hip::check(smhip_chain(hip::dtype_of<T>::id, n, ptrs, strides, scalars, ops, swapped, sh, nd, dst));
+    }
+
+    // The SUM of the chain's value instead of the value (SMArray::sum() of the expression's unevaluated temporary): the same
+    // operands and stages through smhip_chain_sum; the result's storage is left without elements -- it is a temporary nobody
+    // else refers to (pending_temporary()), and goes away with the expression.
+    double run_sum() {
+        std::unique_ptr<PendingBase> self = std::move(out->pending);
+        if (tls_pending == this) tls_pending = nullptr;
+        hip::DeviceGuard on(device);
+        const int n = n_leaves, nd = out_ndim;
+        std::int64_t strides[kMaxLeaves * MAX_NDIM] = {}, sh[MAX_NDIM];
+        for (int i = 0; i < nd; ++i) sh[i] = static_cast<std::int64_t>(out_shape[i]);
+        const void *ptrs[kMaxLeaves] = {};
+        T scalars[kMaxLeaves] = {};
+        for (int k = 0; k < n; ++k) {
+            const Leaf &lf = leaves[k];
+            if (lf.is_scalar) { scalars[k] = lf.value; continue; }
+            const int shift = nd - lf.ndim;
+            for (int i = 0; i < lf.ndim; ++i)
+                strides[k * nd + shift + i] = (lf.shape[i] == 1 && out_shape[shift + i] != 1) ? 0 : static_cast<std::int64_t>(lf.strides[i]);
+            ptrs[k] = lf.st->dev_ro() + lf.offset;
+        }
+        ++tls_fusion_stats.chains;
+        ++tls_fusion_stats.summed_chains;
+        tls_fusion_stats.fused_stages += static_cast<unsigned long long>(n - 1);
+        double total = 0;
+        hip::check(smhip_chain_sum(hip::dtype_of<T>::id, n, ptrs, strides, scalars, ops, swapped, sh, nd, &total));
+        return total;
     }
 
 private:

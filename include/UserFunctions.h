@@ -178,6 +178,10 @@ template <typename T>
 double sum(const SMArray<T> &arr) {
     return arr.sum();
 }
+template <typename T>
+double sum(SMArray<T> &&arr) {  // sm::sum(sm::pow(a - b, 2.0f)): the expression's temporary, summed in its chain's own pass
+    return std::move(arr).sum();
+}
 
 // Block until every queued kernel has finished (operators are asynchronous;
 // anything that reads values on the host synchronises by itself).

@@ -236,6 +236,17 @@ int smhip_fused_contiguous(int op1, int op2, int dtype, const void *a, const voi
 int smhip_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
                 const int *ops, const int *swapped, const int64_t *shape, int ndim, void *out);
 
+/* The SUM of a chain's value -- sm::pow(a - b, 2.0f).sum(), a squared error -- without writing the value: the arguments of
+ * smhip_chain minus `out`; accumulation as smhip_sum (fp64 for the float types, wrapping 64-bit for the integer types, each
+ * element first rounded to the element type stage by stage as the operators round it).  One pass over the operands when
+ * every one of them is dense or a scalar (8 bytes per f32 element for two operands, against 12 + 4 for the chain and the sum
+ * of its result); otherwise the chain into a pooled temporary and smhip_sum of that.  The _async form leaves the fp64 result in
+ * device memory (stream-ordered, like smhip_sum_async); the other waits and returns it. */
+int smhip_chain_sum_async(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
+                          const int *ops, const int *swapped, const int64_t *shape, int ndim, double *sum_dev);
+int smhip_chain_sum(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
+                    const int *swapped, const int64_t *shape, int ndim, double *sum_host);
+
 /* ----------------------------------------------------------- multi-GPU */
 /* The reference's only fan-out is the OpenMP `parallel for` over chunks of the output (calculate.h:47, :152).  Its
  * MI355X counterpart is the RESULT's outermost dimension cut into one block per GPU of the node: elementwise blocks

@@ -347,6 +347,47 @@ class Smhip:
                 self._ck(rc)
         return call, out
 
+    def chain_sum_call(self, first: DeviceArray, *stages):
+        """(callable -> float): the prepared smhip_chain_sum call for the sum of `chain(first, *stages)`'s value, which is not written."""
+        dt = first.dtype
+        shape = list(first.shape)
+        for st in stages:
+            x = st[1]
+            if isinstance(x, DeviceArray):
+                assert x.dtype == dt
+                res = self.broadcast(shape, [0] * len(shape), x.shape, x.strides)
+                if res is None:
+                    raise RuntimeError("Cannot broadcast shapes: incompatible dimensions")
+                shape = res[0]
+        nd = len(shape)
+        operands = [first] + [st[1] for st in stages]
+        strides, ptrs, scal = [], [], np.zeros(len(operands), dtype=dt)
+        for k, x in enumerate(operands):
+            if isinstance(x, DeviceArray):
+                res = self.broadcast(shape, [0] * nd, x.shape, x.strides)
+                strides += list(res[2])
+                ptrs.append(x.ptr)
+            else:
+                strides += [0] * nd
+                ptrs.append(None)
+                scal[k] = x
+        ops = (C.c_int * len(stages))(*[int(st[0]) for st in stages])
+        swp = (C.c_int * len(stages))(*[1 if len(st) > 2 and st[2] else 0 for st in stages])
+        result = C.c_double(0.0)
+        args = (C.c_int(DTYPES[dt]), C.c_int(len(operands)), (C.c_void_p * len(operands))(*ptrs), _i64(strides),
+                scal.ctypes.data_as(C.c_void_p), ops, swp, _i64(shape), C.c_int(nd), C.byref(result))
+        keep = (operands, scal)
+        fn = self.c.smhip_chain_sum
+
+        def call(_keep=keep):
+            self._ck(fn(*args))
+            return result.value
+        return call
+
+    def chain_sum(self, first: DeviceArray, *stages):
+        """sum(chain(first, *stages)) without writing the chain's value (smhip_chain_sum): fp64 / wrapping 64-bit accumulation."""
+        return self.chain_sum_call(first, *stages)()
+
     def chain(self, first: DeviceArray, *stages, out: DeviceArray | None = None):
         """An operator chain in as few passes as possible (smhip_chain): r = first; then for each stage (op, x) -- or
         (op, x, True) for the swapped form x op r -- r = r op x with NumPy broadcasting; x a DeviceArray or a scalar.

@@ -221,6 +221,67 @@ __global__ __launch_bounds__(1024) void chain_kernel(ChainArgs<T> A, T *__restri
     }
 }
 
+// ---- a chain's SUM without its result: `sm::pow(a - b, 2.0f).sum()`, the squared error, in one pass of 8 bytes per element ----
+// Dense operands and scalars only.  One vector per lane; each element of the chain's value -- rounded to T stage by stage, as
+// the operators round -- is widened (fp64 / wrapping 64-bit, reduce.hip: AccOf) and summed: lanes of a wave by DPP moves, waves
+// in index order, one partial per workgroup; reduce.hip's finishing launch folds the partials in its fixed order, so the bits
+// are the same on every run.  (Same scheme as the hipRTC expression + sum kernel, jit.hip.)
+template <typename T, bool INTEGER = std::is_integral<T>::value> struct ChainAcc { typedef double type; };
+template <typename T> struct ChainAcc<T, true> { typedef uint64_t type; };
+template <typename T, typename A> __device__ __forceinline__ A chain_widen(T x) {
+    if constexpr (std::is_integral<T>::value && std::is_signed<T>::value) return (A)(int64_t)x;
+    else return (A)x;
+}
+template <int CTRL, int ROW_MASK, typename A> __device__ __forceinline__ A chain_dpp(A v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(A, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int kChainSumBlock = 256;
+template <typename T, int ND>
+__global__ __launch_bounds__(kChainSumBlock) void chain_sum_kernel(ChainArgs<T> A, typename ChainAcc<T>::type *__restrict__ partials, size_t n_vec, int tail, int pol) {
+    typedef typename VecTraits<T>::vec_t V;
+    typedef typename VecTraits<T>::full_t F;
+    typedef typename ChainAcc<T>::type Acc;
+    constexpr int W = VecTraits<T>::width;
+    const size_t i = (size_t)blockIdx.x * kChainSumBlock + threadIdx.x;
+    Acc acc = 0;
+    F d[ND], r[1], s[1];
+    if (i < n_vec) {
+        if (pol & kLoadNt) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) d[k] = load_stream_as(T, reinterpret_cast<const V *>(A.dense[k]) + i, true);
+        } else {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) d[k] = load_stream_as(T, reinterpret_cast<const V *>(A.dense[k]) + i, false);
+        }
+        const F v = chain_eval<T, ND, 0, 0>(A, d, r, s);
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc += chain_widen<T, Acc>(v[e]);
+    } else if (i == n_vec && tail) {  // the n % W elements past the last whole vector
+#pragma unroll
+        for (int k = 0; k < ND; ++k)
+            for (int e = 0; e < W; ++e) d[k][e] = e < tail ? A.dense[k][n_vec * W + e] : T(1);
+        const F v = chain_eval<T, ND, 0, 0>(A, d, r, s);
+        for (int e = 0; e < tail; ++e) acc += chain_widen<T, Acc>(v[e]);
+    }
+    acc += chain_dpp<0x111, 0xf>(acc);  // row_shr:1, 2, 4, 8, then row_bcast:15 and :31 -- the wave's total ends up in lane 63
+    acc += chain_dpp<0x112, 0xf>(acc);
+    acc += chain_dpp<0x114, 0xf>(acc);
+    acc += chain_dpp<0x118, 0xf>(acc);
+    acc += chain_dpp<0x142, 0xa>(acc);
+    acc += chain_dpp<0x143, 0xc>(acc);
+    __shared__ Acc lds[kChainSumBlock / 64];
+    if ((threadIdx.x & 63) == 63) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Acc total = lds[0];
+        for (int w = 1; w < kChainSumBlock / 64; ++w) total += lds[w];  // index order
+        partials[blockIdx.x] = total;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 enum LeafKind { kDense, kRow, kSplat, kScalar, kComplex };
 
@@ -545,6 +606,93 @@ int launch_expr_bcast(const char *expr, int dtype, const void *const *operands, 
     for (int k = 0; k < n_operands; ++k) { all_dense = all_dense && forms[k].kind == 0; dense[k] = forms[k].ptr; }
     if (all_dense) return jit_fused_expr(expr, dtype, dense, n_operands, scalars_host, n_scalars, out, pb.n, nullptr, s);  // the flat kernel
     return jit_fused_expr_bcast(expr, dtype, forms, n_operands, scalars_host, n_scalars, out, pb.n, s);
+}
+
+namespace {
+// The one-pass sum of a chain whose operands are all dense or scalars (chain_sum_kernel); false: not that kind of chain.
+template <typename T>
+int try_chain_sum(const Problem &pb, int n_operands, const void *const *operands, const int64_t *strides, int ndim, const void *scalars_host,
+                  const int *ops, const int *swapped, double *sum_dev, hipStream_t s, bool *done) {
+    *done = false;
+    constexpr int W = VecTraits<T>::width;
+    const int n_stages = n_operands - 1;
+    if (n_stages > kMaxStages) return SMHIP_OK;
+    ChainArgs<T> A{};
+    int nd = 0;
+    Few<Span, kMaxDense> reads;
+    auto slot_of = [&](int k, int stage) -> int {
+        if (!operands[k]) {
+            if (stage >= 0) memcpy(&A.scalar[stage], static_cast<const char *>(scalars_host) + (size_t)k * sizeof(T), sizeof(T));
+            return kSlotScalar;
+        }
+        uint64_t P, R, C;
+        bool writeout;
+        if (classify(pb, strides + (size_t)k * ndim, &P, &R, &C, &writeout) != kDense) return -1;
+        for (int j = 0; j < nd; ++j)
+            if (A.dense[j] == operands[k]) return j;
+        if (nd >= kMaxDense) return -1;
+        A.dense[nd] = static_cast<const T *>(operands[k]);
+        reads.push_back({operands[k], pb.n * sizeof(T)});
+        return nd++;
+    };
+    const int head = slot_of(0, -1);
+    if (head < 0 || head == kSlotScalar) return SMHIP_OK;
+    A.head = (uint32_t)head;
+    A.n_stages = (uint32_t)n_stages;
+    for (int k = 0; k < n_stages; ++k) {
+        if (ops[k] == SMHIP_OP_POW) {  // only the square is a stage (launch_chain)
+            T e;
+            memcpy(&e, static_cast<const char *>(scalars_host) + (size_t)(k + 1) * sizeof(T), sizeof(T));
+            if (operands[k + 1] || swapped[k] || !(e == T(2))) return SMHIP_OK;
+        }
+        const int slot = slot_of(k + 1, k);
+        if (slot < 0) return SMHIP_OK;
+        A.stage[k] = (uint32_t)ops[k] | (uint32_t)slot << 8 | (uint32_t)(swapped[k] ? 1 : 0) << 16;
+    }
+    const size_t n_vec = pb.n / W;
+    const int tail = (int)(pb.n % W);
+    const size_t grid = (n_vec + (tail ? 1 : 0) + kChainSumBlock - 1) / kChainSumBlock;
+    if (grid == 0 || grid > 0x7fffffffu) return SMHIP_OK;
+    int pol = stream_policy((size_t)nd * pb.n * sizeof(T), 0);
+    pol = refine_policy(pol, reads.data(), reads.size(), {nullptr, 0});
+    double *scratch;
+    ScratchLease lease;
+    if (int rc = lease.take(grid + grid / kReduceFoldSpan + 2, &scratch)) return rc;
+    typedef typename ChainAcc<T>::type Acc;
+    Acc *partials = reinterpret_cast<Acc *>(scratch);
+    switch (nd) {
+        case 1: hipLaunchKernelGGL((chain_sum_kernel<T, 1>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
+        case 2: hipLaunchKernelGGL((chain_sum_kernel<T, 2>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
+        case 3: hipLaunchKernelGGL((chain_sum_kernel<T, 3>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
+        default: hipLaunchKernelGGL((chain_sum_kernel<T, 4>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
+    }
+    SMHIP_LAUNCH_CHECK("chain_sum_kernel");
+    *done = true;
+    return reduce_finish(pb.dtype, scratch, grid, sum_dev, s);
+}
+}  // namespace
+
+// The sum of a chain's value (fp64 / wrapping 64-bit accumulation, as smhip_sum) without writing the value: one pass when every
+// operand is dense or a scalar; otherwise the chain into a temporary, then the sum of that.
+int launch_chain_sum(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
+                     const int *ops, const int *swapped, const int64_t *shape, int ndim, double *sum_dev, hipStream_t s) {
+    Problem pb;
+    make_problem(dtype, shape, ndim, &pb);
+    if (pb.n == 0) return fail(SMHIP_ERR_INVALID, "chain_sum: empty shape");
+    bool done = false;
+    int rc = SMHIP_OK;
+    switch (dtype) {
+        case SMHIP_F32: rc = try_chain_sum<float>(pb, n_operands, operands, strides, ndim, scalars_host, ops, swapped, sum_dev, s, &done); break;
+        case SMHIP_F64: rc = try_chain_sum<double>(pb, n_operands, operands, strides, ndim, scalars_host, ops, swapped, sum_dev, s, &done); break;
+        case SMHIP_I32: rc = try_chain_sum<int32_t>(pb, n_operands, operands, strides, ndim, scalars_host, ops, swapped, sum_dev, s, &done); break;
+        default: rc = try_chain_sum<int64_t>(pb, n_operands, operands, strides, ndim, scalars_host, ops, swapped, sum_dev, s, &done); break;
+    }
+    if (rc || done) return rc;
+    Temps temps;
+    void *value;
+    if (int rc2 = temps.take(pb.n * pb.esz, &value)) return rc2;
+    if (int rc2 = launch_chain(dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, value, s)) return rc2;
+    return launch_sum(dtype, value, pb.n, sum_dev, s);
 }
 
 int launch_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,

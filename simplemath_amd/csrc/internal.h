@@ -191,6 +191,8 @@ int launch_fused(int op1, int op2, int dtype, const void *a, const void *b, cons
 // chain.hip: r = x0; r = r op[k] x[k+1] (swapped[k]: x[k+1] op[k] r) over broadcast operands, as few passes as possible
 int launch_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
                  const int *swapped, const int64_t *shape, int ndim, void *out, hipStream_t s);
+int launch_chain_sum(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
+                     const int *swapped, const int64_t *shape, int ndim, double *sum_dev, hipStream_t s);
 // An operand of smhip_fused_expr_bcast in the index form chain.hip found for it: kind 0 dense a[i], 1 row a[i mod P] (P a
 // whole number of vectors), 2 splat a[(i / R) mod C]
 struct ExprLeaf { int kind; const void *ptr; uint64_t P, R, C; };

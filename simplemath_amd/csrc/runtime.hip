@@ -1343,33 +1343,44 @@ int smhip_fused_expr_bcast(const char *hip_expression, int dtype, const void *co
     return launch_expr_bcast(hip_expression, dtype, operands, strides, n_operands, scalars_host, n_scalars, shape, ndim, out, s);
 }
 
-int smhip_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
-                const int *swapped, const int64_t *shape, int ndim, void *out) {
-    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "chain: bad dtype %d", dtype);
-    if (n_operands < 2 || n_operands > SMHIP_CHAIN_MAX_OPERANDS) return fail(SMHIP_ERR_INVALID, "chain: %d operands outside 2..%d", n_operands, SMHIP_CHAIN_MAX_OPERANDS);
-    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "chain: ndim %d outside 1..%d", ndim, SMHIP_MAX_NDIM);
-    if (!operands || !strides || !ops || !swapped || !shape) return fail(SMHIP_ERR_INVALID, "chain: null argument");
-    if (!operands[0]) return fail(SMHIP_ERR_INVALID, "chain: the first operand must be an array");
+namespace {
+// What smhip_chain and smhip_chain_sum check alike; *n_out = the result's element count.
+int check_chain(const char *who, int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
+                const int *ops, const int *swapped, const int64_t *shape, int ndim, int64_t *n_out) {
+    if (!valid_dtype(dtype)) return fail(SMHIP_ERR_INVALID, "%s: bad dtype %d", who, dtype);
+    if (n_operands < 2 || n_operands > SMHIP_CHAIN_MAX_OPERANDS) return fail(SMHIP_ERR_INVALID, "%s: %d operands outside 2..%d", who, n_operands, SMHIP_CHAIN_MAX_OPERANDS);
+    if (ndim < 1 || ndim > SMHIP_MAX_NDIM) return fail(SMHIP_ERR_INVALID, "%s: ndim %d outside 1..%d", who, ndim, SMHIP_MAX_NDIM);
+    if (!operands || !strides || !ops || !swapped || !shape) return fail(SMHIP_ERR_INVALID, "%s: null argument", who);
+    if (!operands[0]) return fail(SMHIP_ERR_INVALID, "%s: the first operand must be an array", who);
     int64_t n = 1;
     for (int i = 0; i < ndim; ++i) {
-        if (shape[i] < 0) return fail(SMHIP_ERR_INVALID, "chain: negative extent at dim %d", i);
+        if (shape[i] < 0) return fail(SMHIP_ERR_INVALID, "%s: negative extent at dim %d", who, i);
         n *= shape[i];
     }
     for (int k = 0; k < n_operands; ++k) {
         if (!operands[k]) {
-            if (!scalars_host) return fail(SMHIP_ERR_INVALID, "chain: operand %d is a scalar but scalars_host is NULL", k);
+            if (!scalars_host) return fail(SMHIP_ERR_INVALID, "%s: operand %d is a scalar but scalars_host is NULL", who, k);
             continue;
         }
         for (int i = 0; i < ndim; ++i)
-            if (strides[(size_t)k * ndim + i] < 0) return fail(SMHIP_ERR_INVALID, "chain: negative stride (operand %d, dim %d)", k, i);
+            if (strides[(size_t)k * ndim + i] < 0) return fail(SMHIP_ERR_INVALID, "%s: negative stride (operand %d, dim %d)", who, k, i);
     }
     for (int k = 0; k + 1 < n_operands; ++k) {
         if (ops[k] == SMHIP_OP_POW) {  // r ^ scalar only: sm::pow(<expression>, s)
-            if (operands[k + 1] || swapped[k]) return fail(SMHIP_ERR_UNSUPPORTED, "chain: pow (stage %d) takes the chain's value to a SCALAR power", k);
+            if (operands[k + 1] || swapped[k]) return fail(SMHIP_ERR_UNSUPPORTED, "%s: pow (stage %d) takes the chain's value to a SCALAR power", who, k);
             continue;
         }
-        if (ops[k] < SMHIP_OP_ADD || ops[k] > SMHIP_OP_DIV) return fail(SMHIP_ERR_UNSUPPORTED, "chain: op %d (stage %d) is not one of add, sub, mul, div, pow", ops[k], k);
+        if (ops[k] < SMHIP_OP_ADD || ops[k] > SMHIP_OP_DIV) return fail(SMHIP_ERR_UNSUPPORTED, "%s: op %d (stage %d) is not one of add, sub, mul, div, pow", who, ops[k], k);
     }
+    *n_out = n;
+    return SMHIP_OK;
+}
+}  // namespace
+
+int smhip_chain(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
+                const int *swapped, const int64_t *shape, int ndim, void *out) {
+    int64_t n;
+    if (int rc = check_chain("chain", dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, &n)) return rc;
     if (n == 0) return SMHIP_OK;
     if (!out) return fail(SMHIP_ERR_INVALID, "chain: null output");
     Span reads[SMHIP_CHAIN_MAX_OPERANDS];
@@ -1379,6 +1390,27 @@ int smhip_chain(int dtype, int n_operands, const void *const *operands, const in
     OpScope op_scope_;
     if (int rc = op_scope_.begin(reads, (size_t)n_operands, Span{out, (size_t)n * dtype_size(dtype)}, &s)) return rc;
     return launch_chain(dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, out, s);
+}
+
+int smhip_chain_sum_async(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host,
+                          const int *ops, const int *swapped, const int64_t *shape, int ndim, double *sum_dev) {
+    int64_t n;
+    if (int rc = check_chain("chain_sum", dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, &n)) return rc;
+    if (!sum_dev) return fail(SMHIP_ERR_INVALID, "chain_sum: null result");
+    if (n == 0) return fail(SMHIP_ERR_INVALID, "chain_sum: empty shape");
+    SMHIP_ACQUIRE(s);  // a reduction: undeclared spans, ordered behind everything (like smhip_sum_async)
+    return launch_chain_sum(dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, sum_dev, s);
+}
+
+int smhip_chain_sum(int dtype, int n_operands, const void *const *operands, const int64_t *strides, const void *scalars_host, const int *ops,
+                    const int *swapped, const int64_t *shape, int ndim, double *sum_host) {
+    if (!sum_host) return fail(SMHIP_ERR_INVALID, "chain_sum: null result");
+    void *h = nullptr, *d = nullptr;
+    if (int rc = result_slot(&h, &d)) return rc;
+    if (int rc = smhip_chain_sum_async(dtype, n_operands, operands, strides, scalars_host, ops, swapped, shape, ndim, static_cast<double *>(d))) return rc;
+    if (int rc = smhip_synchronize()) return rc;
+    *sum_host = *static_cast<const volatile double *>(h);
+    return SMHIP_OK;
 }
 
 int smhip_sum_async(int dtype, const void *a, size_t n, double *out_dev) {

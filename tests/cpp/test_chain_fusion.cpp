@@ -6,6 +6,7 @@
 // statement evaluated on the host in T.
 #include <sm.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -289,6 +290,28 @@ static void powers() {
         auto u2 = sm::pow(u1, T(1));
         auto u3 = u2 * T(3);
         CHECK(same_bits(g, u3));
+    }
+    {   // the squared error: the sum in the chain's own pass, the squares never written
+        const auto before = sm::fusion_stats().summed_chains;
+        const double got = sm::pow(A - B, T(2)).sum(), got2 = sm::sum((A - B) * (A - B));
+        CHECK(sm::fusion_stats().summed_chains == before + 2);
+        auto t1 = A - B;
+        auto t2 = sm::pow(t1, T(2));
+        const double want = t2.sum();  // a named value: computed, then summed
+        CHECK(sm::fusion_stats().summed_chains == before + 2);
+        double scale = 0;
+        for (std::size_t i = 0; i < t2.totalSize; ++i) scale += std::fabs(static_cast<double>(t2.cdata()[i]));
+        CHECK(std::fabs(got - want) <= 1e-15 * scale && std::fabs(got2 - want) <= 1e-15 * scale);
+        // a row operand: the chain into a temporary, then its sum -- still through the one call
+        const double gr = ((A - row) * B).sum();
+        auto u1 = A - row;
+        auto u2 = u1 * B;
+        double scale2 = 0;
+        for (std::size_t i = 0; i < u2.totalSize; ++i) scale2 += std::fabs(static_cast<double>(u2.cdata()[i]));
+        CHECK(std::fabs(gr - u2.sum()) <= 1e-15 * scale2);
+        // a by-value parameter bound to the temporary is a NAMED array: it may be read after its sum
+        auto both = [](sm::SMArray<T> v) { const double s = v.sum(); return s + static_cast<double>(v(0, 0)); };
+        CHECK(std::fabs(both(A - B) - (t1.sum() + static_cast<double>(t1(0, 0)))) <= 1e-15 * scale + 1e-9);
     }
     {   // a named operand is not a temporary: computed by itself, as before
         Delta d;

@@ -254,6 +254,36 @@ def test_chain_pow_stages(smhip, oracle):
         smhip.chain(dA, (sma.OP_POW, dB))  # an array exponent is not a chain stage
 
 
+def test_chain_sum(smhip, oracle):
+    """The sum of a chain's value without writing it (smhip_chain_sum): one pass for dense / scalar operands, the chain into a
+    temporary and its sum otherwise -- against the oracle's sum of the oracle's chain (fp64 accumulation, any order; integers
+    exactly, modulo 2^64), for sizes with and without a tail, the squared error among them."""
+    rng = np.random.default_rng(31)
+    for dt in DTYPES:
+        for shape in [(70, 96), (1, 5), (33, 1), (257, 1031), (1 << 20,)]:
+            A, B = _rand(rng, shape, dt), _rand(rng, shape, dt)
+            dA, dB = smhip.to_device(A), smhip.to_device(B)
+            two = dt(2)
+            cases = [[(sma.OP_SUB, dB), (sma.OP_POW, two)],                          # the squared error: one pass
+                     [(sma.OP_MUL, dB), (sma.OP_ADD, dA), (sma.OP_MUL, dt(3))],       # dense + scalar stages
+                     [(sma.OP_ADD, dt(1)), (sma.OP_SUB, dB, True)]]                   # swapped
+            if len(shape) == 2 and shape[1] > 1:
+                row = _rand(rng, (1, shape[1]), dt)
+                cases.append([(sma.OP_MUL, smhip.to_device(row)), (sma.OP_ADD, dB)])  # a row operand: chain, then sum
+            for stages in cases:
+                got = smhip.chain_sum(dA, *stages)
+                r = np.ascontiguousarray(A)
+                for st in stages:
+                    if st[0] == sma.OP_POW:  # ^2: one product
+                        r = oracle.binary(orc.MUL, r, r)
+                    else:
+                        x = st[1].numpy() if isinstance(st[1], sma.DeviceArray) else st[1]
+                        r = _oracle_chain(oracle, r, [(st[0], x) + tuple(st[2:])])
+                want = oracle.sum(np.ascontiguousarray(r).reshape(-1))
+                scale = float(np.abs(r.astype(np.float64)).sum())
+                assert abs(got - want) <= 1e-15 * scale + 1e-300, (np.dtype(dt).name, shape, got, want)
+
+
 def test_chain_errors(smhip):
     a = smhip.to_device(np.ones((4, 4), np.float32))
     b = smhip.to_device(np.ones((3, 4), np.float32))
