@@ -660,13 +660,31 @@ int try_chain_sum(const Problem &pb, int n_operands, const void *const *operands
     if (int rc = lease.take(grid + grid / kReduceFoldSpan + 2, &scratch)) return rc;
     typedef typename ChainAcc<T>::type Acc;
     Acc *partials = reinterpret_cast<Acc *>(scratch);
-    switch (nd) {
-        case 1: hipLaunchKernelGGL((chain_sum_kernel<T, 1>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
-        case 2: hipLaunchKernelGGL((chain_sum_kernel<T, 2>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
-        case 3: hipLaunchKernelGGL((chain_sum_kernel<T, 3>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
-        default: hipLaunchKernelGGL((chain_sum_kernel<T, 4>), dim3((unsigned)grid), dim3(kChainSumBlock), 0, s, A, partials, n_vec, tail, pol); break;
+    // very large arrays in pieces, like every streaming kernel (internal.h: piece_for): a piece is a whole number of workgroups,
+    // its partials follow the previous piece's
+    size_t piece = piece_for(n_vec, nd < 3 ? nd : 3);
+    if (piece == 0 || piece >= n_vec) piece = n_vec ? n_vec : 1;
+    piece = (piece + kChainSumBlock - 1) / kChainSumBlock * kChainSumBlock;
+    const T *dense0[kMaxDense];
+    for (int k = 0; k < kMaxDense; ++k) dense0[k] = A.dense[k];
+    for (size_t v0 = 0;; v0 += piece) {
+        const bool last = v0 + piece >= n_vec;
+        const size_t nv = last ? n_vec - v0 : piece;
+        const int tl = last ? tail : 0;
+        const size_t blocks = (nv + (tl ? 1 : 0) + kChainSumBlock - 1) / kChainSumBlock;
+        for (int k = 0; k < nd; ++k) A.dense[k] = dense0[k] + v0 * W;
+        Acc *part = partials + v0 / kChainSumBlock;
+        if (blocks) {
+            switch (nd) {
+                case 1: hipLaunchKernelGGL((chain_sum_kernel<T, 1>), dim3((unsigned)blocks), dim3(kChainSumBlock), 0, s, A, part, nv, tl, pol); break;
+                case 2: hipLaunchKernelGGL((chain_sum_kernel<T, 2>), dim3((unsigned)blocks), dim3(kChainSumBlock), 0, s, A, part, nv, tl, pol); break;
+                case 3: hipLaunchKernelGGL((chain_sum_kernel<T, 3>), dim3((unsigned)blocks), dim3(kChainSumBlock), 0, s, A, part, nv, tl, pol); break;
+                default: hipLaunchKernelGGL((chain_sum_kernel<T, 4>), dim3((unsigned)blocks), dim3(kChainSumBlock), 0, s, A, part, nv, tl, pol); break;
+            }
+            SMHIP_LAUNCH_CHECK("chain_sum_kernel");
+        }
+        if (last) break;
     }
-    SMHIP_LAUNCH_CHECK("chain_sum_kernel");
     *done = true;
     return reduce_finish(pb.dtype, scratch, grid, sum_dev, s);
 }

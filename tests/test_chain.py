@@ -284,6 +284,24 @@ def test_chain_sum(smhip, oracle):
                 assert abs(got - want) <= 1e-15 * scale + 1e-300, (np.dtype(dt).name, shape, got, want)
 
 
+def test_chain_sum_in_pieces():
+    """Very large arrays go out in pieces (internal.h: piece_for); SMHIP_PIECE_LOG2VEC=12 cuts a 300 001-element sum into 19 launches
+    whose partials must line up."""
+    import os, subprocess, sys
+    code = ("import numpy as np, simplemath_amd as sma\n"
+            "lib = sma.load()\n"
+            "rng = np.random.default_rng(3)\n"
+            "for dt in (np.float32, np.float64, np.int32):\n"
+            "    a = (rng.uniform(-2, 2, 300001) * (50 if dt == np.int32 else 1)).astype(dt); b = (rng.uniform(-2, 2, 300001) * (50 if dt == np.int32 else 1)).astype(dt)\n"
+            "    got = lib.chain_sum(lib.to_device(a), (sma.OP_SUB, lib.to_device(b)), (sma.OP_POW, dt(2)))\n"
+            "    d = (a - b); want = float(np.sum((d * d).astype(np.float64)))\n"
+            "    assert abs(got - want) <= 1e-12 * abs(want) + 1e-9, (dt, got, want)\n"
+            "print('pieces ok')\n")
+    env = dict(os.environ, SMHIP_PIECE_LOG2VEC="12", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "pieces ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_chain_errors(smhip):
     a = smhip.to_device(np.ones((4, 4), np.float32))
     b = smhip.to_device(np.ones((3, 4), np.float32))
