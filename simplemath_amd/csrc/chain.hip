@@ -238,33 +238,53 @@ template <int CTRL, int ROW_MASK, typename A> __device__ __forceinline__ A chain
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
     return __builtin_bit_cast(A, ((unsigned long long)hi << 32) | lo);
 }
-constexpr int kChainSumBlock = 256;
+constexpr int kChainSumBlock = 256, kChainSumU = 4;  // vectors per lane: a quarter of the partials, and a lane's loads all in flight together
 template <typename T, int ND>
 __global__ __launch_bounds__(kChainSumBlock) void chain_sum_kernel(ChainArgs<T> A, typename ChainAcc<T>::type *__restrict__ partials, size_t n_vec, int tail, int pol) {
     typedef typename VecTraits<T>::vec_t V;
     typedef typename VecTraits<T>::full_t F;
     typedef typename ChainAcc<T>::type Acc;
-    constexpr int W = VecTraits<T>::width;
-    const size_t i = (size_t)blockIdx.x * kChainSumBlock + threadIdx.x;
+    constexpr int W = VecTraits<T>::width, U = kChainSumU;
+    const size_t base = (size_t)blockIdx.x * (kChainSumBlock * U) + threadIdx.x;
     Acc acc = 0;
-    F d[ND], r[1], s[1];
-    if (i < n_vec) {
+    F r[1], s[1];
+    if (((size_t)blockIdx.x + 1) * (kChainSumBlock * U) <= n_vec) {  // a whole tile: no guards, every load of the lane goes out first
+        F d[U][ND];
         if (pol & kLoadNt) {
 #pragma unroll
-            for (int k = 0; k < ND; ++k) d[k] = load_stream_as(T, reinterpret_cast<const V *>(A.dense[k]) + i, true);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < ND; ++k) d[u][k] = load_stream_as(T, reinterpret_cast<const V *>(A.dense[k]) + base + (size_t)u * kChainSumBlock, true);
         } else {
 #pragma unroll
-            for (int k = 0; k < ND; ++k) d[k] = load_stream_as(T, reinterpret_cast<const V *>(A.dense[k]) + i, false);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < ND; ++k) d[u][k] = load_stream_as(T, reinterpret_cast<const V *>(A.dense[k]) + base + (size_t)u * kChainSumBlock, false);
         }
-        const F v = chain_eval<T, ND, 0, 0>(A, d, r, s);
 #pragma unroll
-        for (int e = 0; e < W; ++e) acc += chain_widen<T, Acc>(v[e]);
-    } else if (i == n_vec && tail) {  // the n % W elements past the last whole vector
+        for (int u = 0; u < U; ++u) {
+            const F v = chain_eval<T, ND, 0, 0>(A, d[u], r, s);
 #pragma unroll
-        for (int k = 0; k < ND; ++k)
-            for (int e = 0; e < W; ++e) d[k][e] = e < tail ? A.dense[k][n_vec * W + e] : T(1);
-        const F v = chain_eval<T, ND, 0, 0>(A, d, r, s);
-        for (int e = 0; e < tail; ++e) acc += chain_widen<T, Acc>(v[e]);
+            for (int e = 0; e < W; ++e) acc += chain_widen<T, Acc>(v[e]);
+        }
+    } else {
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * kChainSumBlock;
+            F d[ND];
+            if (i < n_vec) {
+#pragma unroll
+                for (int k = 0; k < ND; ++k) d[k] = load_stream(reinterpret_cast<const V *>(A.dense[k]) + i);
+                const F v = chain_eval<T, ND, 0, 0>(A, d, r, s);
+#pragma unroll
+                for (int e = 0; e < W; ++e) acc += chain_widen<T, Acc>(v[e]);
+            } else if (i == n_vec && tail) {  // the n % W elements past the last whole vector
+#pragma unroll
+                for (int k = 0; k < ND; ++k)
+                    for (int e = 0; e < W; ++e) d[k][e] = e < tail ? A.dense[k][n_vec * W + e] : T(1);
+                const F v = chain_eval<T, ND, 0, 0>(A, d, r, s);
+                for (int e = 0; e < tail; ++e) acc += chain_widen<T, Acc>(v[e]);
+            }
+        }
     }
     acc += chain_dpp<0x111, 0xf>(acc);  // row_shr:1, 2, 4, 8, then row_bcast:15 and :31 -- the wave's total ends up in lane 63
     acc += chain_dpp<0x112, 0xf>(acc);
@@ -651,7 +671,8 @@ int try_chain_sum(const Problem &pb, int n_operands, const void *const *operands
     }
     const size_t n_vec = pb.n / W;
     const int tail = (int)(pb.n % W);
-    const size_t grid = (n_vec + (tail ? 1 : 0) + kChainSumBlock - 1) / kChainSumBlock;
+    constexpr size_t kTile = (size_t)kChainSumBlock * kChainSumU;  // vectors per workgroup
+    const size_t grid = (n_vec + (tail ? 1 : 0) + kTile - 1) / kTile;
     if (grid == 0 || grid > 0x7fffffffu) return SMHIP_OK;
     int pol = stream_policy((size_t)nd * pb.n * sizeof(T), 0);
     pol = refine_policy(pol, reads.data(), reads.size(), {nullptr, 0});
@@ -664,16 +685,16 @@ int try_chain_sum(const Problem &pb, int n_operands, const void *const *operands
     // its partials follow the previous piece's
     size_t piece = piece_for(n_vec, nd < 3 ? nd : 3);
     if (piece == 0 || piece >= n_vec) piece = n_vec ? n_vec : 1;
-    piece = (piece + kChainSumBlock - 1) / kChainSumBlock * kChainSumBlock;
+    piece = (piece + kTile - 1) / kTile * kTile;
     const T *dense0[kMaxDense];
     for (int k = 0; k < kMaxDense; ++k) dense0[k] = A.dense[k];
     for (size_t v0 = 0;; v0 += piece) {
         const bool last = v0 + piece >= n_vec;
         const size_t nv = last ? n_vec - v0 : piece;
         const int tl = last ? tail : 0;
-        const size_t blocks = (nv + (tl ? 1 : 0) + kChainSumBlock - 1) / kChainSumBlock;
+        const size_t blocks = (nv + (tl ? 1 : 0) + kTile - 1) / kTile;
         for (int k = 0; k < nd; ++k) A.dense[k] = dense0[k] + v0 * W;
-        Acc *part = partials + v0 / kChainSumBlock;
+        Acc *part = partials + v0 / kTile;
         if (blocks) {
             switch (nd) {
                 case 1: hipLaunchKernelGGL((chain_sum_kernel<T, 1>), dim3((unsigned)blocks), dim3(kChainSumBlock), 0, s, A, part, nv, tl, pol); break;
